@@ -1,0 +1,81 @@
+"""ctypes loader for libgprhip.so (the HIP/CDNA4 kernels + C-ABI, include/gpr_hip.h).
+
+There is no CPU fallback anywhere in this package: if the library has not been built
+(`python -c "import __graft_entry__ as g; g.build()"` or `make -C gpr_calculator_amd/csrc`)
+every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+# torch first: its bundled libamdhip64.so.7 must be the HIP runtime the whole process shares
+import torch  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgprhip.so")
+_lib = None
+
+c_double_p = C.POINTER(C.c_double)
+c_int_p = C.POINTER(C.c_int)
+
+
+class KernelParams(C.Structure):
+    """struct gpr_kernel_params (include/gpr_hip.h)."""
+    _fields_ = [("kind", C.c_int), ("zeta", C.c_double), ("sigma", C.c_double), ("l", C.c_double),
+                ("sigma0", C.c_double), ("tol", C.c_double)]
+
+
+KERNEL_RBF, KERNEL_DOT = 0, 1
+ROLE_STREAM, ROLE_RESIDENT = 0, 1
+SET_NUMPY_EPS = 1
+
+_vp, _i, _d, _ll = C.c_void_p, C.c_int, C.c_double, C.c_longlong
+_L1_SIGNATURES = {
+    "gpr_last_error": ([], C.c_char_p),
+    "gpr_build_info": ([], C.c_char_p),
+    "gpr_device_count": ([], _i),
+    "gpr_set_create": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _i], _i),
+    "gpr_set_destroy": ([_vp, _vp], _i),
+    "gpr_set_info": ([_vp, c_int_p, c_int_p, c_int_p, C.POINTER(_ll)], _i),
+    "gpr_block_ee": ([_vp, C.POINTER(KernelParams), _vp, _vp, _i, _vp, _ll, _vp, _ll], _i),
+    "gpr_block_ef": ([_vp, C.POINTER(KernelParams), _vp, _vp, _i, _vp, _ll, _vp, _ll], _i),
+    "gpr_block_ff": ([_vp, C.POINTER(KernelParams), _vp, _vp, _i, _vp, _ll, _vp, _ll], _i),
+    "gpr_diag_ff": ([_vp, C.POINTER(KernelParams), _vp, _vp, _vp], _i),
+    "gpr_diag_ee": ([_vp, C.POINTER(KernelParams), _vp, _vp, _vp], _i),
+    "gpr_potrf_lower": ([_vp, _i, _vp, _ll, _vp], _i),
+    "gpr_trsm_lower": ([_vp, _i, _i, _i, _vp, _ll, _vp, _ll], _i),
+    "gpr_gemm": ([_vp, _i, _i, _i, _i, _i, _d, _vp, _ll, _vp, _ll, _d, _vp, _ll], _i),
+    "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),
+    "gpr_colsumsq": ([_vp, _i, _i, _vp, _ll, _vp], _i),
+    "gpr_sum_log_diag": ([_vp, _i, _vp, _ll, _vp], _i),
+}
+
+
+class GprHipError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library (loads on first use; raises if it was never built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GprHipError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()'). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (args, res) in _L1_SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.argtypes, fn.restype = args, res
+        _lib = handle
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().gpr_last_error()
+        raise GprHipError(f"{what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise GprHipError("no HIP device visible: gpr_calculator_amd computes on the GPU only")

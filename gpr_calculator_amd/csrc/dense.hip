@@ -1,0 +1,320 @@
+// dense.hip -- FP64 dense linear algebra of GP.fit / GP.predict on the matrix cores:
+// Cholesky factor, triangular solves, GEMM, and the small reductions around them.
+// Replaces scipy.linalg.cholesky / cho_solve / solve_triangular and the numpy products of
+// gaussianprocess.py:128-131, 288-299, 880, 903-907.  Row-major storage throughout.
+#include "gpr_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = BM + 16;   // +16 doubles: rows k, k+1 hit disjoint banks
+constexpr int NB = 64;                                        // Cholesky / TRSM panel width
+
+// C[m,n] = alpha * op(A) op(B) + beta * C ;  op(A) is m x k, op(B) is k x n
+// one 64x64 C tile per 256-thread workgroup; each wavefront owns a 32x32 quadrant = 2x2 MFMA tiles
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double alpha,
+                                                    const double *__restrict__ A, long long lda,
+                                                    const double *__restrict__ B, long long ldb,
+                                                    double beta, double *__restrict__ C, long long ldc,
+                                                    int lower_only) {
+    __shared__ double As[BK][LDS_LD];
+    __shared__ double Bs[BK][LDS_LD];
+    const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
+    if (lower_only && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    for (int k0 = 0; k0 < k; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int mm, kk;
+            if (!TA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
+            else     { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+            const int gm = bm0 + mm, gk = k0 + kk;
+            double v = 0.0;
+            if (gm < m && gk < k) v = TA ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk];
+            As[kk][mm] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            int nn, kk;
+            if (!TB) { nn = tid & 63; kk = (tid >> 6) + 4 * i; }
+            else     { kk = tid & 15; nn = (tid >> 4) + 16 * i; }
+            const int gn = bn0 + nn, gk = k0 + kk;
+            double v = 0.0;
+            if (gn < n && gk < k) v = TB ? B[(long long)gn * ldb + gk] : B[(long long)gk * ldb + gn];
+            Bs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < BK / 4; ks++) {
+            const int kr = ks * 4 + (lane >> 4);
+            double a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; i++) a[i] = As[kr][wm + i * 16 + (lane & 15)];
+#pragma unroll
+            for (int j = 0; j < 2; j++) b[j] = Bs[kr][wn + j * 16 + (lane & 15)];
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gm = bm0 + wm + i * 16 + (lane >> 4) + 4 * r;
+                const int gn = bn0 + wn + j * 16 + (lane & 15);
+                if (gm < m && gn < n) {
+                    double *c = C + (long long)gm * ldc + gn;
+                    const double v = alpha * acc[i][j][r];
+                    *c = (beta == 0.0) ? v : v + beta * *c;
+                }
+            }
+}
+
+// unblocked Cholesky of the kb x kb diagonal block at a (lower), one workgroup
+__global__ void __launch_bounds__(256) potrf_diag_kernel(double *a, long long lda, int kb, int k0, int *info) {
+    __shared__ double T[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kb * kb; e += 256) { int i = e / kb, j = e % kb; T[i][j] = a[(long long)i * lda + j]; }
+    __syncthreads();
+    for (int j = 0; j < kb; j++) {
+        if (tid == 0) {
+            double p = T[j][j];
+            if (!(p > 0.0)) { if (info) atomicCAS(info, 0, k0 + j + 1); }
+            T[j][j] = sqrt(p);
+        }
+        __syncthreads();
+        const double piv = T[j][j];
+        if (tid > j && tid < kb) T[tid][j] /= piv;
+        __syncthreads();
+        const int rem = kb - j - 1;
+        for (int e = tid; e < rem * rem; e += 256) {
+            int i = j + 1 + e / rem, c = j + 1 + e % rem;
+            if (c <= i) T[i][c] -= T[i][j] * T[c][j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < kb * kb; e += 256) {
+        int i = e / kb, j = e % kb;
+        a[(long long)i * lda + j] = (j <= i) ? T[i][j] : 0.0;
+    }
+}
+
+// panel solve X L^T = P for the rows below the diagonal block: one thread per row
+__global__ void __launch_bounds__(256) potrf_panel_kernel(const double *lkk, double *p, long long lda, int kb, int rows) {
+    __shared__ double L[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kb * kb; e += 256) { int i = e / kb, j = e % kb; L[i][j] = lkk[(long long)i * lda + j]; }
+    __syncthreads();
+    const int r = blockIdx.x * 256 + tid;
+    if (r >= rows) return;
+    double *x = p + (long long)r * lda;
+    double xr[NB];
+    for (int c = 0; c < kb; c++) {
+        double v = x[c];
+        for (int q = 0; q < c; q++) v -= xr[q] * L[c][q];
+        xr[c] = v / L[c][c];
+    }
+    for (int c = 0; c < kb; c++) x[c] = xr[c];
+}
+
+// diagonal-block solve of the blocked TRSM: one thread per right-hand-side column
+// trans = 0: L x = b (forward) ; trans = 1: L^T x = b (backward)
+__global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double *lkk, long long ldl, int kb,
+                                                         double *b, long long ldb, int nrhs) {
+    __shared__ double L[NB][NB + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < kb * kb; e += 256) { int i = e / kb, j = e % kb; L[i][j] = lkk[(long long)i * ldl + j]; }
+    __syncthreads();
+    const int col = blockIdx.x * 256 + tid;
+    if (col >= nrhs) return;
+    double x[NB];
+    if (!trans) {
+        for (int i = 0; i < kb; i++) {
+            double v = b[(long long)i * ldb + col];
+            for (int q = 0; q < i; q++) v -= L[i][q] * x[q];
+            x[i] = v / L[i][i];
+        }
+    } else {
+        for (int i = kb - 1; i >= 0; i--) {
+            double v = b[(long long)i * ldb + col];
+            for (int q = i + 1; q < kb; q++) v -= L[q][i] * x[q];
+            x[i] = v / L[i][i];
+        }
+    }
+    for (int i = 0; i < kb; i++) b[(long long)i * ldb + col] = x[i];
+}
+
+__global__ void zero_upper_kernel(int n, double *a, long long lda) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < n && j > i) a[(long long)i * lda + j] = 0.0;
+}
+
+__global__ void add_diag_kernel(int n, double *a, long long lda, int n_first, double v1, double v2) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[(long long)i * lda + i] += (i < n_first) ? v1 : v2;
+}
+
+// column sums of squares: thread per column, rows split over blockIdx.y with a fixed-order second pass
+__global__ void colsumsq_partial_kernel(int n, int ncols, const double *v, long long ldv, double *part, int rows_per) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
+    double acc = 0.0;
+    for (int i = r0; i < r1; i++) { double t = v[(long long)i * ldv + j]; acc += t * t; }
+    part[(long long)blockIdx.y * ncols + j] = acc;
+}
+__global__ void colsum_final_kernel(int nparts, int ncols, const double *part, double *out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    double acc = 0.0;
+    for (int p = 0; p < nparts; p++) acc += part[(long long)p * ncols + j];
+    out[j] = acc;
+}
+
+__global__ void __launch_bounds__(256) sum_log_diag_kernel(int n, const double *a, long long lda, double *out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += log(a[(long long)i * lda + i]);
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
+                const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
+    if (m <= 0 || n <= 0) return GPR_OK;
+    dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM), block(256);
+    if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+    else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+    else if (ta && !tb) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+    else hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("gemm launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}
+
+#define LAUNCH_CHECK(name)                                                                   \
+    do { hipError_t _e = hipGetLastError();                                                  \
+         if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
+
+}  // namespace
+
+extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
+                        const double *a, long long lda, const double *b, long long ldb, double beta,
+                        double *c, long long ldc) {
+    GPR_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gpr_gemm: negative dimension");
+    GPR_REQUIRE(m == 0 || n == 0 || (c && (k == 0 || (a && b))), "gpr_gemm: null pointer");
+    return launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
+}
+
+// Blocked right-looking lower Cholesky: diagonal block (one workgroup), panel solve, then the
+// trailing update A22 -= P P^T on the matrix cores (lower tiles only).
+extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(n >= 0 && (n == 0 || a) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
+    if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int kb = (n - k0 < NB) ? n - k0 : NB;
+        double *akk = a + (long long)k0 * lda + k0;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, akk, lda, kb, k0, info_dev);
+        LAUNCH_CHECK("potrf_diag");
+        const int rows = n - k0 - kb;
+        if (rows > 0) {
+            double *p = a + (long long)(k0 + kb) * lda + k0;
+            hipLaunchKernelGGL(potrf_panel_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, akk, p, lda, kb, rows);
+            LAUNCH_CHECK("potrf_panel");
+            double *a22 = a + (long long)(k0 + kb) * lda + (k0 + kb);
+            int rc = launch_gemm(st, 0, 1, rows, rows, kb, -1.0, p, lda, p, lda, 1.0, a22, lda, 1);
+            if (rc) return rc;
+        }
+    }
+    if (n > 1) {
+        hipLaunchKernelGGL(zero_upper_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
+        LAUNCH_CHECK("zero_upper");
+    }
+    return GPR_OK;
+}
+
+extern "C" int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
+                              double *b, long long ldb) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(n >= 0 && nrhs >= 0, "gpr_trsm_lower: negative dimension");
+    if (n == 0 || nrhs == 0) return GPR_OK;
+    GPR_REQUIRE(l && b && ldl >= n && ldb >= nrhs, "gpr_trsm_lower: bad arguments");
+    const int nblk = (n + NB - 1) / NB;
+    for (int ib = 0; ib < nblk; ib++) {
+        const int blk = trans ? nblk - 1 - ib : ib;
+        const int k0 = blk * NB, kb = (n - k0 < NB) ? n - k0 : NB;
+        const double *lkk = l + (long long)k0 * ldl + k0;
+        double *bk = b + (long long)k0 * ldb;
+        hipLaunchKernelGGL(trsm_diag_kernel, dim3((nrhs + 255) / 256), dim3(256), 0, st, trans, lkk, ldl, kb, bk, ldb, nrhs);
+        LAUNCH_CHECK("trsm_diag");
+        int rc = GPR_OK;
+        if (!trans) {
+            const int rows = n - k0 - kb;     // B[k0+kb:, :] -= L[k0+kb:, k0:k0+kb] X_k
+            if (rows > 0)
+                rc = launch_gemm(st, 0, 0, rows, nrhs, kb, -1.0, l + (long long)(k0 + kb) * ldl + k0, ldl, bk, ldb,
+                                 1.0, b + (long long)(k0 + kb) * ldb, ldb, 0);
+        } else {
+            if (k0 > 0)                        // B[:k0, :] -= L[k0:k0+kb, :k0]^T X_k
+                rc = launch_gemm(st, 1, 0, k0, nrhs, kb, -1.0, l + (long long)k0 * ldl, ldl, bk, ldb, 1.0, b, ldb, 0);
+        }
+        if (rc) return rc;
+    }
+    return GPR_OK;
+}
+
+extern "C" int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, double add_first,
+                            double add_rest) {
+    if (n <= 0) return GPR_OK;
+    GPR_REQUIRE(a && lda >= n, "gpr_add_diag: bad arguments");
+    hipLaunchKernelGGL(add_diag_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, a, lda, n_first,
+                       add_first, add_rest);
+    LAUNCH_CHECK("add_diag");
+    return GPR_OK;
+}
+
+extern "C" int gpr_colsumsq(void *stream, int n, int ncols, const double *v, long long ldv, double *out) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ncols <= 0) return GPR_OK;
+    GPR_REQUIRE(out && (n == 0 || v), "gpr_colsumsq: null pointer");
+    const int rows_per = 512;
+    const int nparts = (n + rows_per - 1) / rows_per > 0 ? (n + rows_per - 1) / rows_per : 1;
+    void *part;
+    int rc = gpr_dev_alloc(&part, (size_t)nparts * ncols * 8, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsumsq_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, v, ldv,
+                       (double *)part, rows_per);
+    LAUNCH_CHECK("colsumsq_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
+                       (const double *)part, out);
+    LAUNCH_CHECK("colsum_final");
+    return gpr_dev_free(part, st);
+}
+
+extern "C" int gpr_sum_log_diag(void *stream, int n, const double *a, long long lda, double *out) {
+    GPR_REQUIRE(out && (n == 0 || a), "gpr_sum_log_diag: null pointer");
+    hipLaunchKernelGGL(sum_log_diag_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, a, lda, out);
+    LAUNCH_CHECK("sum_log_diag");
+    return GPR_OK;
+}

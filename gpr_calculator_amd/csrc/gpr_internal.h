@@ -1,0 +1,89 @@
+// gpr_internal.h -- shared declarations of libgprhip.so (not part of the public C-ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <climits>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "gpr_hip.h"
+
+// ---------------------------------------------------------------- error plumbing
+void gpr_set_error(const char *fmt, ...);
+
+#define GPR_HIP_TRY(expr)                                                                    \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            gpr_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #expr,                 \
+                          hipGetErrorString(_e));                                            \
+            return GPR_ERR_HIP;                                                              \
+        }                                                                                    \
+    } while (0)
+
+#define GPR_REQUIRE(cond, ...)                                                               \
+    do {                                                                                     \
+        if (!(cond)) {                                                                       \
+            gpr_set_error(__VA_ARGS__);                                                      \
+            return GPR_ERR_ARG;                                                              \
+        }                                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------- geometry constants
+constexpr int GPR_WAVE = 64;
+constexpr int GPR_KSTEPS = 8;          // descriptor length padded to 4*KSTEPS = 32 (d <= 32)
+constexpr int GPR_KPAD = 4 * GPR_KSTEPS;
+constexpr int GPR_PLANE = GPR_KSTEPS * GPR_WAVE;   // doubles per 16x(4*KSTEPS) operand plane (4 KiB)
+constexpr int GPR_CHUNK_TILES = 8;     // stream tiles staged per LDS buffer (32 KiB)
+constexpr int GPR_GROUP_ROWS = 16;     // rows per resident group (one MFMA N extent)
+constexpr int GPR_ELE_PAD_STREAM = INT_MIN;        // species code of padded / skipped stream rows
+constexpr int GPR_ELE_PAD_RESIDENT = INT_MIN + 1;  // ... resident rows (never equal to the above)
+
+// chunk descriptor of the stream side: tiles [tile0, tile0+ntiles) all belong to packed point `pt`
+struct gpr_chunk { int tile0, ntiles, pt, last; };
+// resident point descriptor: groups [group0, group0+ngroups)
+struct gpr_rpoint { int group0, ngroups; };
+
+struct gpr_set {
+    int role, d, width, col0, nc, flags;
+    int npts, nrows, rpad;
+    int tile_rows;     // rows per operand plane on this side (stream force: 4, otherwise 16)
+    int nunits;        // number of planes-groups: stream tiles or resident groups
+    // device arrays
+    double *ops = nullptr;     // stream: [ntiles][KSTEPS][64]; resident: [ngroups][nc][KSTEPS][64]
+    int *ele = nullptr;        // [rpad]
+    double *norms = nullptr;   // [rpad] effective row norms (used by the numpy-eps ee variant)
+    int *perm = nullptr;       // [npts] packed position -> caller's point index
+    double *inv_cnt = nullptr; // [npts] 1/rows of the point, packed order
+    gpr_chunk *chunks = nullptr;    // stream only
+    int *pt_chunk0 = nullptr;       // stream only [npts+1]
+    gpr_rpoint *rpts = nullptr;     // resident only [npts]
+    int nchunks = 0, maxgroups = 0;
+    // host mirrors used for launch planning
+    std::vector<int> h_perm, h_cnt, h_pt_chunk0, h_pt_tiles, h_groups;
+    long long bytes = 0;
+};
+
+// ---------------------------------------------------------------- internal block launcher
+enum { GPR_MODE_FF = 0, GPR_MODE_EF = 1, GPR_MODE_EE = 2 };
+
+struct gpr_block_call {
+    int mode;
+    const gpr_set *s1, *s2;
+    int kind;                 // gpr_kernel_kind
+    double zeta, sigma2, l, l2, sigma02, tol;   // l2 = l*l as the caller computed it (natives take l2)
+    int grad;                 // also produce the l-derivative (RBF only)
+    int symmetric, diag_only;
+    double scale, dl_scale;   // global factors on the value / derivative outputs
+    int norm1, norm2;         // multiply by 1/count of the stream / resident point
+    int eps_mode;             // numpy-eps cosine (ee diag only)
+    double *out; long long s_i, s_j, s_a, s_b;      // element strides of the value output
+    double *dl;  long long d_i, d_j, d_a, d_b;      // ... of the derivative output
+};
+// zero-fills nothing: the caller has already zeroed the output; bins are accumulated with RMW adds
+int gpr_launch_block(hipStream_t st, const gpr_block_call &c);
+
+// small helpers
+int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
+int gpr_dev_free(void *p, hipStream_t st);

@@ -1,0 +1,396 @@
+// kblock.hip -- covariance-block kernels (energy-energy, energy-force, force-force; RBF and Dot)
+// on the FP64 matrix cores of gfx950.
+//
+// Replaces the row-pair loop nests of rbf_kee/kef/kff_many(+_with_grad) (rbf_kernel.cpp:5-640) and
+// dot_kee/kef/kff_many (dot_kernel.cpp:5-336).  Formulation (restated for
+// the projected operands of pack.hip): for a row pair (a, b) the 4x4 product
+//        [A'^T ; a~^T] (4 x d)  *  [B' , b~] (d x 4)
+// yields G = A'^T B' (3x3), w = A'^T b~ (3), z = a~^T B' (3) and the cosine c, and
+//        force-force 3x3 block = alpha * G + beta * w z^T
+//        energy-force 3-vector = coef * z
+//        energy-energy scalar  = k(c)
+// with alpha, beta, coef, k scalar functions of c (one exp for RBF).  The 4x4 products of a
+// 4-row x 16-row tile are four v_mfma_f64_16x16x4_f64 accumulators whose C/D layout leaves all 16
+// numbers of ONE row pair in ONE lane, so the scalar epilogue needs no cross-lane traffic.
+//
+// Work decomposition: one wavefront owns one resident ("set 2") point j and keeps the MFMA B
+// operands of one 16-row group of it in registers; the workgroup streams the tiles of the
+// stream ("set 1") points through double-buffered LDS; each wavefront accumulates the bin (i, j)
+// in registers and, at the last tile of point i, reduces over its 64 lanes and adds the 3x3
+// (3, 1) result to the output with a plain read-modify-write (exactly one wavefront ever touches a
+// bin, so no atomics and a deterministic summation order).
+#include "gpr_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct kb_args {
+    const double *a_ops; const int *a_ele; const double *a_norm; const gpr_chunk *a_chunks;
+    const int *a_perm; const double *a_inv; const int *a_pt_chunk0;
+    const double *b_ops; const int *b_ele; const double *b_norm; const gpr_rpoint *b_pts;
+    const int *b_perm; const double *b_inv;
+    int b_npts, a_npts;
+    const int *ir_chunk0;   // [nir+1] chunk range of each stream range
+    const int *ir_pt0;      // [nir+1] first packed point of each stream range
+    int njb, nir;
+    int symmetric, diag_only, eps_mode, norm1, norm2;
+    double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
+    double scale, dl_scale;
+    double *out; long long s_i, s_j, s_a, s_b;
+    double *dl;  long long d_i, d_j, d_a, d_b;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// scalar functions of the cosine c shared by all blocks
+template <int KIND, bool Z2>
+__device__ __forceinline__ void pair_scalars(double c, const kb_args &P, double &D, double &d1,
+                                             double &d2, double &Kv, double &g) {
+    if (Z2) { d1 = c; D = c * c; d2 = 1.0; }
+    else {                                   // rbf_kernel.cpp:400-402
+        double cz2 = pow(c, P.zeta - 2.0);
+        d1 = c * cz2; D = c * d1; d2 = cz2 * (P.zeta - 1.0);
+    }
+    if (KIND == GPR_KERNEL_RBF) {
+        Kv = P.sigma2 * exp((D - 1.0) * P.inv2l2);   // sigma2*exp(-(1-D)/(2 l2))
+        g = Kv * P.inv2l2;                           // dK_dD
+    } else { Kv = 0.0; g = 1.0; }
+}
+
+template <int MODE, int KIND, bool Z2, bool GRAD, int NW>
+__global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
+    constexpr int KS = GPR_KSTEPS;
+    constexpr int NCB = (MODE == GPR_MODE_EE) ? 1 : 4;            // resident planes per group
+    constexpr int NOUT = (MODE == GPR_MODE_FF) ? 9 : (MODE == GPR_MODE_EF ? 3 : 1);
+    constexpr int AROWS = (MODE == GPR_MODE_FF) ? 4 : 16;         // stream rows per tile
+    constexpr int NTHREADS = NW * 64;
+    constexpr int CHUNK_BYTES = GPR_CHUNK_TILES * GPR_PLANE * 8;
+    constexpr int NLD = CHUNK_BYTES / (NTHREADS * 16);
+    static_assert(NLD * NTHREADS * 16 == CHUNK_BYTES, "chunk must divide evenly");
+
+    __shared__ __attribute__((aligned(16))) double sA[2][GPR_CHUNK_TILES * GPR_PLANE];
+    __shared__ int sEle[2][GPR_CHUNK_TILES * 16];
+    __shared__ double sNorm[2][GPR_CHUNK_TILES * 16];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int jb = blockIdx.x % P.njb, ir = blockIdx.x / P.njb;
+    const int jp = jb * NW + wave;                     // packed resident point of this wavefront
+    const bool active = jp < P.b_npts;
+    const int jlast = min((jb + 1) * NW, P.b_npts) - 1;
+
+    int c0, c1;
+    if (P.diag_only) {                                 // only the chunks of this block's own points
+        c0 = P.a_pt_chunk0[jb * NW];
+        c1 = P.a_pt_chunk0[jlast + 1];
+    } else {
+        if (P.symmetric && P.ir_pt0[ir] > jlast) return;   // range entirely below the diagonal
+        c0 = P.ir_chunk0[ir];
+        c1 = P.ir_chunk0[ir + 1];
+    }
+    if (c0 >= c1) return;
+
+    gpr_rpoint pj = active ? P.b_pts[jp] : gpr_rpoint{0, 0};
+    const int maxg = P.b_pts[jb * NW].ngroups;         // packed order is descending in groups
+    const int j_orig = active ? P.b_perm[jp] : 0;
+    const double fac_j = (active && P.norm2) ? P.b_inv[jp] : 1.0;
+
+    for (int g = 0; g < maxg; ++g) {
+        const bool has = active && g < pj.ngroups;
+        double Breg[NCB][KS];
+        int eleB = GPR_ELE_PAD_RESIDENT;
+        double normB = 0.0;
+        if (has) {
+            const double *bp = P.b_ops + (size_t)(pj.group0 + g) * NCB * GPR_PLANE;
+#pragma unroll
+            for (int t = 0; t < NCB; t++)
+#pragma unroll
+                for (int s = 0; s < KS; s++) Breg[t][s] = bp[(t * KS + s) * 64 + lane];
+            eleB = P.b_ele[(pj.group0 + g) * 16 + (lane & 15)];
+            if (MODE == GPR_MODE_EE) normB = P.b_norm[(pj.group0 + g) * 16 + (lane & 15)];
+        } else {
+#pragma unroll
+            for (int t = 0; t < NCB; t++)
+#pragma unroll
+                for (int s = 0; s < KS; s++) Breg[t][s] = 0.0;
+        }
+
+        double bin[NOUT], bin2[GRAD ? NOUT : 1];
+#pragma unroll
+        for (int k = 0; k < NOUT; k++) bin[k] = 0.0;
+#pragma unroll
+        for (int k = 0; k < (GRAD ? NOUT : 1); k++) bin2[k] = 0.0;
+
+        // ---- stage the first chunk
+        float4 regs[NLD];
+        int ereg = 0; double nreg = 0.0;
+        auto stage_load = [&](int c) {
+            const gpr_chunk ch = P.a_chunks[c];
+            const char *src = (const char *)(P.a_ops + (size_t)ch.tile0 * GPR_PLANE);
+            const int bytes = ch.ntiles * GPR_PLANE * 8;
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                int off = (i * NTHREADS + tid) * 16;
+                if (off < bytes) regs[i] = *(const float4 *)(src + off);
+            }
+            if (tid < ch.ntiles * AROWS) {
+                ereg = P.a_ele[ch.tile0 * AROWS + tid];
+                if (MODE == GPR_MODE_EE) nreg = P.a_norm[ch.tile0 * AROWS + tid];
+            }
+        };
+        auto stage_store = [&](int c, int buf) {
+            const gpr_chunk ch = P.a_chunks[c];
+            const int bytes = ch.ntiles * GPR_PLANE * 8;
+            char *dst = (char *)sA[buf];
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                int off = (i * NTHREADS + tid) * 16;
+                if (off < bytes) *(float4 *)(dst + off) = regs[i];
+            }
+            if (tid < ch.ntiles * AROWS) {
+                sEle[buf][tid] = ereg;
+                if (MODE == GPR_MODE_EE) sNorm[buf][tid] = nreg;
+            }
+        };
+        stage_load(c0);
+        stage_store(c0, 0);
+        __syncthreads();
+
+        for (int c = c0; c < c1; ++c) {
+            const int buf = (c - c0) & 1;
+            const gpr_chunk ch = P.a_chunks[c];
+            if (c + 1 < c1) stage_load(c + 1);
+
+            bool mine = has;
+            if (P.symmetric && ch.pt > jp) mine = false;     // below the diagonal
+            if (P.diag_only && ch.pt != jp) mine = false;
+            if (mine) {
+                for (int tile = 0; tile < ch.ntiles; ++tile) {
+                    const double *At = sA[buf] + tile * GPR_PLANE;
+                    d4 acc[NCB];
+#pragma unroll
+                    for (int t = 0; t < NCB; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int s = 0; s < KS; s++) {
+                        const double a = At[s * 64 + lane];
+#pragma unroll
+                        for (int t = 0; t < NCB; t++)
+                            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Breg[t][s], acc[t], 0, 0, 0);
+                    }
+                    if (MODE == GPR_MODE_FF) {
+                        // lane = (stream row lane>>4 of the tile, resident row lane&15);
+                        // acc[t][r]: r = stream component (A'x,A'y,A'z,a~), t = resident component
+                        const int eleA = sEle[buf][tile * 4 + (lane >> 4)];
+                        bool ok = (eleA == eleB);
+                        const double c_ = acc[3][3];
+                        double D, d1, d2, Kv, gg;
+                        pair_scalars<KIND, Z2>(c_, P, D, d1, d2, Kv, gg);
+                        double alpha, beta, alpha2 = 0.0, beta2 = 0.0;
+                        if (KIND == GPR_KERNEL_RBF) {
+                            const double zd1 = P.zeta * d1;
+                            const double cross = zd1 * zd1 * P.inv2l2;   // (1/2l2) dD/dx1 dD/dx2 scale
+                            alpha = gg * zd1;
+                            beta = gg * (P.zeta * d2 + cross);
+                            if (GRAD) {                                   // rbf_kernel.cpp:622-630
+                                const double f = (D - 1.0) * P.inv_l3 + 2.0 * P.inv_l;
+                                alpha2 = -f * alpha;
+                                beta2 = -(f * beta + 2.0 * P.inv_l * gg * cross);
+                            } else {
+                                ok = ok && (gg > P.tol);                  // rbf_kernel.cpp:395
+                            }
+                        } else {                                          // dot_kernel.cpp:285-289
+                            alpha = d1; beta = d2;
+                        }
+                        alpha = ok ? alpha : 0.0; beta = ok ? beta : 0.0;
+                        if (GRAD) { alpha2 = ok ? alpha2 : 0.0; beta2 = ok ? beta2 : 0.0; }
+#pragma unroll
+                        for (int p = 0; p < 3; p++) {
+                            const double bw = beta * acc[3][p];
+                            const double bw2 = GRAD ? beta2 * acc[3][p] : 0.0;
+#pragma unroll
+                            for (int q = 0; q < 3; q++) {
+                                bin[p * 3 + q] += alpha * acc[q][p] + bw * acc[q][3];
+                                if (GRAD) bin2[p * 3 + q] += alpha2 * acc[q][p] + bw2 * acc[q][3];
+                            }
+                        }
+                    } else {
+                        // lane = (stream rows (lane>>4) + 4 r, r < 4 ; resident row lane&15)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int arow = tile * 16 + (lane >> 4) + 4 * r;
+                            const int eleA = sEle[buf][arow];
+                            const bool ok = (eleA == eleB);
+                            double c_ = acc[NCB - 1][r];
+                            if (MODE == GPR_MODE_EE && P.eps_mode) {       // base.py:121, Dot_mb.py:191
+                                const double nn = sNorm[buf][arow] * normB;
+                                c_ = c_ * nn / (1e-8 + nn);
+                            }
+                            double D, d1, d2, Kv, gg;
+                            pair_scalars<KIND, Z2>(c_, P, D, d1, d2, Kv, gg);
+                            if (MODE == GPR_MODE_EF) {
+                                // rbf_kernel.cpp:143-165 (pout -= ...), dot_kernel.cpp:104-122 (+=)
+                                double coef = (KIND == GPR_KERNEL_RBF) ? -gg * P.zeta * d1 : P.zeta * d1;
+                                coef = ok ? coef : 0.0;
+#pragma unroll
+                                for (int q = 0; q < 3; q++) bin[q] += coef * acc[q][r];
+                                if (GRAD) {                                 // rbf_kernel.cpp:245-247
+                                    const double f = (D - 1.0) * P.inv_l3 + 2.0 * P.inv_l;
+                                    const double coef2 = -coef * f;
+#pragma unroll
+                                    for (int q = 0; q < 3; q++) bin2[q] += coef2 * acc[q][r];
+                                }
+                            } else {
+                                double v = (KIND == GPR_KERNEL_RBF) ? Kv : (D + P.sigma02);
+                                bin[0] += ok ? v : 0.0;
+                                if (GRAD) bin2[0] += ok ? Kv * (1.0 - D) : 0.0;   // rbf_kernel.cpp:93
+                            }
+                        }
+                    }
+                }
+                if (ch.last) {
+                    const int i_orig = P.a_perm[ch.pt];
+                    const double fac = fac_j * (P.norm1 ? P.a_inv[ch.pt] : 1.0);
+                    double mineV = 0.0, mineD = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NOUT; k++) {
+                        const double tot = wave_sum(bin[k]);
+                        mineV = (lane == k) ? tot : mineV;
+                        bin[k] = 0.0;
+                        if (GRAD) {
+                            const double tot2 = wave_sum(bin2[k]);
+                            mineD = (lane == k) ? tot2 : mineD;
+                            bin2[k] = 0.0;
+                        }
+                    }
+                    if (lane < NOUT) {
+                        const int a = (MODE == GPR_MODE_FF) ? lane / 3 : 0;
+                        const int b = (MODE == GPR_MODE_FF) ? lane % 3 : lane;
+                        if (P.diag_only) {
+                            if (a == b) P.out[(long long)j_orig * P.s_j + b * P.s_b] += mineV * fac * P.scale;
+                        } else {
+                            double *o = P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b;
+                            *o += mineV * fac * P.scale;
+                            if (P.symmetric && ch.pt != jp) {
+                                double *o2 = P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b;
+                                *o2 += mineV * fac * P.scale;
+                            }
+                            if (GRAD) {
+                                double *q = P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b;
+                                *q += mineD * fac * P.dl_scale;
+                                if (P.symmetric && ch.pt != jp) {
+                                    double *q2 = P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b;
+                                    *q2 += mineD * fac * P.dl_scale;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (c + 1 < c1) stage_store(c + 1, buf ^ 1);
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------- host launcher
+template <int MODE, int KIND, bool Z2, bool GRAD>
+static void launch_nw(hipStream_t st, int nw, int nblocks, const kb_args &a) {
+    if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8>), dim3(nblocks), dim3(512), 0, st, a);
+    else         hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4>), dim3(nblocks), dim3(256), 0, st, a);
+}
+
+template <int MODE, int KIND>
+static void launch_zg(hipStream_t st, bool z2, bool grad, int nw, int nblocks, const kb_args &a) {
+    if (z2) { if (grad) launch_nw<MODE, KIND, true, true>(st, nw, nblocks, a); else launch_nw<MODE, KIND, true, false>(st, nw, nblocks, a); }
+    else    { if (grad) launch_nw<MODE, KIND, false, true>(st, nw, nblocks, a); else launch_nw<MODE, KIND, false, false>(st, nw, nblocks, a); }
+}
+
+int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
+    const gpr_set *s1 = c.s1, *s2 = c.s2;
+    GPR_REQUIRE(s1 && s2, "block: null set");
+    GPR_REQUIRE(s1->role == GPR_ROLE_STREAM && s2->role == GPR_ROLE_RESIDENT,
+                "block: set1 must be packed with role STREAM and set2 with role RESIDENT");
+    GPR_REQUIRE(s1->d == s2->d, "block: descriptor lengths differ (%d vs %d)", s1->d, s2->d);
+    const int nc1 = (c.mode == GPR_MODE_FF) ? 4 : 1, nc2 = (c.mode == GPR_MODE_EE) ? 1 : 4;
+    GPR_REQUIRE(s1->nc == nc1 && s2->nc == nc2, "block: sets have the wrong kind (energy/force) for this block");
+    GPR_REQUIRE(!(c.grad && c.kind != GPR_KERNEL_RBF), "block: length-scale gradient exists for RBF only");
+    GPR_REQUIRE(!c.grad || c.dl, "block: grad requested without dl output");
+    if (c.symmetric || c.diag_only) {
+        GPR_REQUIRE(s1->npts == s2->npts && s1->h_perm == s2->h_perm && s1->h_cnt == s2->h_cnt,
+                    "block: symmetric/diag needs the same points packed in both roles");
+    }
+    if (s1->npts == 0 || s2->npts == 0 || s1->nchunks == 0 || s2->maxgroups == 0) return GPR_OK;
+
+    // workgroup width: 8 wavefronts when that still leaves >= 2 blocks per CU, else 4
+    int nw = (s2->npts >= 8 * 512) ? 8 : 4;
+    if (c.diag_only) nw = 4;
+    const int njb = (s2->npts + nw - 1) / nw;
+
+    // stream ranges: consecutive packed points, about RANGE_TILES tiles each
+    const int RANGE_TILES = 128;
+    std::vector<int> ir_chunk0{0}, ir_pt0{0};
+    if (!c.diag_only) {
+        int tiles = 0;
+        for (int p = 0; p < s1->npts; p++) {
+            tiles += s1->h_pt_tiles[p];
+            if (tiles >= RANGE_TILES && p + 1 < s1->npts) {
+                ir_chunk0.push_back(s1->h_pt_chunk0[p + 1]);
+                ir_pt0.push_back(p + 1);
+                tiles = 0;
+            }
+        }
+    }
+    ir_chunk0.push_back(s1->nchunks);
+    ir_pt0.push_back(s1->npts);
+    const int nir = (int)ir_chunk0.size() - 1;
+
+    int *d_meta = nullptr;
+    std::vector<int> meta(ir_chunk0);
+    meta.insert(meta.end(), ir_pt0.begin(), ir_pt0.end());
+    {
+        void *p;
+        int rc = gpr_dev_alloc(&p, meta.size() * sizeof(int), st);
+        if (rc) return rc;
+        d_meta = (int *)p;
+        GPR_HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        // meta is a host temporary: pageable async copies are staged before return on ROCm, but
+        // be explicit so the vector may die safely
+        GPR_HIP_TRY(hipStreamSynchronize(st));
+    }
+
+    kb_args a;
+    a.a_ops = s1->ops; a.a_ele = s1->ele; a.a_norm = s1->norms; a.a_chunks = s1->chunks;
+    a.a_perm = s1->perm; a.a_inv = s1->inv_cnt; a.a_pt_chunk0 = s1->pt_chunk0;
+    a.b_ops = s2->ops; a.b_ele = s2->ele; a.b_norm = s2->norms; a.b_pts = s2->rpts;
+    a.b_perm = s2->perm; a.b_inv = s2->inv_cnt;
+    a.b_npts = s2->npts; a.a_npts = s1->npts;
+    a.ir_chunk0 = d_meta; a.ir_pt0 = d_meta + (nir + 1);
+    a.njb = njb; a.nir = nir;
+    a.symmetric = c.symmetric; a.diag_only = c.diag_only; a.eps_mode = c.eps_mode;
+    a.norm1 = c.norm1; a.norm2 = c.norm2;
+    a.zeta = c.zeta; a.sigma2 = c.sigma2; a.sigma02 = c.sigma02; a.tol = c.tol;
+    if (c.kind == GPR_KERNEL_RBF) {
+        a.inv2l2 = 1.0 / (2.0 * c.l2); a.inv_l = 1.0 / c.l; a.inv_l3 = a.inv_l / (c.l * c.l);
+    } else { a.inv2l2 = 0.0; a.inv_l = 0.0; a.inv_l3 = 0.0; }
+    a.scale = c.scale; a.dl_scale = c.dl_scale;
+    a.out = c.out; a.s_i = c.s_i; a.s_j = c.s_j; a.s_a = c.s_a; a.s_b = c.s_b;
+    a.dl = c.dl; a.d_i = c.d_i; a.d_j = c.d_j; a.d_a = c.d_a; a.d_b = c.d_b;
+
+    const bool z2 = (c.zeta == 2.0);
+    const int nblocks = c.diag_only ? njb : njb * nir;
+    const bool grad = c.grad != 0;
+    switch (c.mode * 2 + c.kind) {
+        case GPR_MODE_FF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_FF, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
+        case GPR_MODE_FF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_FF, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
+        case GPR_MODE_EF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EF, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
+        case GPR_MODE_EF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EF, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
+        case GPR_MODE_EE * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EE, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
+        case GPR_MODE_EE * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EE, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
+        default: gpr_set_error("block: bad mode/kind"); return GPR_ERR_ARG;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("kblock launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return gpr_dev_free(d_meta, st);
+}

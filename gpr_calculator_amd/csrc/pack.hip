@@ -1,0 +1,281 @@
+// pack.hip -- gpr_set: descriptor rows normalised, projected and laid out in
+// v_mfma_f64_16x16x4_f64 operand order.
+//
+// What is stored per row (reference quantities: rbf_kernel.cpp:355-420, Appendix B of SURVEY.md):
+//   a~  = x / n                 n = |x| (+1e-8 under GPR_SET_NUMPY_EPS)
+//   A'  = (I - a~ a~^T) dxdr/n  the derivative columns with the a~ component projected out
+// With these, for a row pair (a, b):  c = a~.b~ is the cosine d,  A'^T B' = dx1dr^T H dx2dr with H the
+// second derivative of d (d2d_dx1dx2 in the reference),  A'^T b~ = dx1dr^T dd/dx1 and
+// a~^T B' = dd/dx2^T dx2dr -- so one 4x4 product [A'^T; a~^T][B', b~] carries everything the
+// reference's O(d^2) loop nest computes.
+#include <algorithm>
+#include <cstdarg>
+#include <numeric>
+#include "gpr_internal.h"
+
+// ---------------------------------------------------------------- errors / misc
+static thread_local std::string g_last_error;
+
+void gpr_set_error(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+}
+
+extern "C" const char *gpr_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" const char *gpr_build_info(void) {
+    return "libgprhip gfx950 (v_mfma_f64_16x16x4_f64) built " __DATE__ " " __TIME__;
+}
+
+extern "C" int gpr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    GPR_HIP_TRY(hipMallocAsync(p, bytes, st));
+    return GPR_OK;
+}
+
+int gpr_dev_free(void *p, hipStream_t st) {
+    if (p) GPR_HIP_TRY(hipFreeAsync(p, st));
+    return GPR_OK;
+}
+
+// ---------------------------------------------------------------- pack kernel
+struct pack_args {
+    const double *x, *dxdr;
+    const int *ele, *src_row;
+    double *ops, *norms;
+    int *ele_out;
+    int d, width, col0, nc, role, rpad, tile_rows;
+    int numpy_eps, pad_code;
+};
+
+// one thread per padded row
+__global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
+    int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= a.rpad) return;
+    const int src = a.src_row[r];
+    const int nplanes = (a.role == GPR_ROLE_RESIDENT) ? a.nc : 1;
+    // plane base of this row and its slot inside a plane
+    size_t base;
+    int slot_row;
+    if (a.role == GPR_ROLE_STREAM && a.nc == 4) {
+        base = (size_t)(r >> 2) * GPR_PLANE;            // tile of 4 rows, comps share the plane
+        slot_row = r & 3;
+    } else {
+        base = (size_t)(r >> 4) * nplanes * GPR_PLANE;  // 16 rows per plane, nc planes (resident)
+        slot_row = r & 15;
+    }
+    auto slot = [&](int comp, int k) -> size_t {
+        int s = k >> 2, kk = k & 3;
+        if (a.role == GPR_ROLE_STREAM && a.nc == 4)
+            return base + (size_t)s * GPR_WAVE + slot_row + 4 * comp + 16 * kk;
+        return base + (size_t)comp * GPR_PLANE + (size_t)s * GPR_WAVE + slot_row + 16 * kk;
+    };
+
+    double n = 0.0;
+    bool live = src >= 0;
+    const double *xr = nullptr;
+    if (live) {
+        xr = a.x + (size_t)src * a.d;
+        double acc = 0.0;
+        for (int k = 0; k < a.d; k++) acc += xr[k] * xr[k];
+        n = sqrt(acc);
+        if (a.numpy_eps) n += 1e-8;                 // base.py:118-119, Dot_mb.py:188-189, :206-211
+        else if (!(n > 1e-8)) live = false;         // rbf_kernel.cpp:26,37 skip
+    }
+    if (!live) {
+        for (int c = 0; c < a.nc; c++)
+            for (int k = 0; k < GPR_KPAD; k++) a.ops[slot(c, k)] = 0.0;
+        a.ele_out[r] = a.pad_code;
+        a.norms[r] = 0.0;
+        return;
+    }
+    const double inv = 1.0 / n;
+    const int row_comp = a.nc - 1;                  // plane / comp index of the a~ row
+    if (a.nc == 4) {
+        const double *D = a.dxdr + (size_t)src * a.d * a.width + a.col0;
+        double proj[3] = {0.0, 0.0, 0.0};
+        for (int k = 0; k < a.d; k++) {
+            double ak = xr[k] * inv;
+            for (int c = 0; c < 3; c++) proj[c] += ak * (D[(size_t)k * a.width + c] * inv);
+        }
+        for (int k = 0; k < a.d; k++) {
+            double ak = xr[k] * inv;
+            for (int c = 0; c < 3; c++)
+                a.ops[slot(c, k)] = D[(size_t)k * a.width + c] * inv - ak * proj[c];
+        }
+        for (int c = 0; c < 3; c++)
+            for (int k = a.d; k < GPR_KPAD; k++) a.ops[slot(c, k)] = 0.0;
+    }
+    for (int k = 0; k < a.d; k++) a.ops[slot(row_comp, k)] = xr[k] * inv;
+    for (int k = a.d; k < GPR_KPAD; k++) a.ops[slot(row_comp, k)] = 0.0;
+    a.ele_out[r] = a.ele[src];
+    a.norms[r] = n;
+}
+
+// ---------------------------------------------------------------- host side
+template <class T>
+static int upload(T **dev, const std::vector<T> &h, hipStream_t st, long long *bytes) {
+    void *p;
+    int rc = gpr_dev_alloc(&p, h.size() * sizeof(T), st);
+    if (rc) return rc;
+    *dev = (T *)p;
+    *bytes += (long long)(h.size() * sizeof(T));
+    if (!h.empty()) GPR_HIP_TRY(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, st));
+    return GPR_OK;
+}
+
+extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int width, int col0,
+                              int nrows, int npts, const int *counts_host, const double *x_dev,
+                              const double *dxdr_dev, const int *ele_dev, int flags) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(out != nullptr, "gpr_set_create: out is null");
+    *out = nullptr;
+    GPR_REQUIRE(role == GPR_ROLE_STREAM || role == GPR_ROLE_RESIDENT, "gpr_set_create: bad role %d", role);
+    GPR_REQUIRE(width == 0 || width == 3 || width == 9, "gpr_set_create: width must be 0, 3 or 9 (got %d)", width);
+    GPR_REQUIRE(width == 0 || (col0 >= 0 && col0 + 3 <= width), "gpr_set_create: col0=%d outside width=%d", col0, width);
+    GPR_REQUIRE(npts >= 0 && nrows >= 0, "gpr_set_create: negative sizes");
+    if (d < 1 || d > GPR_KPAD) {
+        gpr_set_error("gpr_set_create: descriptor length d=%d unsupported by this build (1..%d)", d, GPR_KPAD);
+        return GPR_ERR_UNSUPPORTED;
+    }
+    GPR_REQUIRE(nrows == 0 || (x_dev && ele_dev && (width == 0 || dxdr_dev)), "gpr_set_create: null device pointer");
+    long long tot = 0;
+    for (int p = 0; p < npts; p++) {
+        GPR_REQUIRE(counts_host[p] >= 0, "gpr_set_create: negative count at point %d", p);
+        tot += counts_host[p];
+    }
+    GPR_REQUIRE(tot == nrows, "gpr_set_create: counts sum to %lld but nrows=%d", tot, nrows);
+
+    gpr_set *s = new gpr_set();
+    s->role = role; s->d = d; s->width = width; s->col0 = col0; s->flags = flags;
+    s->nc = (width == 0) ? 1 : 4;
+    s->npts = npts; s->nrows = nrows;
+    s->tile_rows = (role == GPR_ROLE_STREAM && s->nc == 4) ? 4 : 16;
+
+    // packed order: points sorted by resident group count (descending, stable) so that the
+    // wavefronts of one workgroup own points of similar size; both roles use the same order
+    std::vector<int> order(npts);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        return (counts_host[a] + 15) / 16 > (counts_host[b] + 15) / 16;
+    });
+    std::vector<long long> row0(npts + 1, 0);
+    for (int p = 0; p < npts; p++) row0[p + 1] = row0[p] + counts_host[p];
+
+    s->h_perm = order;
+    s->h_cnt.resize(npts);
+    std::vector<int> src_row;
+    src_row.reserve((size_t)nrows + 16 * (size_t)npts);
+    std::vector<double> inv_cnt(npts);
+    std::vector<gpr_chunk> chunks;
+    std::vector<gpr_rpoint> rpts(npts);
+    s->h_pt_chunk0.assign(npts + 1, 0);
+    s->h_pt_tiles.assign(npts, 0);
+    s->h_groups.assign(npts, 0);
+    int unit = 0;
+    s->maxgroups = 0;
+    for (int p = 0; p < npts; p++) {
+        int o = order[p], cnt = counts_host[o];
+        s->h_cnt[p] = cnt;
+        inv_cnt[p] = cnt > 0 ? 1.0 / cnt : 0.0;
+        int units = (cnt + s->tile_rows - 1) / s->tile_rows;
+        for (int r = 0; r < units * s->tile_rows; r++)
+            src_row.push_back(r < cnt ? (int)(row0[o] + r) : -1);
+        s->h_pt_tiles[p] = units;
+        s->h_pt_chunk0[p] = (int)chunks.size();
+        if (role == GPR_ROLE_STREAM) {
+            for (int t = 0; t < units; t += GPR_CHUNK_TILES) {
+                int nt = std::min(GPR_CHUNK_TILES, units - t);
+                chunks.push_back(gpr_chunk{unit + t, nt, p, (t + nt >= units) ? 1 : 0});
+            }
+        } else {
+            rpts[p] = gpr_rpoint{unit, units};
+            s->h_groups[p] = units;
+            s->maxgroups = std::max(s->maxgroups, units);
+        }
+        unit += units;
+    }
+    s->h_pt_chunk0[npts] = (int)chunks.size();
+    s->nunits = unit;
+    s->rpad = unit * s->tile_rows;
+    s->nchunks = (int)chunks.size();
+
+    int rc = GPR_OK;
+    long long bytes = 0;
+    int *d_src = nullptr;
+    auto fail = [&](int code) { gpr_set_destroy(s, stream); return code; };
+    if ((rc = upload(&d_src, src_row, st, &bytes))) return fail(rc);
+    bytes -= (long long)(src_row.size() * sizeof(int));   // temporary
+    if ((rc = upload(&s->perm, s->h_perm, st, &bytes))) return fail(rc);
+    if ((rc = upload(&s->inv_cnt, inv_cnt, st, &bytes))) return fail(rc);
+    if (role == GPR_ROLE_STREAM) {
+        if ((rc = upload(&s->chunks, chunks, st, &bytes))) return fail(rc);
+        if ((rc = upload(&s->pt_chunk0, s->h_pt_chunk0, st, &bytes))) return fail(rc);
+    } else {
+        if ((rc = upload(&s->rpts, rpts, st, &bytes))) return fail(rc);
+    }
+    size_t planes = (size_t)s->nunits * (role == GPR_ROLE_RESIDENT ? s->nc : 1);
+    size_t ops_bytes = planes * GPR_PLANE * sizeof(double);
+    void *p;
+    if ((rc = gpr_dev_alloc(&p, ops_bytes, st))) return fail(rc);
+    s->ops = (double *)p; bytes += (long long)ops_bytes;
+    if ((rc = gpr_dev_alloc(&p, (size_t)s->rpad * sizeof(int), st))) return fail(rc);
+    s->ele = (int *)p; bytes += (long long)s->rpad * 4;
+    if ((rc = gpr_dev_alloc(&p, (size_t)s->rpad * sizeof(double), st))) return fail(rc);
+    s->norms = (double *)p; bytes += (long long)s->rpad * 8;
+    s->bytes = bytes;
+
+    if (s->rpad > 0) {
+        pack_args a;
+        a.x = x_dev; a.dxdr = dxdr_dev; a.ele = ele_dev; a.src_row = d_src;
+        a.ops = s->ops; a.norms = s->norms; a.ele_out = s->ele;
+        a.d = d; a.width = width; a.col0 = col0; a.nc = s->nc; a.role = role;
+        a.rpad = s->rpad; a.tile_rows = s->tile_rows;
+        a.numpy_eps = (flags & GPR_SET_NUMPY_EPS) ? 1 : 0;
+        a.pad_code = (role == GPR_ROLE_STREAM) ? GPR_ELE_PAD_STREAM : GPR_ELE_PAD_RESIDENT;
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((s->rpad + 255) / 256), dim3(256), 0, st, a);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) {
+            gpr_set_error("pack_rows_kernel launch failed: %s", hipGetErrorString(e));
+            return fail(GPR_ERR_HIP);
+        }
+    }
+    // src_row (host vector) feeds an async copy: finish it before the vector dies
+    if (hipStreamSynchronize(st) != hipSuccess) {
+        gpr_set_error("gpr_set_create: stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
+        return fail(GPR_ERR_HIP);
+    }
+    gpr_dev_free(d_src, st);
+    *out = s;
+    return GPR_OK;
+}
+
+extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
+    if (!s) return GPR_OK;
+    hipStream_t st = (hipStream_t)stream;
+    gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
+    gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
+    gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st);
+    delete s;
+    return GPR_OK;
+}
+
+extern "C" int gpr_set_info(const gpr_set *s, int *npts, int *nrows, int *rows_padded, long long *bytes) {
+    GPR_REQUIRE(s != nullptr, "gpr_set_info: null set");
+    if (npts) *npts = s->npts;
+    if (nrows) *nrows = s->nrows;
+    if (rows_padded) *rows_padded = s->rpad;
+    if (bytes) *bytes = s->bytes;
+    return GPR_OK;
+}

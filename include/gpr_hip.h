@@ -1,0 +1,185 @@
+/*
+ * gpr_hip.h -- C-ABI of libgprhip.so: the MI355X (gfx950) implementation of the GPR hot path
+ * of MaterSim/GPR_calculator.  Plain C types only; no torch / Python objects cross this boundary.
+ *
+ * Two levels:
+ *
+ *  (L0) Legacy natives.  The 13 `extern "C" void` entry points the reference binds through cffi
+ *       (gpr_calc/kernels/rbf_kernel.h:4-38, gpr_calc/kernels/dot_kernel.h:4-27; cdefs in
+ *       gpr_calc/kernels/librbf_builder.py:4-13 and libdot_builder.py:4-10), with identical
+ *       names, argument order and semantics: HOST pointers in and out, outputs ACCUMULATED
+ *       (+= / -=) into caller-zeroed buffers, rows with |x| <= 1e-8 and species mismatches
+ *       skipped, void return.  They upload, run the HIP kernels on the current device and
+ *       download; a failure (no GPU, bad shapes) is reported through gpr_last_error() and
+ *       aborts loudly on stderr -- there is NO CPU fallback.
+ *
+ *  (L1) Device-resident API used by the Python host layer (gpr_calculator_amd/): descriptor
+ *       rows are packed once into MFMA operand order (gpr_set), covariance blocks are written
+ *       straight into caller-provided device matrices, and the dense factor / solve /
+ *       variance kernels operate on device pointers.  Every L1 call takes the HIP stream to
+ *       launch on (hipStream_t passed as void*; NULL = default stream) and returns 0 on
+ *       success or a negative gpr_status; the message is available from gpr_last_error().
+ *
+ * All floating point is FP64; species / counts / indices are int32.
+ */
+#ifndef GPR_HIP_H
+#define GPR_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status / errors */
+enum gpr_status {
+    GPR_OK = 0,
+    GPR_ERR_HIP = -1,        /* a HIP runtime call failed (message has the HIP error string) */
+    GPR_ERR_ARG = -2,        /* inconsistent shapes / null pointers / unsupported parameter   */
+    GPR_ERR_UNSUPPORTED = -3,/* a configuration this build has no kernel for                  */
+    GPR_ERR_NOT_SPD = -4     /* Cholesky met a non-positive pivot (info in gpr_last_error)    */
+};
+const char *gpr_last_error(void);
+/* "gfx950 ... ; built <date>" -- lets tests prove which native library was loaded */
+const char *gpr_build_info(void);
+/* number of HIP devices visible (0 if none / runtime unavailable); never throws */
+int gpr_device_count(void);
+
+/* ------------------------------------------------------------------ kernel parameters */
+enum gpr_kernel_kind { GPR_KERNEL_RBF = 0, GPR_KERNEL_DOT = 1 };
+typedef struct gpr_kernel_params {
+    int kind;        /* gpr_kernel_kind                                                        */
+    double zeta;     /* power on the cosine d (RBF_mb.py:24, Dot_mb.py:10)                      */
+    double sigma;    /* signal std; sigma^2 multiplies every block                              */
+    double l;        /* RBF length scale (ignored for Dot)                                      */
+    double sigma0;   /* Dot offset (ignored for RBF)                                            */
+    double tol;      /* RBF force-force skip: pairs with K/(2 l^2) <= tol dropped               */
+                     /* (rbf_kernel.cpp:395); ignored by every other block                      */
+} gpr_kernel_params;
+
+/* ------------------------------------------------------------------ packed descriptor sets */
+/* A gpr_set holds the rows of a list of training / prediction POINTS (an energy point = one
+ * structure: all atoms' descriptor rows; a force point = one atom: the rows of every centre
+ * that feels it -- SURVEY.md App. A.1-A.2, utilities.py:340-390 `list_to_tuple`) normalised,
+ * projected and laid out in v_mfma_f64_16x16x4_f64 operand order.  See DESIGN.md section 3.   */
+typedef struct gpr_set gpr_set;
+
+enum gpr_set_role {
+    GPR_ROLE_STREAM = 0,   /* "set 1" side: rows streamed through LDS                          */
+    GPR_ROLE_RESIDENT = 1  /* "set 2" side: rows held in registers, one point per wavefront     */
+};
+enum gpr_set_flags {
+    GPR_SET_NUMPY_EPS = 1  /* norms get +1e-8 and small rows are NOT skipped: the convention of */
+                           /* the numpy helpers behind kernel.diag (base.py:107-130,            */
+                           /* Dot_mb.py:177-258)                            */
+};
+
+/* width = 0 (energy rows: x only), 3 (force rows: dxdr[n,d,3]) or 9 (stress rows, dxdr[n,d,9]);
+ * col0 = first of the three derivative columns packed (0 for forces; 0, 3 or 6 select the
+ * force / diagonal-stress / off-diagonal-stress triplets of a 9-wide row, see rbf_kernel.cpp:256-338).
+ * counts_host[npts] = rows per point (host memory); x/dxdr/ele are DEVICE pointers with the
+ * reference's row-major layouts x[nrows,d], dxdr[nrows,d,width], ele[nrows].                  */
+int gpr_set_create(gpr_set **out, void *stream, int role, int d, int width, int col0, int nrows,
+                   int npts, const int *counts_host, const double *x_dev, const double *dxdr_dev,
+                   const int *ele_dev, int flags);
+int gpr_set_destroy(gpr_set *set, void *stream);
+/* introspection (tests, DESIGN.md numbers): padded rows and bytes held on the device */
+int gpr_set_info(const gpr_set *set, int *npts, int *nrows, int *rows_padded, long long *bytes);
+
+/* ------------------------------------------------------------------ covariance blocks */
+/* All three write the block exactly as the reference's Python wrappers return it
+ * (kee_C / kef_C / kff_C in gpr_calc/kernels/rbf_kernel.py and dot_kernel.py), i.e. with the
+ * 1/n_i n_j (ee) and 1/n_i (ef) averaging and the Dot sigma^2 / zeta factors applied:
+ *   ee:  out[i*ld + j]                      i < m1 energy points, j < m2 energy points
+ *   ef:  out[i*ld + 3*j+b]                  (or transposed: out[(3*j+b)*ld + i])
+ *   ff:  out[(3*i+a)*ld + 3*j+b]
+ * `out` is a DEVICE pointer to the top-left element of the block inside a row-major matrix of
+ * leading dimension ld (so blocks can be written in place into K).  If dl_out != NULL (RBF
+ * only) the derivative of the block with respect to the length scale l is written there with
+ * the same layout (kee/kef/kff_C(..., grad=True)'s C_l); d/dsigma is 2*block/sigma.
+ * set1 must have role STREAM, set2 role RESIDENT.  symmetric != 0 (ff / ee only) promises
+ * set1 and set2 pack the same points: only the upper triangle of point pairs is computed and
+ * mirrored.                                                                                    */
+int gpr_block_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
+                 const gpr_set *set2, int symmetric, double *out, long long ld,
+                 double *dl_out, long long dl_ld);
+int gpr_block_ef(void *stream, const gpr_kernel_params *kp, const gpr_set *eset1,
+                 const gpr_set *fset2, int transpose, double *out, long long ld,
+                 double *dl_out, long long dl_ld);
+int gpr_block_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
+                 const gpr_set *set2, int symmetric, double *out, long long ld,
+                 double *dl_out, long long dl_ld);
+/* diagonal of the force-force self blocks: out[3*j+b] = kff(point j, point j)[b,b]
+ * (RBF_mb.diag, RBF_mb.py:99-109; Dot_mb.diag, Dot_mb.py:72-78).  set1/set2 = the same points
+ * packed in both roles. */
+int gpr_diag_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
+                const gpr_set *set2, double *out);
+/* diagonal of the energy-energy self blocks: out[j] = kee(point j, point j) */
+int gpr_diag_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
+                const gpr_set *set2, double *out);
+
+/* ------------------------------------------------------------------ dense FP64 linear algebra */
+/* Row-major device matrices.  Lower Cholesky in place: on return the lower triangle of a holds
+ * L (a = L L^T), the strict upper triangle is zeroed (scipy.linalg.cholesky(lower=True)
+ * semantics, gaussianprocess.py:297).  info_dev (device int, may be NULL) receives 0 or the
+ * 1-based index of the first non-positive pivot. */
+int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev);
+/* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
+int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
+                   double *b, long long ldb);
+/* C[m,n] = alpha * op(A) op(B) + beta * C, row-major, op = transpose if the flag is set */
+int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
+             const double *a, long long lda, const double *b, long long ldb, double beta,
+             double *c, long long ldc);
+/* a[i*lda+i] += (i < n_first ? add_first : add_rest): the noise diagonal (gaussianprocess.py:290-294) */
+int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, double add_first,
+                 double add_rest);
+/* out[j] = sum_i v[i*ldv + j]^2  (j < ncols): column sums of squares of an n x ncols matrix */
+int gpr_colsumsq(void *stream, int n, int ncols, const double *v, long long ldv, double *out);
+/* out[0] = sum_i log(a[i*lda+i]) (deterministic tree reduction) */
+int gpr_sum_log_diag(void *stream, int n, const double *a, long long lda, double *out);
+
+/* ------------------------------------------------------------------ L0: legacy natives */
+void rbf_kee_many(int n1, int n2, int d, int x2i, double zeta, double sigma2, double l2,
+                  double *x1, int *ele1, int *x1_inds, double *x2, int *ele2, int *x2_inds,
+                  double *pout);
+void rbf_kee_many_with_grad(int n1, int n2, int d, int x2i, double zeta, double sigma2, double l2,
+                            double *x1, int *ele1, int *x1_inds, double *x2, int *ele2,
+                            int *x2_inds, double *pout, double *dpout_dl);
+void rbf_kef_many(int n1, int n2, int d, int x2i, double zeta, double sigma2, double l2,
+                  double *x1, int *ele1, int *x1_inds, double *x2, double *dx2dr, int *ele2,
+                  int *x2_inds, double *pout);
+void rbf_kef_many_with_grad(int n1, int n2, int d, int x2i, double zeta, double sigma2, double l,
+                            double *x1, int *ele1, int *x1_inds, double *x2, double *dx2dr,
+                            int *ele2, int *x2_inds, double *pout);
+void rbf_kef_many_stress(int n1, int n2, int d, int x2i, double zeta, double sigma2, double l2,
+                         double *x1, int *ele1, int *x1_inds, double *x2, double *dx2dr,
+                         int *ele2, int *x2_inds, double *pout);
+void rbf_kff_many(int n1, int n2, int n2_start, int n2_end, int d, int x2i, double zeta,
+                  double sigma2, double l2, double tol, double *x1, double *dx1dr, int *ele1,
+                  int *x1_inds, double *x2, double *dx2dr, int *ele2, int *x2_inds, double *pout);
+void rbf_kff_many_with_grad(int n1, int n2, int n2_start, int n2_end, int d, int x2i,
+                            double zeta, double sigma2, double l, double *x1, double *dx1dr,
+                            int *ele1, int *x1_inds, double *x2, double *dx2dr, int *ele2,
+                            int *x2_inds, double *pout, double *dpout_dl);
+void rbf_kff_many_stress(int n1, int n2, int n2_start, int n2_end, int d, int x2i, double zeta,
+                         double sigma2, double l2, double tol, double *x1, double *dx1dr,
+                         int *ele1, int *x1_inds, double *x2, double *dx2dr, int *ele2,
+                         int *x2_inds, double *pout);
+void dot_kee_many(int n1, int n2, int d, int x2i, double zeta, double sigma2, double sigma02,
+                  double *x1, int *ele1, int *x1_inds, double *x2, int *ele2, int *x2_inds,
+                  double *pout);
+void dot_kef_many(int n1, int n2, int d, int x2i, double zeta, double *x1, int *ele1,
+                  int *x1_inds, double *x2, double *dx2dr, int *ele2, int *x2_inds, double *pout);
+void dot_kef_many_stress(int n1, int n2, int d, int x2i, double zeta, double *x1, int *ele1,
+                         int *x1_inds, double *x2, double *dx2dr, int *ele2, int *x2_inds,
+                         double *pout);
+void dot_kff_many(int n1, int n2, int n2_start, int n2_end, int d, int x2i, double zeta,
+                  double *x1, double *dx1dr, int *ele1, int *x1_inds, double *x2, double *dx2dr,
+                  int *ele2, int *x2_inds, double *pout);
+void dot_kff_many_stress(int n1, int n2, int n2_start, int n2_end, int d, int x2i, double zeta,
+                         double *x1, double *dx1dr, int *ele1, int *x1_inds, double *x2,
+                         double *dx2dr, int *ele2, int *x2_inds, double *pout);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPR_HIP_H */
