@@ -1,0 +1,207 @@
+"""Thin Python layer over the L1 C-ABI (include/gpr_hip.h): torch owns device memory and streams,
+libgprhip.so does the arithmetic.  Nothing here computes on the CPU."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import KernelParams, check
+
+F64 = torch.float64
+
+
+def device():
+    _lib.require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def to_dev(a, dtype=F64):
+    """numpy / tensor -> contiguous device tensor of dtype"""
+    if isinstance(a, torch.Tensor):
+        return a.to(device=device(), dtype=dtype).contiguous()
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device())
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def kernel_params(kind, zeta, sigma, l=1.0, sigma0=0.0, tol=0.0):
+    return KernelParams(int(kind), float(zeta), float(sigma), float(l), float(sigma0), float(tol))
+
+
+class PackedSet:
+    """A list of energy / force points packed on the device (gpr_set).
+
+    x[nrows, d], dxdr[nrows, d, width] or None, ele[nrows], counts[npts] follow the reference's
+    `list_to_tuple` tuple (gpr_calc/utilities.py:340-390)."""
+
+    def __init__(self, role, x, dxdr, ele, counts, col0=0, flags=0):
+        counts = np.ascontiguousarray(np.asarray(counts, dtype=np.int32))
+        self.role, self.flags, self.col0 = role, flags, col0
+        self.npts = int(len(counts))
+        self.counts = counts
+        self.x = to_dev(x)
+        if self.x.dim() != 2:
+            raise ValueError("x must be [nrows, d]")
+        self.nrows, self.d = int(self.x.shape[0]), int(self.x.shape[1])
+        self.ele = to_dev(ele, torch.int32).reshape(-1)
+        if dxdr is not None:
+            self.dxdr = to_dev(dxdr)
+            self.width = int(self.dxdr.shape[-1])
+        else:
+            self.dxdr, self.width = None, 0
+        if int(counts.sum()) != self.nrows:
+            raise ValueError(f"counts sum to {int(counts.sum())} but there are {self.nrows} rows")
+        self._h = C.c_void_p()
+        check(_lib.lib().gpr_set_create(
+            C.byref(self._h), stream_ptr(), role, self.d, self.width, col0, self.nrows, self.npts,
+            counts.ctypes.data_as(_lib.c_int_p), ptr(self.x), ptr(self.dxdr), ptr(self.ele), flags),
+            "gpr_set_create")
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self):
+        a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_longlong()
+        check(_lib.lib().gpr_set_info(self._h, C.byref(a), C.byref(b), C.byref(c), C.byref(d)), "gpr_set_info")
+        return dict(npts=a.value, nrows=b.value, rows_padded=c.value, bytes=d.value)
+
+    def close(self):
+        if self._h:
+            _lib.lib().gpr_set_destroy(self._h, stream_ptr())
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class SetPair:
+    """The same points packed in both roles (needed when a set appears on both sides of a block)."""
+
+    def __init__(self, x, dxdr, ele, counts, flags=0):
+        self.stream = PackedSet(_lib.ROLE_STREAM, x, dxdr, ele, counts, flags=flags)
+        # share the uploaded tensors
+        self.resident = PackedSet(_lib.ROLE_RESIDENT, self.stream.x, self.stream.dxdr, self.stream.ele, counts,
+                                  flags=flags)
+        self.npts, self.nrows, self.counts = self.stream.npts, self.stream.nrows, self.stream.counts
+
+    def close(self):
+        self.stream.close()
+        self.resident.close()
+
+
+def _view(out, nrows, ncols):
+    if out is None:
+        out = torch.empty((nrows, ncols), dtype=F64, device=device())
+    assert out.dtype == F64 and out.is_cuda and out.stride(-1) == 1 and tuple(out.shape) == (nrows, ncols), \
+        (out.shape, (nrows, ncols), out.stride())
+    return out
+
+
+def block_ee(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None):
+    o = _view(out, s1.npts, s2.npts)
+    dl = _view(dl_out, s1.npts, s2.npts) if grad else None
+    check(_lib.lib().gpr_block_ee(stream_ptr(), C.byref(kp), s1.handle, s2.handle, int(symmetric), ptr(o),
+                                  max(int(o.stride(0)), s2.npts), ptr(dl), max(int(dl.stride(0)), s2.npts) if grad else 0),
+          "gpr_block_ee")
+    return (o, dl) if grad else o
+
+
+def block_ef(kp, es1, fs2, transpose=False, out=None, grad=False, dl_out=None):
+    shape = (3 * fs2.npts, es1.npts) if transpose else (es1.npts, 3 * fs2.npts)
+    o = _view(out, *shape)
+    dl = _view(dl_out, *shape) if grad else None
+    check(_lib.lib().gpr_block_ef(stream_ptr(), C.byref(kp), es1.handle, fs2.handle, int(transpose), ptr(o),
+                                  max(int(o.stride(0)), shape[1]), ptr(dl), max(int(dl.stride(0)), shape[1]) if grad else 0),
+          "gpr_block_ef")
+    return (o, dl) if grad else o
+
+
+def block_ff(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None):
+    shape = (3 * s1.npts, 3 * s2.npts)
+    o = _view(out, *shape)
+    dl = _view(dl_out, *shape) if grad else None
+    check(_lib.lib().gpr_block_ff(stream_ptr(), C.byref(kp), s1.handle, s2.handle, int(symmetric), ptr(o),
+                                  max(int(o.stride(0)), shape[1]), ptr(dl), max(int(dl.stride(0)), shape[1]) if grad else 0),
+          "gpr_block_ff")
+    return (o, dl) if grad else o
+
+
+def diag_ff(kp, pair, out=None):
+    o = out if out is not None else torch.empty(3 * pair.npts, dtype=F64, device=device())
+    check(_lib.lib().gpr_diag_ff(stream_ptr(), C.byref(kp), pair.stream.handle, pair.resident.handle, ptr(o)),
+          "gpr_diag_ff")
+    return o
+
+
+def diag_ee(kp, pair, out=None):
+    o = out if out is not None else torch.empty(pair.npts, dtype=F64, device=device())
+    check(_lib.lib().gpr_diag_ee(stream_ptr(), C.byref(kp), pair.stream.handle, pair.resident.handle, ptr(o)),
+          "gpr_diag_ee")
+    return o
+
+
+# ------------------------------------------------------------------ dense linear algebra
+def potrf_lower_(a):
+    """in-place lower Cholesky of a square row-major device matrix; returns info (0 = ok)"""
+    n = a.shape[0]
+    info = torch.zeros(1, dtype=torch.int32, device=a.device)
+    check(_lib.lib().gpr_potrf_lower(stream_ptr(), n, ptr(a), int(a.stride(0)) if n > 1 else n, ptr(info)),
+          "gpr_potrf_lower")
+    return info
+
+
+def trsm_lower_(l, b, trans=False):
+    """b <- L^-1 b (trans False) or L^-T b (trans True); b is [n, nrhs] row-major, in place"""
+    n, nrhs = b.shape
+    check(_lib.lib().gpr_trsm_lower(stream_ptr(), int(trans), n, nrhs, ptr(l), int(l.stride(0)) if n > 1 else n,
+                                    ptr(b), int(b.stride(0)) if n > 1 else nrhs), "gpr_trsm_lower")
+    return b
+
+
+def gemm(a, b, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
+    m = a.shape[1] if transa else a.shape[0]
+    k = a.shape[0] if transa else a.shape[1]
+    n = b.shape[0] if transb else b.shape[1]
+    kb = b.shape[1] if transb else b.shape[0]
+    assert k == kb, (a.shape, b.shape, transa, transb)
+    if out is None:
+        out = torch.empty((m, n), dtype=F64, device=a.device)
+        beta = 0.0
+    check(_lib.lib().gpr_gemm(stream_ptr(), int(transa), int(transb), m, n, k, float(alpha), ptr(a),
+                              max(int(a.stride(0)), a.shape[1]), ptr(b), max(int(b.stride(0)), b.shape[1]),
+                              float(beta), ptr(out), max(int(out.stride(0)), n)), "gpr_gemm")
+    return out
+
+
+def add_diag_(a, n_first, add_first, add_rest):
+    n = a.shape[0]
+    check(_lib.lib().gpr_add_diag(stream_ptr(), n, ptr(a), max(int(a.stride(0)), n), int(n_first), float(add_first),
+                                  float(add_rest)), "gpr_add_diag")
+    return a
+
+
+def colsumsq(v):
+    n, ncols = v.shape
+    out = torch.empty(ncols, dtype=F64, device=v.device)
+    check(_lib.lib().gpr_colsumsq(stream_ptr(), n, ncols, ptr(v), max(int(v.stride(0)), ncols), ptr(out)),
+          "gpr_colsumsq")
+    return out
+
+
+def sum_log_diag(a):
+    n = a.shape[0]
+    out = torch.empty(1, dtype=F64, device=a.device)
+    check(_lib.lib().gpr_sum_log_diag(stream_ptr(), n, ptr(a), max(int(a.stride(0)), n), ptr(out)),
+          "gpr_sum_log_diag")
+    return out
