@@ -28,20 +28,23 @@ static int check_kp(const gpr_kernel_params *kp, const double *dl_out) {
 }
 
 extern "C" int gpr_block_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *s1,
-                            const gpr_set *s2, int symmetric, double *out, long long ld,
+                            const gpr_set *s2, int flags, double *out, long long ld,
                             double *dl_out, long long dl_ld) {
     hipStream_t st = (hipStream_t)stream;
     int rc = check_kp(kp, dl_out); if (rc) return rc;
     GPR_REQUIRE(s1 && s2, "gpr_block_ee: null set");
-    if ((rc = zero_block(st, out, ld, s1->npts, s2->npts))) return rc;
-    if (dl_out && (rc = zero_block(st, dl_out, dl_ld, s1->npts, s2->npts))) return rc;
+    const bool tr = (flags & GPR_BLOCK_TRANSPOSE) != 0;
+    const long long rows = tr ? s2->npts : s1->npts, cols = tr ? s1->npts : s2->npts;
+    if ((rc = zero_block(st, out, ld, rows, cols))) return rc;
+    if (dl_out && (rc = zero_block(st, dl_out, dl_ld, rows, cols))) return rc;
     gpr_block_call c; fill_kernel(c, kp);
-    c.mode = GPR_MODE_EE; c.s1 = s1; c.s2 = s2; c.symmetric = symmetric;
+    c.mode = GPR_MODE_EE; c.s1 = s1; c.s2 = s2; c.symmetric = (flags & GPR_BLOCK_SYMMETRIC) ? 1 : 0;
     c.norm1 = 1; c.norm2 = 1;                                    // C /= n_i n_j (rbf_kernel.py:70)
     c.scale = (kp->kind == GPR_KERNEL_DOT) ? c.sigma2 : 1.0;     // dot_kernel.cpp:49
-    c.out = out; c.s_i = ld; c.s_j = 1;
+    c.out = out; c.s_i = tr ? 1 : ld; c.s_j = tr ? ld : 1;
     if (dl_out) {                                                // C_l *= 1/l^3 (rbf_kernel.py:47,60)
-        c.grad = 1; c.dl = dl_out; c.d_i = dl_ld; c.d_j = 1; c.dl_scale = 1.0 / (kp->l * kp->l * kp->l);
+        c.grad = 1; c.dl = dl_out; c.d_i = tr ? 1 : dl_ld; c.d_j = tr ? dl_ld : 1;
+        c.dl_scale = 1.0 / (kp->l * kp->l * kp->l);
     }
     return gpr_launch_block(st, c);
 }
@@ -72,19 +75,25 @@ extern "C" int gpr_block_ef(void *stream, const gpr_kernel_params *kp, const gpr
 }
 
 extern "C" int gpr_block_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *s1,
-                            const gpr_set *s2, int symmetric, double *out, long long ld,
+                            const gpr_set *s2, int flags, double *out, long long ld,
                             double *dl_out, long long dl_ld) {
     hipStream_t st = (hipStream_t)stream;
     int rc = check_kp(kp, dl_out); if (rc) return rc;
     GPR_REQUIRE(s1 && s2, "gpr_block_ff: null set");
-    if ((rc = zero_block(st, out, ld, 3LL * s1->npts, 3LL * s2->npts))) return rc;
-    if (dl_out && (rc = zero_block(st, dl_out, dl_ld, 3LL * s1->npts, 3LL * s2->npts))) return rc;
+    const bool tr = (flags & GPR_BLOCK_TRANSPOSE) != 0;
+    const long long rows = 3LL * (tr ? s2->npts : s1->npts), cols = 3LL * (tr ? s1->npts : s2->npts);
+    if ((rc = zero_block(st, out, ld, rows, cols))) return rc;
+    if (dl_out && (rc = zero_block(st, dl_out, dl_ld, rows, cols))) return rc;
     gpr_block_call c; fill_kernel(c, kp);
-    c.mode = GPR_MODE_FF; c.s1 = s1; c.s2 = s2; c.symmetric = symmetric;
+    c.mode = GPR_MODE_FF; c.s1 = s1; c.s2 = s2; c.symmetric = (flags & GPR_BLOCK_SYMMETRIC) ? 1 : 0;
     c.scale = (kp->kind == GPR_KERNEL_DOT) ? c.sigma2 * kp->zeta : 1.0;   // dot_kernel.py:256
-    c.out = out; c.s_i = 3 * ld; c.s_a = ld; c.s_j = 3; c.s_b = 1;
+    c.out = out;
+    if (tr) { c.s_i = 3; c.s_a = 1; c.s_j = 3 * ld; c.s_b = ld; }
+    else    { c.s_i = 3 * ld; c.s_a = ld; c.s_j = 3; c.s_b = 1; }
     if (dl_out) {
-        c.grad = 1; c.dl = dl_out; c.d_i = 3 * dl_ld; c.d_a = dl_ld; c.d_j = 3; c.d_b = 1;
+        c.grad = 1; c.dl = dl_out;
+        if (tr) { c.d_i = 3; c.d_a = 1; c.d_j = 3 * dl_ld; c.d_b = dl_ld; }
+        else    { c.d_i = 3 * dl_ld; c.d_a = dl_ld; c.d_j = 3; c.d_b = 1; }
         c.tol = -1.0;   // the gradient native has no skip (rbf_kernel.cpp:534-536)
     }
     return gpr_launch_block(st, c);

@@ -108,11 +108,16 @@ def _view(out, nrows, ncols):
     return out
 
 
-def block_ee(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None):
-    o = _view(out, s1.npts, s2.npts)
-    dl = _view(dl_out, s1.npts, s2.npts) if grad else None
-    check(_lib.lib().gpr_block_ee(stream_ptr(), C.byref(kp), s1.handle, s2.handle, int(symmetric), ptr(o),
-                                  max(int(o.stride(0)), s2.npts), ptr(dl), max(int(dl.stride(0)), s2.npts) if grad else 0),
+BLOCK_SYMMETRIC, BLOCK_TRANSPOSE = 1, 2
+
+
+def block_ee(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None, transpose=False):
+    shape = (s2.npts, s1.npts) if transpose else (s1.npts, s2.npts)
+    o = _view(out, *shape)
+    dl = _view(dl_out, *shape) if grad else None
+    flags = (BLOCK_SYMMETRIC if symmetric else 0) | (BLOCK_TRANSPOSE if transpose else 0)
+    check(_lib.lib().gpr_block_ee(stream_ptr(), C.byref(kp), s1.handle, s2.handle, flags, ptr(o),
+                                  max(int(o.stride(0)), shape[1]), ptr(dl), max(int(dl.stride(0)), shape[1]) if grad else 0),
           "gpr_block_ee")
     return (o, dl) if grad else o
 
@@ -127,11 +132,12 @@ def block_ef(kp, es1, fs2, transpose=False, out=None, grad=False, dl_out=None):
     return (o, dl) if grad else o
 
 
-def block_ff(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None):
-    shape = (3 * s1.npts, 3 * s2.npts)
+def block_ff(kp, s1, s2, symmetric=False, out=None, grad=False, dl_out=None, transpose=False):
+    shape = (3 * s2.npts, 3 * s1.npts) if transpose else (3 * s1.npts, 3 * s2.npts)
     o = _view(out, *shape)
     dl = _view(dl_out, *shape) if grad else None
-    check(_lib.lib().gpr_block_ff(stream_ptr(), C.byref(kp), s1.handle, s2.handle, int(symmetric), ptr(o),
+    flags = (BLOCK_SYMMETRIC if symmetric else 0) | (BLOCK_TRANSPOSE if transpose else 0)
+    check(_lib.lib().gpr_block_ff(stream_ptr(), C.byref(kp), s1.handle, s2.handle, flags, ptr(o),
                                   max(int(o.stride(0)), shape[1]), ptr(dl), max(int(dl.stride(0)), shape[1]) if grad else 0),
           "gpr_block_ff")
     return (o, dl) if grad else o

@@ -1,0 +1,102 @@
+"""Dot-product kernel object with the reference's protocol (gpr_calc/kernels/Dot_mb.py:5-173):
+k(x_i, x_j) = sigma^2 (d^zeta + sigma0^2).  GPU only."""
+import numpy as np
+import torch
+
+from .. import _lib
+from .. import device as dev
+from ._common import DeviceKernel, as_energy_tuple, as_force_tuple, n_points
+
+
+class Dot_mb(DeviceKernel):
+    def __init__(self, para=[1., 1.], bounds=[[1e-2, 5e+1], [1e-2, 1e+1]], zeta=3, device="gpu"):
+        super().__init__()
+        self.name = 'Dot'
+        self.bounds = bounds
+        self.update(para)
+        self.zeta = zeta
+        self.device = device
+
+    def __str__(self):
+        return "{:.3f}**2 *Dot({:.3f})".format(self.sigma, self.sigma0)
+
+    def load_from_dict(self, dict0):
+        self.sigma = dict0["sigma"]
+        self.sigma0 = dict0["sigma0"]
+        self.zeta = dict0["zeta"]
+        self.bounds = dict0["bounds"]
+        self.name = dict0["name"]
+
+    def save_dict(self):
+        return {"name": self.name, "sigma": self.sigma, "sigma0": self.sigma0, "zeta": self.zeta,
+                "bounds": self.bounds}
+
+    def parameters(self):
+        return [self.sigma, self.sigma0]
+
+    def update(self, para):
+        self.sigma, self.sigma0 = para[0], para[1]
+
+    def _kp(self, zeta):
+        return dev.kernel_params(_lib.KERNEL_DOT, zeta, self.sigma, 1.0, self.sigma0, 0.0)
+
+    # ------------------------------------------------------------------ device-resident entry points
+    def k_total_dev(self, data1, data2=None, tol=1e-12, transpose=False):
+        """Dot_mb.k_total (Dot_mb.py:87-119).  The reference calls kef_C / kff_C with zeta in the
+        sigma0 slot, so those blocks silently use zeta = 2.0 while K_ee uses self.zeta
+        (SURVEY.md Appendix A.13); reproduced here."""
+        return self._assemble(data1, data2, self._kp(self.zeta), self._kp(2.0), self._kp(2.0), transpose=transpose)
+
+    def k_total_with_grad_dev(self, data1):
+        """(K, dK/dsigma, dK/dsigma0, nE) (Dot_mb.py:121-148; all blocks use self.zeta here)."""
+        kp = self._kp(self.zeta)
+        K = self._assemble(data1, None, kp, kp, kp)
+        nE = n_points(data1["energy"]) if "energy" in data1 else 0
+        K2 = torch.zeros_like(K)
+        K2[:nE, :nE] = 0.8 * 2 * self.sigma ** 2 * self.sigma0          # dot_kernel.py:58 (sic)
+        return K, K * (2.0 / self.sigma), K2, nE
+
+    def diag_dev(self, data):
+        """Dot_mb.diag (Dot_mb.py:45-85): both parts go through the numpy helpers K_ee / K_ff, i.e. the
+        numpy-eps convention (Dot_mb.py:177-258), with self.zeta."""
+        parts = []
+        kp = self._kp(self.zeta)
+        if "energy" in data and n_points(data["energy"]) > 0:
+            X, ELE, counts = as_energy_tuple(data["energy"])
+            parts.append(dev.diag_ee(kp, dev.SetPair(X, None, ELE, counts, flags=_lib.SET_NUMPY_EPS)))
+        if "force" in data and n_points(data["force"]) > 0:
+            X, dXdR, ELE, counts = as_force_tuple(data["force"])
+            pair = dev.SetPair(X, np.ascontiguousarray(dXdR[:, :, :3]), ELE, counts, flags=_lib.SET_NUMPY_EPS)
+            parts.append(dev.diag_ff(kp, pair))
+        return torch.cat(parts) if parts else None
+
+    # ------------------------------------------------------------------ reference protocol (numpy out)
+    def diag(self, data):
+        out = self.diag_dev(data)
+        return None if out is None else out.cpu().numpy()
+
+    def k_total(self, data1, data2=None, tol=1e-12):
+        return self.k_total_dev(data1, data2, tol).cpu().numpy()
+
+    def k_total_with_grad(self, data1):
+        K, K1, K2, _ = self.k_total_with_grad_dev(data1)
+        return K.cpu().numpy(), np.dstack((K1.cpu().numpy(), K2.cpu().numpy()))
+
+    def k_total_with_stress(self, data1, data2, tol=1e-10):
+        """Dot_mb.k_total_with_stress (Dot_mb.py:150-173)"""
+        from .dot_kernel import kee_C, kef_C, kff_C
+        from .base import build_covariance
+        s, s0, z = self.sigma, self.sigma0, self.zeta
+        C_ee = C_ef = C_fe = C_ff = C_se = C_sf = None
+        for key1, d1 in data1.items():
+            for key2, d2 in data2.items():
+                if n_points(d1) > 0 and n_points(d2) > 0:
+                    if key1 == 'energy' and key2 == 'energy':
+                        C_ee = kee_C(d1, d2, s, s0, z)
+                    elif key1 == 'energy' and key2 == 'force':
+                        C_ef = kef_C(d1, d2, s, z)
+                    elif key1 == 'force' and key2 == 'energy':
+                        C_fe, C_se = kef_C(d2, d1, s, z, stress=True, transpose=True)
+                    elif key1 == 'force' and key2 == 'force':
+                        C_ff, C_sf = kff_C(d1, d2, s, z, stress=True)
+        return build_covariance(C_ee, C_ef, C_fe, C_ff), build_covariance(None, None, C_se, C_sf)

@@ -95,17 +95,20 @@ int gpr_set_info(const gpr_set *set, int *npts, int *nrows, int *rows_padded, lo
  * leading dimension ld (so blocks can be written in place into K).  If dl_out != NULL (RBF
  * only) the derivative of the block with respect to the length scale l is written there with
  * the same layout (kee/kef/kff_C(..., grad=True)'s C_l); d/dsigma is 2*block/sigma.
- * set1 must have role STREAM, set2 role RESIDENT.  symmetric != 0 (ff / ee only) promises
- * set1 and set2 pack the same points: only the upper triangle of point pairs is computed and
- * mirrored.                                                                                    */
+ * set1 must have role STREAM, set2 role RESIDENT.  `flags` (ee / ff) is a bit mask:
+ *   GPR_BLOCK_SYMMETRIC  set1 and set2 pack the same points: only the upper triangle of point
+ *                        pairs is computed and mirrored;
+ *   GPR_BLOCK_TRANSPOSE  write the transposed block (out[j*ld + i], out[(3*j+b)*ld + 3*i+a]), which
+ *                        lets predict build K(train, X) = K_trans^T directly with X streamed.   */
+enum gpr_block_flags { GPR_BLOCK_SYMMETRIC = 1, GPR_BLOCK_TRANSPOSE = 2 };
 int gpr_block_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
-                 const gpr_set *set2, int symmetric, double *out, long long ld,
+                 const gpr_set *set2, int flags, double *out, long long ld,
                  double *dl_out, long long dl_ld);
 int gpr_block_ef(void *stream, const gpr_kernel_params *kp, const gpr_set *eset1,
                  const gpr_set *fset2, int transpose, double *out, long long ld,
                  double *dl_out, long long dl_ld);
 int gpr_block_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
-                 const gpr_set *set2, int symmetric, double *out, long long ld,
+                 const gpr_set *set2, int flags, double *out, long long ld,
                  double *dl_out, long long dl_ld);
 /* diagonal of the force-force self blocks: out[3*j+b] = kff(point j, point j)[b,b]
  * (RBF_mb.diag, RBF_mb.py:99-109; Dot_mb.diag, Dot_mb.py:72-78).  set1/set2 = the same points

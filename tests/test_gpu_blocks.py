@@ -1,0 +1,138 @@
+"""GPU parity of the L1 covariance blocks, kernel objects and FFI-glue mirrors against the oracle's
+restatement of the reference wrappers (oracle/gp_numpy.py on top of the plain-C natives).
+Tolerance 1e-12 relative to the largest magnitude of each matrix."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+REL = 1e-12
+
+
+def rel(a, b):
+    return np.abs(np.asarray(a) - np.asarray(b)).max() / (np.abs(np.asarray(b)).max() + 1e-300)
+
+
+def make_data(seed, nE, nF, d=30, species=(8, 46), rows_e=(3, 9), rows_f=(1, 50), zero_row=False):
+    rng = np.random.default_rng(seed)
+    energy, force = [], []
+    for _ in range(nE):
+        n = int(rng.integers(*rows_e))
+        energy.append((rng.random((n, d)), rng.choice(species, n)))
+    for _ in range(nF):
+        n = int(rng.integers(*rows_f))
+        force.append((rng.random((n, d)), rng.standard_normal((n, d, 3)), rng.choice(species, n)))
+    if zero_row and force:
+        force[0][0][0, :] = 0.0
+    return {"energy": energy, "force": force}
+
+
+def tupled(data):
+    from oracle.gp_numpy import list_to_tuple
+    out = {}
+    if "energy" in data:
+        out["energy"] = list_to_tuple(data["energy"], mode="energy")
+    if "force" in data:
+        out["force"] = list_to_tuple(data["force"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    from gpr_calculator_amd import _lib
+    _lib.require_gpu()
+    return _lib.lib()
+
+
+@pytest.mark.parametrize("zeta", [2.0, 3.0])
+def test_rbf_kernel_object_matches_oracle(gpu, port_natives, zeta):
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from oracle.gp_numpy import OracleRBF
+    train = tupled(make_data(1, 5, 23, zero_row=True))
+    new = make_data(2, 2, 7)
+    k = RBF_mb(para=[2.5, 1.3], zeta=zeta)
+    o = OracleRBF(para=(2.5, 1.3), zeta=zeta, natives=port_natives)
+    K, Ko = k.k_total(train), o.k_total(train)
+    assert K.shape == Ko.shape and rel(K, Ko) < REL
+    assert rel(K, K.T) < 1e-13       # off-diagonal bins are mirrored exactly; 3x3 self blocks to rounding
+    Kt, Kto = k.k_total(new, train, f_tol=1e-8), o.k_total(new, train, f_tol=1e-8)
+    assert rel(Kt, Kto) < REL
+    # transposed device layout used by predict
+    assert rel(k.k_total_dev(new, train, 1e-8, transpose=True).cpu().numpy().T, Kto) < REL
+    Kg, dK = k.k_total_with_grad(train)
+    Kgo, dKo = o.k_total_with_grad(train)
+    assert rel(Kg, Kgo) < REL and rel(dK[:, :, 0], dKo[:, :, 0]) < REL and rel(dK[:, :, 1], dKo[:, :, 1]) < REL
+    assert rel(k.diag(new), o.diag(new)) < REL
+    # only-force / only-energy dictionaries
+    for sub in ({"force": new["force"]}, {"energy": new["energy"]}):
+        assert rel(k.k_total(sub, train), o.k_total(sub, train)) < REL
+        assert rel(k.diag(sub), o.diag(sub)) < REL
+
+
+@pytest.mark.parametrize("zeta", [2.0, 3.0])
+def test_dot_kernel_object_matches_oracle(gpu, port_natives, zeta):
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from oracle.gp_numpy import OracleDot
+    train = tupled(make_data(3, 4, 19))
+    new = make_data(4, 2, 6)
+    k = Dot_mb(para=[2.0, 2.0], zeta=zeta)
+    o = OracleDot(para=(2.0, 2.0), zeta=zeta, natives=port_natives)
+    assert rel(k.k_total(train), o.k_total(train)) < REL          # includes the zeta=2 quirk of ef/ff
+    assert rel(k.k_total(new, train), o.k_total(new, train)) < REL
+    Kg, dK = k.k_total_with_grad(train)
+    Kgo, dKo = o.k_total_with_grad(train)
+    assert rel(Kg, Kgo) < REL and rel(dK[:, :, 0], dKo[:, :, 0]) < REL
+    assert np.array_equal(dK[:, :, 1], dKo[:, :, 1])
+    assert rel(k.diag(new), o.diag(new)) < 1e-11                   # numpy-eps convention on both sides
+
+
+def test_ffi_glue_mirrors(gpu, port_natives):
+    from gpr_calculator_amd.kernels import rbf_kernel, dot_kernel
+    from oracle.gp_numpy import Wrappers, list_to_tuple
+    w = Wrappers(port_natives)
+    rng = np.random.default_rng(9)
+    d = 30
+    e1 = [(rng.random((n, d)), rng.choice((8, 46), n)) for n in (4, 7, 2)]
+    e2 = list_to_tuple([(rng.random((n, d)), rng.choice((8, 46), n)) for n in (5, 3)], mode="energy")
+    f2 = list_to_tuple([(rng.random((n, d)), rng.standard_normal((n, d, 3)), rng.choice((8, 46), n)) for n in (17, 4, 33)])
+    f9 = [(rng.random((n, d)), rng.standard_normal((n, d, 9)), rng.choice((8, 46), n)) for n in (6, 21)]
+    assert rel(rbf_kernel.kee_C(e1, e2, 2.5, 1.3, 2.0), w.rbf_kee(e1, e2, 2.5, 1.3, 2.0)) < REL
+    for a, b in zip(rbf_kernel.kee_C(e1, e2, 2.5, 1.3, 2.0, grad=True), w.rbf_kee(e1, e2, 2.5, 1.3, 2.0, grad=True)):
+        assert rel(a, b) < REL
+    assert rel(rbf_kernel.kef_C(e1, f2, 2.5, 1.3, 2.0, transpose=True), w.rbf_kef(e1, f2, 2.5, 1.3, 2.0, transpose=True)) < REL
+    for a, b in zip(rbf_kernel.kef_C(e1, f9, 2.5, 1.3, 2.0, stress=True, transpose=True),
+                    w.rbf_kef(e1, f9, 2.5, 1.3, 2.0, stress=True, transpose=True)):
+        assert a.shape == b.shape and rel(a, b) < REL
+    for a, b in zip(rbf_kernel.kff_C(f9, f2, 2.5, 1.3, 2.0, stress=True, tol=1e-10),
+                    w.rbf_kff(f9, f2, 2.5, 1.3, 2.0, stress=True, tol=1e-10)):
+        assert a.shape == b.shape and rel(a, b) < REL
+    assert rel(dot_kernel.kee_C(e1, e2, 2.0, 1.5, 3.0), w.dot_kee(e1, e2, 2.0, 1.5, 3.0)) < REL
+    for a, b in zip(dot_kernel.kef_C(e1, f9, 2.0, 1.5, 2.0, stress=True), w.dot_kef(e1, f9, 2.0, 1.5, 2.0, stress=True)):
+        assert rel(a, b) < REL
+    for a, b in zip(dot_kernel.kff_C(f9, f2, 2.0, 1.5, 2.0, stress=True), w.dot_kff(f9, f2, 2.0, 1.5, 2.0, stress=True)):
+        assert rel(a, b) < REL
+
+
+def test_dense_linear_algebra(gpu):
+    import torch
+    from scipy.linalg import cholesky, solve_triangular
+    from gpr_calculator_amd import device as dev
+    rng = np.random.default_rng(0)
+    for n in (1, 37, 64, 200, 333):
+        a = rng.standard_normal((n, n))
+        spd = a @ a.T + n * np.eye(n)
+        t = torch.tensor(spd, device="cuda")
+        info = dev.potrf_lower_(t)
+        L = cholesky(spd, lower=True)
+        assert int(info.item()) == 0 and rel(t.cpu().numpy(), L) < 1e-13
+        b = rng.standard_normal((n, 45))
+        for trans in (False, True):
+            x = dev.trsm_lower_(t, torch.tensor(b, device="cuda"), trans=trans).cpu().numpy()
+            assert rel(x, solve_triangular(L, b, lower=True, trans=1 if trans else 0)) < 1e-11
+        assert rel(dev.colsumsq(torch.tensor(b, device="cuda")).cpu().numpy(), (b * b).sum(0)) < 1e-14
+        assert abs(dev.sum_log_diag(t).item() - np.log(np.diag(L)).sum()) < 1e-12 * max(1, n)
+    A, B = rng.standard_normal((70, 33)), rng.standard_normal((33, 51))
+    tA, tB = torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda")
+    assert rel(dev.gemm(tA, tB).cpu().numpy(), A @ B) < 1e-14
+    assert rel(dev.gemm(tB, tA, transa=True, transb=True).cpu().numpy(), B.T @ A.T) < 1e-14
+    bad = torch.tensor(np.array([[1.0, 2.0], [2.0, 1.0]]), device="cuda")
+    assert int(dev.potrf_lower_(bad).item()) == 2          # not positive definite: pivot 2
