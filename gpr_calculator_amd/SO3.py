@@ -1,0 +1,257 @@
+"""SO3: SO(3) power-spectrum descriptor with the reference's class interface
+(gpr_calc/SO3.py:7-323), evaluated by csrc/so3.hip on the GPU.
+
+Host side (this file): neighbour search and index bookkeeping (which pair belongs to which centre and
+to which (i, j) row of `seq`), and the 3 x 80 table of radial quadrature weights, which depends only
+on (nmax, lmax, rcut, alpha) and is built once.  Device side: everything per neighbour pair and per
+centre -- Bessel functions, spherical harmonics and gradients, expansion coefficients, power
+spectrum and its derivatives."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import device as dev
+from .neighbors import atoms_arrays, neighbor_pairs, symbol_of
+
+
+def radial_table(nmax, lmax, rcut, alpha):
+    """Gauss-Chebyshev nodes r_q and G[n, q] = g_n(r_q) w_q r_q^2 exp(-alpha r_q^2) sqrt(1 - t_q^2)
+    (gpr_calc/SO3.py:417-453, 623-655).  A (nmax x 10(nmax+lmax+1)) constant table."""
+    NQ = (nmax + lmax + 1) * 10
+    t = np.cos((2 * np.arange(1, NQ + 1) - 1) * np.pi / 2 / NQ)
+    rq = rcut / 2 * (t + 1)
+    S = np.zeros((nmax, nmax))
+    for a in range(1, nmax + 1):
+        for b in range(1, a + 1):
+            S[a - 1, b - 1] = S[b - 1, a - 1] = np.sqrt((2 * a + 5) * (2 * a + 6) * (2 * a + 7) * (2 * b + 5) * (2 * b + 6) * (2 * b + 7)) \
+                / (5 + a + b) / (6 + a + b) / (7 + a + b)
+    evals, V = np.linalg.eig(np.linalg.inv(S))
+    w = V @ np.diag(np.sqrt(evals)) @ np.linalg.inv(V)         # S^(-1/2), non-symmetric eig as in W()
+    G = np.zeros((nmax, NQ))
+    for n in range(nmax):
+        for a in range(1, nmax + 1):
+            G[n] += w[n, a - 1] * (rcut - rq) ** (a + 2) / np.sqrt(2 * rcut ** (2 * a + 7) / (2 * a + 5) / (2 * a + 6) / (2 * a + 7))
+    G *= (np.pi / NQ * rcut / 2) * rq ** 2 * np.exp(-alpha * rq ** 2) * np.sqrt(1 - t ** 2)
+    return rq, np.ascontiguousarray(G.real)
+
+
+class SO3:
+    '''
+    SO3 power spectrum components of the Gaussian atomic neighbour density.
+
+    args (as gpr_calc.SO3.SO3): nmax, lmax, rcut, alpha, derivative, stress, cutoff_function
+    (only 'cosine' exists upstream), weight_on, primitive.
+    '''
+
+    def __init__(self, nmax=3, lmax=3, rcut=3.5, alpha=2.0, derivative=True, stress=False,
+                 cutoff_function='cosine', weight_on=False, primitive=False):
+        self.nmax = nmax
+        self.lmax = lmax
+        self.rcut = rcut
+        self.alpha = alpha
+        self.derivative = derivative
+        self.stress = stress
+        self._type = "SO3"
+        self.cutoff_function = cutoff_function
+        self.weight_on = weight_on
+        self.primitive = primitive
+        self._tables = None
+
+    def __str__(self):
+        s = "SO3 descriptor with Cutoff: {:6.3f}".format(self.rcut)
+        s += " lmax: {:d}, nmax: {:d}, alpha: {:.3f}\n".format(self.lmax, self.nmax, self.alpha)
+        return s
+
+    __repr__ = __str__
+
+    def load_from_dict(self, dict0):
+        self.nmax = dict0["nmax"]
+        self.lmax = dict0["lmax"]
+        self.rcut = dict0["rcut"]
+        self.alpha = dict0["alpha"]
+        self.derivative = dict0["derivative"]
+        self.stress = dict0["stress"]
+        self._tables = None
+
+    def save_dict(self):
+        return {"nmax": self.nmax, "lmax": self.lmax, "rcut": self.rcut, "alpha": self.alpha,
+                "derivative": self.derivative, "stress": self.stress, "_type": "SO3"}
+
+    # -- validated attributes (gpr_calc/SO3.py:67-182)
+    @property
+    def nmax(self):
+        return self._nmax
+
+    @nmax.setter
+    def nmax(self, nmax):
+        if not isinstance(nmax, int):
+            raise ValueError('nmax must be an integer')
+        if nmax < 1:
+            raise ValueError('nmax must be greater than or equal to 1')
+        if nmax > 11:
+            raise ValueError('nmax > 11 yields complex eigenvalues which will mess up the calculation')
+        self._nmax = nmax
+        self._tables = None
+
+    @property
+    def lmax(self):
+        return self._lmax
+
+    @lmax.setter
+    def lmax(self, lmax):
+        if not isinstance(lmax, int):
+            raise ValueError('lmax must be an integer')
+        if lmax < 0:
+            raise ValueError('lmax must be greater than or equal to zero')
+        if lmax > 32:
+            raise NotImplementedError('lmax up to 32 only')
+        self._lmax = lmax
+        self._tables = None
+
+    @property
+    def rcut(self):
+        return self._rcut
+
+    @rcut.setter
+    def rcut(self, rcut):
+        if not isinstance(rcut, (float, int)):
+            raise ValueError('rcut must be a float')
+        if rcut <= 0:
+            raise ValueError('rcut must be greater than zero')
+        self._rcut = rcut
+        self._tables = None
+
+    @property
+    def alpha(self):
+        return self._alpha
+
+    @alpha.setter
+    def alpha(self, alpha):
+        if not isinstance(alpha, (float, int)):
+            raise ValueError('alpha must be a float')
+        if alpha <= 0:
+            raise ValueError('alpha must be greater than zero')
+        self._alpha = alpha
+        self._tables = None
+
+    @property
+    def derivative(self):
+        return self._derivative
+
+    @derivative.setter
+    def derivative(self, derivative):
+        if not isinstance(derivative, bool):
+            raise ValueError('derivative must be a boolean value')
+        self._derivative = derivative
+
+    @property
+    def stress(self):
+        return self._stress
+
+    @stress.setter
+    def stress(self, stress):
+        if not isinstance(stress, bool):
+            raise ValueError('stress must be a boolean value')
+        self._stress = stress
+
+    @property
+    def cutoff_function(self):
+        return self._cutoff_function
+
+    @cutoff_function.setter
+    def cutoff_function(self, cutoff_function):
+        if not isinstance(cutoff_function, str):
+            raise ValueError('You must specify the cutoff function as a string')
+        if cutoff_function != 'cosine':
+            # the reference accepts tanh / poly1-4 / exp / unity here but defines none of them (SO3.py:155-170)
+            raise NotImplementedError('The requested cutoff function has not been implemented')
+        self._cutoff_function = cutoff_function
+
+    @property
+    def ncoefs(self):
+        return self.nmax * (self.nmax + 1) // 2 * (self.lmax + 1)
+
+    # ------------------------------------------------------------------ host bookkeeping
+    def _device_tables(self):
+        if self._tables is None:
+            rq, G = radial_table(self.nmax, self.lmax, float(self.rcut), float(self.alpha))
+            self._tables = (dev.to_dev(rq), dev.to_dev(G), len(rq))
+        return self._tables
+
+    def neighbor_index(self, atoms, atom_ids=None):
+        """pairs, `seq` and the pair/row maps of one structure (the bookkeeping of
+        SO3.build_neighbor_list, gpr_calc/SO3.py:348-407), as numpy arrays."""
+        numbers, pos, cell, pbc = atoms_arrays(atoms)
+        n = len(numbers)
+        ci, cj, vec = neighbor_pairs(atoms, float(self.rcut), atom_ids)
+        centres = np.arange(n) if atom_ids is None else np.asarray(list(atom_ids), dtype=np.int64)
+        key = ci * n + cj
+        keys = np.union1d(key, centres * n + centres)            # sorted unique (i, j) incl. (i, i)
+        seq = np.stack((keys // n, keys % n), axis=1).astype(np.int64)
+        row_of_pair = np.searchsorted(keys, key)
+        S = len(keys)
+        # pairs are ordered by (centre, neighbour, image) => by row
+        row_pair0 = np.concatenate(([0], np.cumsum(np.bincount(row_of_pair, minlength=S)))).astype(np.int32)
+        cidx = np.searchsorted(centres, ci)
+        centre_pair0 = np.concatenate(([0], np.cumsum(np.bincount(cidx, minlength=len(centres))))).astype(np.int32)
+        ridx = np.searchsorted(centres, seq[:, 0])
+        centre_row0 = np.concatenate(([0], np.cumsum(np.bincount(ridx, minlength=len(centres))))).astype(np.int32)
+        self_row = np.searchsorted(keys, centres * n + centres).astype(np.int32)
+        w = numbers[cj].astype(np.float64)
+        if self.weight_on:                                       # SO3.py:381-385
+            w = np.where(numbers[cj] != numbers[ci], -w, w)
+        return dict(n=n, centres=centres, numbers=numbers, vec=vec, w=w, seq=seq, centre_pair0=centre_pair0,
+                    centre_row0=centre_row0, row_pair0=row_pair0, self_row=self_row)
+
+    def calculate_batch_dev(self, strucs):
+        """Descriptors of several structures in one launch.  Returns a dict of device tensors
+        x [sum n, d], dxdr [sum S, d, 3] and host arrays: seq [sum S, 2] (local atom ids),
+        struct_atom0 / struct_row0 offsets, numbers."""
+        if not self.derivative:
+            raise NotImplementedError("derivative=False is not used on the GPR hot path")
+        idx = [self.neighbor_index(s) for s in strucs]
+        atom0 = np.concatenate(([0], np.cumsum([i["n"] for i in idx]))).astype(np.int64)
+        row0 = np.concatenate(([0], np.cumsum([len(i["seq"]) for i in idx]))).astype(np.int64)
+        pair0 = np.concatenate(([0], np.cumsum([len(i["vec"]) for i in idx]))).astype(np.int64)
+        vec = np.concatenate([i["vec"] for i in idx], axis=0) if pair0[-1] else np.zeros((0, 3))
+        w = np.concatenate([i["w"] for i in idx])
+        cp0 = np.concatenate([i["centre_pair0"][:-1] + pair0[k] for k, i in enumerate(idx)] + [[pair0[-1]]]).astype(np.int32)
+        cr0 = np.concatenate([i["centre_row0"][:-1] + row0[k] for k, i in enumerate(idx)] + [[row0[-1]]]).astype(np.int32)
+        rp0 = np.concatenate([i["row_pair0"][:-1] + pair0[k] for k, i in enumerate(idx)] + [[pair0[-1]]]).astype(np.int32)
+        sr = np.concatenate([i["self_row"] + row0[k] for k, i in enumerate(idx)]).astype(np.int32)
+        nc, P, S, d = int(atom0[-1]), int(pair0[-1]), int(row0[-1]), self.ncoefs
+        rq, G, nq = self._device_tables()
+        D = dev.device()
+        x = torch.empty((nc, d), dtype=dev.F64, device=D)
+        dxdr = torch.empty((S, d, 3), dtype=dev.F64, device=D)
+        nlm = self.nmax * (self.lmax + 1) * (2 * self.lmax + 1)
+        scratch = torch.empty((max(P, 1) * nlm * 3, 2), dtype=dev.F64, device=D)
+        t = lambda a, dt: dev.to_dev(a, dt)
+        d_vec, d_w = t(vec, dev.F64), t(w, dev.F64)
+        d_cp0, d_cr0, d_rp0, d_sr = (t(a, torch.int32) for a in (cp0, cr0, rp0, sr))
+        dev.check(_lib.lib().gpr_so3_power_spectrum(
+            dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nq, dev.ptr(G), dev.ptr(rq),
+            nc, P, S, dev.ptr(d_vec), dev.ptr(d_w), dev.ptr(d_cp0), dev.ptr(d_cr0), dev.ptr(d_rp0), dev.ptr(d_sr),
+            dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
+        return dict(x=x, dxdr=dxdr, seq=[i["seq"] for i in idx], numbers=[i["numbers"] for i in idx],
+                    atom0=atom0, row0=row0)
+
+    def calculate(self, atoms, atom_ids=None, use_mpi=False):
+        '''
+        Power spectrum x [n, ncoef], its derivatives dxdr [S, ncoef, 3] per (centre, neighbour) row of
+        seq [S, 2], the chemical symbols, and rdxdr (None unless stress) -- the dictionary of
+        gpr_calc.SO3.SO3.calculate (SO3.py:186-323), as numpy arrays.  `use_mpi` is accepted for
+        signature compatibility; the work is already one GPU launch.
+        '''
+        if atom_ids is not None:
+            raise NotImplementedError("atom_ids subsets are not used on the GPR hot path")
+        if self._stress:
+            raise NotImplementedError("stress=True (rdxdr) belongs to the path the reference marks obsolete "
+                                      "(RBF_mb.py:210); not built on the GPU yet")
+        out = self.calculate_batch_dev([atoms])
+        numbers = out["numbers"][0]
+        symbols = list(atoms.symbols) if hasattr(atoms, "symbols") else [symbol_of(z) for z in numbers]
+        return {'x': out["x"].cpu().numpy(), 'dxdr': out["dxdr"].cpu().numpy(), 'rdxdr': None,
+                'elements': [str(s) for s in symbols], 'seq': out["seq"][0]}

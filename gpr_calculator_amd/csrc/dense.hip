@@ -200,6 +200,37 @@ __global__ void __launch_bounds__(256) sum_log_diag_kernel(int n, const double *
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// sum_ij a[i*lda+j] * b[i*ldb+j]: per-block partials in a fixed order, then one block sums them
+__global__ void __launch_bounds__(256) frob_partial_kernel(int m, int n, const double *a, long long lda,
+                                                            const double *b, long long ldb, double *part) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    const long long total = (long long)m * n;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / n, j = e % n;
+        acc += a[i * lda + j] * b[i * ldb + j];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+__global__ void __launch_bounds__(256) sum_partials_kernel(int n, const double *part, double *out) {
+    __shared__ double red[256];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) acc += part[i];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
@@ -317,4 +348,22 @@ extern "C" int gpr_sum_log_diag(void *stream, int n, const double *a, long long 
     hipLaunchKernelGGL(sum_log_diag_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, n, a, lda, out);
     LAUNCH_CHECK("sum_log_diag");
     return GPR_OK;
+}
+
+extern "C" int gpr_frob_dot(void *stream, int m, int n, const double *a, long long lda, const double *b,
+                            long long ldb, double *out) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(out != nullptr, "gpr_frob_dot: null output");
+    if (m <= 0 || n <= 0) { GPR_HIP_TRY(hipMemsetAsync(out, 0, 8, st)); return GPR_OK; }
+    GPR_REQUIRE(a && b && lda >= n && ldb >= n, "gpr_frob_dot: bad arguments");
+    const long long total = (long long)m * n;
+    int nblk = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+    void *part;
+    int rc = gpr_dev_alloc(&part, (size_t)nblk * 8, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(frob_partial_kernel, dim3(nblk), dim3(256), 0, st, m, n, a, lda, b, ldb, (double *)part);
+    LAUNCH_CHECK("frob_partial");
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, nblk, (const double *)part, out);
+    LAUNCH_CHECK("sum_partials");
+    return gpr_dev_free(part, st);
 }

@@ -32,6 +32,7 @@ struct kb_args {
     const int *ir_chunk0;   // [nir+1] chunk range of each stream range
     const int *ir_pt0;      // [nir+1] first packed point of each stream range
     int njb, nir;
+    int shard_mod, shard_rem;
     int symmetric, diag_only, eps_mode, norm1, norm2;
     double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
     double scale, dl_scale;
@@ -80,6 +81,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
     const int jp = jb * NW + wave;                     // packed resident point of this wavefront
     const bool active = jp < P.b_npts;
     const int jlast = min((jb + 1) * NW, P.b_npts) - 1;
+    if ((jb + ir) % P.shard_mod != P.shard_rem) return;   // multi-GPU: this task belongs to another rank
 
     int c0, c1;
     if (P.diag_only) {                                 // only the chunks of this block's own points
@@ -307,6 +309,14 @@ static void launch_zg(hipStream_t st, bool z2, bool grad, int nw, int nblocks, c
     else    { if (grad) launch_nw<MODE, KIND, false, true>(st, nw, nblocks, a); else launch_nw<MODE, KIND, false, false>(st, nw, nblocks, a); }
 }
 
+static thread_local int g_shard_mod = 1, g_shard_rem = 0;
+
+extern "C" int gpr_set_shard(int nshards, int shard) {
+    GPR_REQUIRE(nshards >= 1 && shard >= 0 && shard < nshards, "gpr_set_shard: bad shard %d of %d", shard, nshards);
+    g_shard_mod = nshards; g_shard_rem = shard;
+    return GPR_OK;
+}
+
 int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     const gpr_set *s1 = c.s1, *s2 = c.s2;
     GPR_REQUIRE(s1 && s2, "block: null set");
@@ -368,6 +378,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     a.b_npts = s2->npts; a.a_npts = s1->npts;
     a.ir_chunk0 = d_meta; a.ir_pt0 = d_meta + (nir + 1);
     a.njb = njb; a.nir = nir;
+    a.shard_mod = g_shard_mod; a.shard_rem = g_shard_rem;
     a.symmetric = c.symmetric; a.diag_only = c.diag_only; a.eps_mode = c.eps_mode;
     a.norm1 = c.norm1; a.norm2 = c.norm2;
     a.zeta = c.zeta; a.sigma2 = c.sigma2; a.sigma02 = c.sigma02; a.tol = c.tol;

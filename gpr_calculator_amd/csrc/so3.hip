@@ -1,0 +1,302 @@
+// so3.hip -- SO(3) power-spectrum descriptor and its position derivatives on the GPU.
+//
+// Replaces the numpy/scipy pipeline of gpr_calc/SO3.py: compute_dcs (:608-727: Gauss-Chebyshev radial
+// quadrature x modified spherical Bessel x Y_lm x Gaussian x cosine cutoff and their gradients) and
+// the per-centre assembly loop of SO3.calculate (:243-273: c_tot, power spectrum P, dP per neighbour
+// pair, scatter into the (i, j) rows of `seq`, self row = -sum of the others).
+//
+// One 256-thread workgroup per centre atom.  Phase 1: each wavefront takes neighbour pairs of the
+// centre in turn -- lanes over quadrature nodes for the radial integrals, over m for the Legendre
+// recurrences, over (n, l, m) for the expansion coefficients -- stores dC of the pair in a global
+// scratch and accumulates c_tot in wavefront-private LDS.  Phase 2: the four partial c_tot are summed
+// in a fixed order, lanes over coefficients emit x_i, and one wavefront per seq row contracts the
+// stored dC with conj(c_tot).  No atomics; the summation order is fixed.
+#include "gpr_internal.h"
+
+namespace {
+
+constexpr int SO3_LCAP = 7;      // lmax <= 6  (tables hold l = 0 .. lmax+1)
+constexpr int SO3_NQCAP = 128;   // quadrature nodes: 10*(nmax+lmax+1) <= 128
+constexpr int SO3_NLM_CAP = 32 * (2 * (SO3_LCAP - 1) + 1);   // nmax*L <= 32 planes of M <= 13
+constexpr int SO3_WAVES = 4;
+
+struct so3_args {
+    int nmax, lmax, nq, d;
+    double rcut, alpha;
+    const double *G;            // [nmax][nq] radial weights (SO3.py:623-655)
+    const double *rq;           // [nq] quadrature radii
+    const double *vec;          // [P][3] neighbour displacement
+    const double *wj;           // [P] neighbour weight (Z_j, SO3.py:385)
+    const int *centre_pair0;    // [nc+1]
+    const int *centre_row0;     // [nc+1] seq-row range of each centre
+    const int *row_pair0;       // [S+1]  pair range of each seq row
+    const int *self_row;        // [nc]   seq row (i, i)
+    double *x;                  // [nc][d]
+    double *dxdr;               // [S][d][3]
+    double2 *dc;                // scratch [P][nmax*L*M][3]
+};
+
+struct cplx { double re, im; };
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
+__device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.im * s}; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
+
+// modified spherical Bessel functions of the first kind i_0 .. i_lt(x), x > 0
+// (scipy.special.spherical_in in the reference, SO3.py:563-565).  Power series for small x, closed
+// forms + upward recurrence once x is large enough for the recurrence to be well conditioned.
+__device__ void sph_in_table(double x, int lt, double *b) {
+    const double xs = fmax(6.0, 2.0 * lt);
+    if (x < xs) {
+        const double h = 0.5 * x * x;
+        double pw = 1.0;                                    // x^l / (2l+1)!!
+        for (int l = 0; l <= lt; l++) {
+            if (l > 0) pw *= x / (2 * l + 1);
+            double t = pw, s = pw;
+            for (int k = 1; k < 200; k++) {
+                t *= h / (double(k) * (2 * l + 2 * k + 1));
+                s += t;
+                if (t < 1e-18 * s) break;
+            }
+            b[l] = s;
+        }
+    } else {
+        const double e = exp(x), em = 1.0 / e, sh = 0.5 * (e - em), ch = 0.5 * (e + em);
+        b[0] = sh / x;
+        if (lt >= 1) b[1] = (x * ch - sh) / (x * x);
+        for (int l = 1; l < lt; l++) b[l + 1] = b[l - 1] - (2 * l + 1) / x * b[l];
+    }
+}
+
+__global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
+    const int L = A.lmax + 1, M = 2 * A.lmax + 1, NLM = A.nmax * L * M;
+    const int LT = A.lmax + 1;                  // highest l in the Y table (gradients need l+1)
+    __shared__ double sB[SO3_WAVES][SO3_LCAP + 1][SO3_NQCAP];
+    __shared__ double sD[SO3_WAVES][SO3_LCAP + 1][SO3_NQCAP];
+    __shared__ double sI[SO3_WAVES][32], sdI[SO3_WAVES][32];
+    __shared__ cplx sY[SO3_WAVES][SO3_LCAP + 1][SO3_LCAP + 1];          // Y_l^m, m >= 0, l <= lmax+1
+    __shared__ cplx sGY[SO3_WAVES][SO3_LCAP][2 * SO3_LCAP - 1][3];      // grad Y_l^m, l <= lmax
+    __shared__ cplx sCw[SO3_WAVES][SO3_NLM_CAP];                        // per-wavefront partial c_tot
+    __shared__ double sSelf[SO3_WAVES][96];
+
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int ic = blockIdx.x;
+    const int p0 = A.centre_pair0[ic], p1 = A.centre_pair0[ic + 1];
+    for (int e = lane; e < NLM; e += 64) sCw[wave][e] = {0.0, 0.0};
+
+    auto Ylm = [&](int l, int m) -> cplx {     // any m; zero outside |m| <= l
+        if (m > l || -m > l) return {0.0, 0.0};
+        if (m >= 0) return sY[wave][l][m];
+        cplx v = sY[wave][l][-m];
+        const double sgn = ((-m) & 1) ? -1.0 : 1.0;
+        return {sgn * v.re, -sgn * v.im};
+    };
+
+    const int rounds = (p1 - p0 + SO3_WAVES - 1) / SO3_WAVES;
+    for (int it = 0; it < rounds; ++it) {
+        const int p = p0 + it * SO3_WAVES + wave;
+        const bool act = p < p1;
+        double vx = 0, vy = 0, vz = 1, r = 1;
+        if (act) { vx = A.vec[3 * p]; vy = A.vec[3 * p + 1]; vz = A.vec[3 * p + 2]; r = sqrt(vx * vx + vy * vy + vz * vz); }
+        const double ux = vx / r, uy = vy / r, uz = vz / r;
+        // ---- A1: Bessel values at the quadrature nodes (lanes over nodes)
+        if (act) {
+            const int lt = A.lmax > 1 ? A.lmax : 1;
+            for (int q = lane; q < A.nq; q += 64) {
+                double b[SO3_LCAP + 1];
+                const double rqq = A.rq[q];
+                const double xarg = 2.0 * A.alpha * r * rqq;
+                sph_in_table(xarg, lt, b);
+                const double chain = 2.0 * A.alpha * rqq;       // d/dr of the argument
+                for (int l = 0; l <= A.lmax; l++) {
+                    sB[wave][l][q] = b[l];
+                    const double db = (l == 0) ? b[1] : b[l - 1] - (l + 1) / xarg * b[l];   // scipy _spherical_in_d
+                    sD[wave][l][q] = db * chain;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- A2: radial integrals I[n][l], dI/dr (lanes over (n, l))
+        if (act) {
+            for (int e = lane; e < A.nmax * L; e += 64) {
+                const int n = e / L, l = e % L;
+                double s0 = 0.0, s1 = 0.0;
+                for (int q = 0; q < A.nq; q++) {
+                    const double g = A.G[n * A.nq + q];
+                    s0 += g * sB[wave][l][q];
+                    s1 += g * sD[wave][l][q];
+                }
+                sI[wave][e] = s0; sdI[wave][e] = s1;
+            }
+            // ---- B1: Y_l^m for m = lane >= 0, l = m .. lmax+1
+            if (lane <= LT) {
+                const int m = lane;
+                const double ct = uz, rho = sqrt(ux * ux + uy * uy), st = rho;
+                const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
+                double cm = 1.0, sm = 0.0;                       // cos(m phi), sin(m phi)
+                for (int k = 0; k < m; k++) { const double c2 = cm * cphi - sm * sphi; sm = sm * cphi + cm * sphi; cm = c2; }
+                double pmm = 1.0;                                // P_m^m with the Condon-Shortley phase
+                for (int k = 1; k <= m; k++) pmm *= -(2 * k - 1) * st;
+                double plm2 = 0.0, plm1 = pmm;
+                for (int l = m; l <= LT; l++) {
+                    double plm;
+                    if (l == m) plm = pmm;
+                    else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
+                    else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) / (l - m);
+                    if (l > m) { plm2 = plm1; plm1 = plm; }
+                    double ratio = 1.0;                          // (l-m)! / (l+m)!
+                    for (int k = l - m + 1; k <= l + m; k++) ratio /= k;
+                    const double nrm = sqrt((2 * l + 1) / (4.0 * M_PI) * ratio);
+                    sY[wave][l][m] = {nrm * plm * cm, nrm * plm * sm};
+                }
+            }
+        }
+        __syncthreads();
+        // ---- B2: gradient of Y_l^m from its covariant spherical components (SO3.py:682-707)
+        if (act) {
+            for (int e = lane; e < L * M; e += 64) {
+                const int l = e / M, m = e % M - A.lmax;
+                cplx g0 = {0, 0}, gp = {0, 0}, gm = {0, 0};
+                if (l >= 1 && m >= -l && m <= l) {
+                    const double dl = l;
+                    const double inv_r = 1.0 / r;
+                    g0 = cscale(Ylm(l + 1, m), -sqrt(((dl + 1) * (dl + 1) - m * m) / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
+                    if (abs(m) <= l - 1)
+                        g0 = cadd(g0, cscale(Ylm(l - 1, m), sqrt((dl * dl - m * m) / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
+                    gp = cscale(Ylm(l + 1, m + 1), -sqrt((dl + m + 1) * (dl + m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
+                    if (abs(m + 1) <= l - 1)
+                        gp = cadd(gp, cscale(Ylm(l - 1, m + 1), -sqrt((dl - m - 1) * (dl - m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
+                    gm = cscale(Ylm(l + 1, m - 1), -sqrt((dl - m + 1) * (dl - m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
+                    if (abs(m - 1) <= l - 1)
+                        gm = cadd(gm, cscale(Ylm(l - 1, m - 1), -sqrt((dl + m - 1) * (dl + m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
+                }
+                const double is2 = 0.70710678118654752440;
+                cplx dmp = {gm.re - gp.re, gm.im - gp.im}, smp = {gm.re + gp.re, gm.im + gp.im};
+                sGY[wave][l][e % M][0] = cscale(dmp, is2);
+                sGY[wave][l][e % M][1] = {-is2 * smp.im, is2 * smp.re};          // i/sqrt(2) * (gm + gp)
+                sGY[wave][l][e % M][2] = g0;
+            }
+        }
+        __syncthreads();
+        // ---- C: expansion coefficients and gradients of this pair (lanes over (n, l, m))
+        if (act) {
+            const double w = A.wj[p];
+            const double E = 4.0 * M_PI * exp(-A.alpha * r * r);
+            const double gE = -2.0 * A.alpha * r * E;                            // d/dr
+            const double fc = 0.5 * (cos(M_PI * r / A.rcut) + 1.0);
+            const double dfc = -0.5 * M_PI / A.rcut * sin(M_PI * r / A.rcut);
+            const double u[3] = {ux, uy, uz};
+            for (int e = lane; e < NLM; e += 64) {
+                const int n = e / (L * M), l = (e / M) % L, mi = e % M, m = mi - A.lmax;
+                cplx cval = {0, 0}, dcv[3] = {{0, 0}, {0, 0}, {0, 0}};
+                if (m >= -l && m <= l) {
+                    const double norm = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * l + 1.0)) * w;     // SO3.py:206, 221
+                    const double In = sI[wave][n * L + l], dIn = sdI[wave][n * L + l];
+                    const cplx Y = Ylm(l, m);
+                    const cplx yin = cscale(Y, In);
+                    cval = cscale(yin, E);
+                    for (int k = 0; k < 3; k++) {
+                        cplx t = cscale(yin, gE * u[k]);
+                        cplx h = cadd(cscale(sGY[wave][l][mi][k], In), cscale(Y, dIn * u[k]));
+                        t = cadd(t, cscale(h, E));
+                        t = cadd(cscale(t, fc), cscale(cval, dfc * u[k]));
+                        dcv[k] = cscale(t, norm);
+                    }
+                    cval = cscale(cval, fc * norm);
+                }
+                double2 *o = A.dc + ((size_t)p * NLM + e) * 3;
+                for (int k = 0; k < 3; k++) o[k] = make_double2(dcv[k].re, dcv[k].im);
+                sCw[wave][e] = cadd(sCw[wave][e], cval);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- phase 2: c_tot, x_i, dP rows
+    cplx *ctot = sCw[0];
+    for (int e = tid; e < NLM; e += 256) {
+        cplx s = sCw[0][e];
+        for (int w2 = 1; w2 < SO3_WAVES; w2++) s = cadd(s, sCw[w2][e]);
+        sCw[0][e] = s;
+    }
+    __syncthreads();
+    auto decode = [&](int c, int &n1, int &n2, int &l) {
+        const int pi = c / L;
+        l = c % L;
+        n1 = 0;
+        while ((n1 + 1) * (n1 + 2) / 2 <= pi) n1++;
+        n2 = pi - n1 * (n1 + 1) / 2;
+    };
+    for (int c = tid; c < A.d; c += 256) {
+        int n1, n2, l;
+        decode(c, n1, n2, l);
+        double s = 0.0;
+        for (int mi = 0; mi < M; mi++) {
+            const cplx a = ctot[(n1 * L + l) * M + mi], b = ctot[(n2 * L + l) * M + mi];
+            s += a.re * b.re + a.im * b.im;
+        }
+        A.x[(size_t)ic * A.d + c] = s;
+    }
+    const int r0 = A.centre_row0[ic], r1 = A.centre_row0[ic + 1], rself = A.self_row[ic];
+    const int ne = A.d * 3;
+    double self0 = 0.0, self1 = 0.0;
+    for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
+        if (row == rself) continue;
+        const int q0 = A.row_pair0[row], q1 = A.row_pair0[row + 1];
+        for (int e = lane, rnd = 0; e < ne; e += 64, rnd++) {
+            const int c = e / 3, k = e % 3;
+            int n1, n2, l;
+            decode(c, n1, n2, l);
+            double s = 0.0;
+            for (int p = q0; p < q1; p++) {
+                const double2 *dp = A.dc + (size_t)p * NLM * 3;
+                for (int mi = 0; mi < M; mi++) {
+                    const int i1 = (n1 * L + l) * M + mi, i2 = (n2 * L + l) * M + mi;
+                    const double2 d1 = dp[i1 * 3 + k], d2 = dp[i2 * 3 + k];
+                    s += d1.x * ctot[i2].re + d1.y * ctot[i2].im + d2.x * ctot[i1].re + d2.y * ctot[i1].im;
+                }
+            }
+            A.dxdr[(size_t)row * ne + e] = s;
+            if (rnd == 0) self0 += s; else self1 += s;
+        }
+    }
+    sSelf[wave][lane] = self0;
+    if (lane < 32) sSelf[wave][64 + lane] = self1;
+    __syncthreads();
+    for (int e = tid; e < ne; e += 256) {
+        double s = 0.0;
+        for (int w2 = 0; w2 < SO3_WAVES; w2++) s += sSelf[w2][e];
+        A.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
+    }
+}
+
+}  // namespace
+
+// x[nc, d], dxdr[S, d, 3] from neighbour pairs grouped by centre and, inside a centre, by seq row.
+// All pointers are device pointers; scratch must hold P * nmax*(lmax+1)*(2*lmax+1) * 3 complex doubles.
+extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nq,
+                                      const double *G, const double *rq, int ncentres, int npairs, int nrows,
+                                      const double *vec, const double *wj, const int *centre_pair0,
+                                      const int *centre_row0, const int *row_pair0, const int *self_row,
+                                      double *x, double *dxdr, void *scratch) {
+    hipStream_t st = (hipStream_t)stream;
+    const int d = nmax * (nmax + 1) / 2 * (lmax + 1);
+    GPR_REQUIRE(nmax >= 1 && lmax >= 0, "gpr_so3_power_spectrum: bad nmax/lmax");
+    if (lmax > SO3_LCAP - 1 || nq > SO3_NQCAP || nmax * (lmax + 1) > 32 || d * 3 > 96 || nq < 1) {
+        gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d, nq=%d) outside this build's limits "
+                      "(lmax <= %d, nq <= %d, ncoef <= 32)", nmax, lmax, nq, SO3_LCAP - 1, SO3_NQCAP);
+        return GPR_ERR_UNSUPPORTED;
+    }
+    if (ncentres <= 0) return GPR_OK;
+    GPR_REQUIRE(G && rq && centre_pair0 && centre_row0 && row_pair0 && self_row && x && dxdr,
+                "gpr_so3_power_spectrum: null pointer");
+    GPR_REQUIRE(npairs == 0 || (vec && wj && scratch), "gpr_so3_power_spectrum: null pair arrays");
+    (void)nrows;
+    so3_args A;
+    A.nmax = nmax; A.lmax = lmax; A.nq = nq; A.d = d; A.rcut = rcut; A.alpha = alpha;
+    A.G = G; A.rq = rq; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
+    A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr; A.dc = (double2 *)scratch;
+    hipLaunchKernelGGL(so3_centre_kernel, dim3(ncentres), dim3(256), 0, st, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("so3_centre_kernel launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}

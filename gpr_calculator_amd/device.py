@@ -31,6 +31,11 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
 
 
+def set_shard(nshards, shard):
+    """restrict the following block calls of this thread to one shard of the point-pair tasks"""
+    check(_lib.lib().gpr_set_shard(int(nshards), int(shard)), "gpr_set_shard")
+
+
 def kernel_params(kind, zeta, sigma, l=1.0, sigma0=0.0, tol=0.0):
     return KernelParams(int(kind), float(zeta), float(sigma), float(l), float(sigma0), float(tol))
 
@@ -210,4 +215,16 @@ def sum_log_diag(a):
     out = torch.empty(1, dtype=F64, device=a.device)
     check(_lib.lib().gpr_sum_log_diag(stream_ptr(), n, ptr(a), max(int(a.stride(0)), n), ptr(out)),
           "gpr_sum_log_diag")
+    return out
+
+
+def frob_dot(a, b):
+    """sum(a * b) of two equally shaped row-major device matrices -> 1-element device tensor"""
+    assert a.shape == b.shape
+    a2 = a if a.dim() == 2 else a.reshape(-1, 1)
+    b2 = b if b.dim() == 2 else b.reshape(-1, 1)
+    m, n = a2.shape
+    out = torch.empty(1, dtype=F64, device=a.device)
+    check(_lib.lib().gpr_frob_dot(stream_ptr(), m, n, ptr(a2), max(int(a2.stride(0)), n), ptr(b2),
+                                  max(int(b2.stride(0)), n), ptr(out)), "gpr_frob_dot")
     return out

@@ -119,6 +119,30 @@ int gpr_diag_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
 int gpr_diag_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
                 const gpr_set *set2, double *out);
 
+/* Multi-GPU sharding of the block calls issued from this host thread: with (nshards, shard) set, a
+ * gpr_block_* call evaluates only the point-pair tasks t with t % nshards == shard and leaves every
+ * other output element untouched (zero after the call's own zero-fill).  Summing the outputs of all
+ * shards (one RCCL all-reduce) gives the full block exactly, because every element is produced by
+ * exactly one shard.  (1, 0) restores the default.  Role of the reference's MPI row chunking,
+ * RBF_mb.py:257-269, 471-481. */
+int gpr_set_shard(int nshards, int shard);
+
+/* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
+/* x[ncentres, d] and dxdr[nrows, d, 3] (d = nmax(nmax+1)/2 (lmax+1)) from neighbour pairs grouped by
+ * centre atom and, inside a centre, by `seq` row (gpr_calc/SO3.py:186-323, 608-727).
+ *   G[nmax, nq], rq[nq]     radial quadrature table (SO3.py:446-453, 623-655), device
+ *   vec[npairs, 3], wj[npairs]   displacement and weight (Z_j) of every neighbour pair, device
+ *   centre_pair0[ncentres+1]     pair range of each centre
+ *   centre_row0[ncentres+1]      seq-row range of each centre
+ *   row_pair0[nrows+1]           pair range of each seq row (i, j)
+ *   self_row[ncentres]           seq row (i, i), which receives minus the sum of the other rows
+ *   scratch                      npairs * nmax*(lmax+1)*(2 lmax+1) * 3 * 16 bytes, device          */
+int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nq,
+                           const double *G, const double *rq, int ncentres, int npairs, int nrows,
+                           const double *vec, const double *wj, const int *centre_pair0,
+                           const int *centre_row0, const int *row_pair0, const int *self_row,
+                           double *x, double *dxdr, void *scratch);
+
 /* ------------------------------------------------------------------ dense FP64 linear algebra */
 /* Row-major device matrices.  Lower Cholesky in place: on return the lower triangle of a holds
  * L (a = L L^T), the strict upper triangle is zeroed (scipy.linalg.cholesky(lower=True)
@@ -137,6 +161,10 @@ int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, dou
                  double add_rest);
 /* out[j] = sum_i v[i*ldv + j]^2  (j < ncols): column sums of squares of an n x ncols matrix */
 int gpr_colsumsq(void *stream, int n, int ncols, const double *v, long long ldv, double *out);
+/* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
+ * gaussianprocess.py:196-198), deterministic reduction order */
+int gpr_frob_dot(void *stream, int m, int n, const double *a, long long lda, const double *b,
+                 long long ldb, double *out);
 /* out[0] = sum_i log(a[i*lda+i]) (deterministic tree reduction) */
 int gpr_sum_log_diag(void *stream, int n, const double *a, long long lda, double *out);
 

@@ -1,0 +1,158 @@
+"""GPU parity of GP.fit / predict / predict_structure(s) / log-marginal-likelihood against the oracle
+(numpy/scipy restatement of gaussianprocess.py on top of the plain-C natives) on seeded synthetic
+structures.  Tolerances from BASELINE.json north_star: energies 1e-6 eV, forces 1e-5 eV/A, and the
+same for the predictive standard deviations."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+E_TOL, F_TOL = 1e-6, 1e-5
+
+
+def oracle_descriptor():
+    from oracle.so3_numpy import so3_calculate
+    from gpr_calculator_amd.neighbors import symbol_of
+
+    class D:
+        def calculate(self, atoms, use_mpi=False):
+            out = so3_calculate(atoms.numbers, atoms.positions, atoms.cell, atoms.pbc, 3, 4, 5.0, 2.0)
+            out["elements"] = [symbol_of(z) for z in atoms.numbers]
+            return out
+    return D()
+
+
+def training_structures(n, species=(46,), natoms_reps=1):
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    out = []
+    for s in range(n):
+        atoms = fcc_cell(seed=s, reps=natoms_reps, species=species, sigma=0.08)
+        E, F = lj_energy_forces(atoms)
+        out.append((atoms, E, F))
+    return out
+
+
+def oracle_train(kernel_o, strucs, force_ids):
+    """training dictionary through the oracle descriptor, reference packing"""
+    from oracle.gp_numpy import list_to_tuple
+    from gpr_calculator_amd.utilities import species_numbers
+    des = oracle_descriptor()
+    energy, force, yE, yF = [], [], [], []
+    for (atoms, E, F) in strucs:
+        d = des.calculate(atoms)
+        ele = species_numbers(d["elements"])
+        energy.append((d["x"], ele)); yE.append(E / len(atoms))
+        for a in force_ids:
+            ids = np.argwhere(d["seq"][:, 1] == a).flatten()
+            ci = d["seq"][ids, 0]
+            force.append((d["x"][ci], d["dxdr"][ids], ele[ci])); yF.append(F[a])
+    train_x = {"energy": list_to_tuple(energy, mode="energy"), "force": list_to_tuple(force)}
+    y = np.concatenate((np.array(yE), np.array(yF).reshape(-1))).reshape(-1, 1)
+    return train_x, y, len(energy)
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Dot"])
+def test_fit_predict_structure_matches_oracle(kind, port_natives):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from oracle import gp_numpy as og
+    strucs = training_structures(4, species=(46, 78))          # 4-atom cells, two species
+    force_ids = [0, 2, 3]
+    noise_e, noise_f = 0.002, 0.1
+    if kind == "RBF":
+        kern, okern = RBF_mb(para=[2.5, 1.3], zeta=2.0), og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=port_natives)
+    else:
+        kern, okern = Dot_mb(para=[2.0, 2.0], zeta=2.0), og.OracleDot(para=(2.0, 2.0), zeta=2.0, natives=port_natives)
+    gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=noise_e, noise_f=noise_f, log_file="/tmp/gpr_test.log")
+    rows = [(a, E, F, True, force_ids) for (a, E, F) in strucs]
+    gp.fit(gp.points_from_structures(rows), show=False, opt=False)
+
+    train_x, y, NE = oracle_train(okern, strucs, force_ids)
+    assert np.abs(gp.y_train - y).max() < 1e-12
+    K = okern.k_total(train_x)
+    L, alpha, K_inv = og.fit_core(K, y, NE, noise_e, noise_f)
+    assert np.abs(gp.L_ - L).max() / np.abs(L).max() < 1e-10
+    assert np.abs(gp.alpha_ - alpha).max() / np.abs(alpha).max() < 1e-7     # cond(K) amplifies rounding
+    assert np.abs(gp._K_inv - K_inv).max() / np.abs(K_inv).max() < 1e-7
+
+    # predict a new structure with one fixed atom, E/F/sigma
+    new = fcc_cell(seed=77, reps=1, species=(46, 78), sigma=0.08)
+    new.fixed = np.array([1])
+    E, F, S, E_std, F_std = gp.predict_structure(new, stress=False, return_std=True, f_tol=1e-8)
+    des = oracle_descriptor()
+    d = des.calculate(new)
+    from gpr_calculator_amd.utilities import species_numbers
+    ele = species_numbers(d["elements"])
+    free = [0, 2, 3]
+    data = {"energy": og.list_to_tuple([(d["x"], ele)], mode="energy"), "force": []}
+    for a in free:
+        ids = np.argwhere(d["seq"][:, 1] == a).flatten()
+        ci = d["seq"][ids, 0]
+        data["force"].append((d["x"][ci], d["dxdr"][ids], ele[ci]))
+    K_trans = okern.k_total(data, train_x, 1e-8) if kind == "RBF" else okern.k_total(data, train_x)
+    mean, std = og.predict_core(K_trans, alpha, K_inv, okern.diag(data))
+    assert abs(E - mean[0] * len(new)) < E_TOL
+    assert np.abs(F[free] - mean[1:].reshape(-1, 3)).max() < F_TOL and np.all(F[1] == 0)
+    assert abs(E_std - std[0]) < E_TOL
+    assert np.abs(F_std[free] - std[1:].reshape(-1, 3)).max() < F_TOL and S is None
+
+    # batched predict of several structures equals the one-by-one path
+    batch = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(3)]
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True, f_tol=1e-8)
+    for k, s in enumerate(batch):
+        e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True, f_tol=1e-8)
+        assert abs(Es[k] - e1) < 1e-9 and np.abs(Fs[k] - f1).max() < 1e-9
+        assert abs(Es_std[k] - es1) < 1e-8 and np.abs(Fs_std[k] - fs1).max() < 1e-8
+
+    # validate_data on the training set = K alpha of the oracle
+    Et, Ep, Ft, Fp = gp.validate_data()
+    pred_o = (K @ alpha)[:, 0]
+    assert np.abs(Ep - pred_o[:NE]).max() < E_TOL and np.abs(Fp - pred_o[NE:]).max() < F_TOL
+    assert np.abs(Et - y[:NE, 0]).max() == 0 and np.abs(Ft - y[NE:, 0]).max() == 0
+
+
+def test_log_marginal_likelihood_and_gradient_match_oracle(port_natives):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from oracle import gp_numpy as og
+    strucs = training_structures(3, species=(46,))
+    force_ids = [0, 1, 2, 3]
+    gp = GP(kernel=RBF_mb(para=[1.0, 0.5], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002,
+            noise_f=0.1, log_file="/tmp/gpr_test.log")
+    gp.set_train_pts(gp.points_from_structures([(a, E, F, True, force_ids) for (a, E, F) in strucs]))
+    okern = og.OracleRBF(para=(1.0, 0.5), zeta=2.0, natives=port_natives)
+    train_x, y, NE = oracle_train(okern, strucs, force_ids)
+    for params in ([1.0, 0.5], [2.2, 1.7]):
+        lml, grad = gp.log_marginal_likelihood(np.array(params), eval_gradient=True)
+        lml_o, grad_o = og.log_marginal_likelihood(okern, train_x, y, NE, 0.002, 0.1, np.array(params))
+        assert abs(lml - lml_o) < 1e-7 * max(1.0, abs(lml_o))
+        assert np.abs(grad - grad_o).max() < 1e-6 * max(1.0, np.abs(grad_o).max())
+    # and the optimiser runs end to end on the device-evaluated objective
+    gp.fit(show=False, opt=True, maxiter=3)
+    assert gp.alpha_ is not None and gp.N_queue == 0 and gp.fits == 1
+
+
+def test_add_structure_queue_semantics():
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    strucs = training_structures(3, species=(46,))
+    gp = GP(kernel=RBF_mb(para=[1.0, 0.5], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002,
+            noise_f=0.1, log_file="/tmp/gpr_test.log")
+    # untrained model: every atom is a candidate, de-duplicated by cosine similarity (A.17)
+    pts, n_pts, _ = gp.add_structure(strucs[0])
+    assert n_pts >= 2 and gp.N_energy == 1 and gp.N_queue == n_pts
+    gp.fit(show=False, opt=False)
+    assert gp.N_queue == 0
+    n_before = gp.alpha_.shape[0]
+    gp.add_structure(strucs[1])
+    # queued points are invisible to prediction until the next fit (A.16)
+    tx = gp.get_train_x()
+    assert len(tx["energy"][-1]) == 1 and gp.alpha_.shape[0] == n_before
+    E, F, _ = gp.predict_structure(strucs[2][0], stress=False)
+    assert np.isfinite(E) and np.isfinite(F).all()
+    gp.fit(show=False, opt=False)
+    assert gp.alpha_.shape[0] > n_before
