@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the GPR hot path on MI355X.
+
+Metric (BASELINE.json): GPR predict E+F+sigma structures/sec (+ fit ms) at N_train = 2000.
+Workload (BASELINE.json configs[2], SURVEY.md section 8d "cfg3"): 2000 training force environments
+(+ 63 energy points) of seeded synthetic 32-atom fcc Pd cells, SO3(nmax=3, lmax=4, rcut=5), Dot-product
+kernel with force derivatives; one step = predict energy, forces and both standard deviations for a
+batch of 64 synthetic NEB images (descriptor -> K_trans -> K_trans alpha -> L^-1 K_trans^T -> variance),
+inputs resident on the host as ASE-like structures, model resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One JSON line on stdout (rank 0).  Extra objects: "roofline" for the dominant kernel (the force-force
+covariance block, FP64 MFMA bound) and "cpu_baseline" (the reference's CPU natives -- oracle/_ref if
+present, else the oracle's C port -- timed on a bounded sample of the same predict workload on the
+host cores).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP64_MFMA_PEAK_TFLOPS = 78.6     # 256 CU x 4 SIMD x 2.4 GHz x (2048 flop / 64 clk per v_mfma_f64_16x16x4_f64)
+FLOP_PER_PAIR_FF = 1.10e3        # force-force work per same-species row pair
+N_TRAIN = 2000
+BATCH = 64
+
+
+def build_model(kernel_name, n_train, comm):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    kern = Dot_mb(para=[2.0, 2.0], zeta=2.0) if kernel_name == "Dot" else RBF_mb(para=[2.5, 1.3], zeta=2.0)
+    gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0), noise_e=0.002, noise_f=0.1,
+            log_file=os.path.join("/tmp", f"gpr_bench_{os.getpid()}.log"))
+    n_struc = math.ceil(n_train / 32)
+    rows, left = [], n_train
+    for s in range(n_struc):
+        atoms = fcc_cell(seed=s)
+        E, F = lj_energy_forces(atoms)
+        take = min(32, left)
+        rows.append((atoms, E, F, True, list(range(take))))
+        left -= take
+    gp.set_train_pts(gp.points_from_structures(rows))
+    return gp
+
+
+def time_fit(gp, reps=2):
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        gp.fit(show=False, opt=False)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    return min(ts) * 1e3
+
+
+def same_species_pairs(ele1, ele2):
+    z1, c1 = np.unique(ele1, return_counts=True)
+    z2, c2 = np.unique(ele2, return_counts=True)
+    d2 = dict(zip(z2.tolist(), c2.tolist()))
+    return float(sum(c * d2.get(z, 0) for z, c in zip(z1.tolist(), c1.tolist())))
+
+
+def cpu_baseline(gp, batch, budget_s=20.0):
+    """Reference CPU path on a bounded sample: one structure of the batch against a slice of the training
+    force rows sized for ~budget_s of single-core rbf/dot_kff_many work, one process per host core on
+    disjoint slices of the predicted structure's rows (the reference's MPI row chunking,
+    RBF_mb.py:471-481).  Extrapolated by pair count to structures/s of the full predict workload."""
+    import multiprocessing as mp
+    from oracle.natives import NativeSet
+    kind = "reference" if NativeSet.available("ref") else "port"
+    cores = max(1, min(16, os.cpu_count() or 1))
+    d = gp.descriptor.calculate(batch[0])
+    from gpr_calculator_amd.utilities import species_numbers
+    ele = species_numbers(d["elements"])
+    data, _ = gp._structure_data(batch[0], d)
+    Xf, dXf, Ef, cntf = data["force"]
+    tX, tdX, tE, tcnt = gp.train_x["force"]
+    is_dot = gp.kernel.name == "Dot"
+    rate_guess = 0.26e6                                   # row pairs / s / core
+    n_rows2 = int(min(len(tX), max(64, budget_s * rate_guess * cores / len(Xf))))
+    full_pairs = float(len(Xf)) * len(tX) + len(d["x"]) * len(tX) + len(Xf) * len(gp.train_x["energy"][0])
+    chunks = np.array_split(np.arange(len(Xf)), cores)
+    jobs = [(kind, is_dot, Xf[c], dXf[c], Ef[c], tX[:n_rows2], tdX[:n_rows2], tE[:n_rows2]) for c in chunks if len(c)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        pool.map(_cpu_job, jobs)
+    wall = time.perf_counter() - t0
+    sample_pairs = float(len(Xf)) * n_rows2
+    per_struct = wall * full_pairs / sample_pairs
+    return {"value": 1.0 / per_struct, "unit": "structures/s", "cores": len(jobs), "kind": kind,
+            "sample": f"force-force block of 1 structure ({len(Xf)} rows) x {n_rows2} of {len(tX)} training force rows "
+                      f"({sample_pairs:.3g} row pairs in {wall:.1f} s wall on {len(jobs)} processes), extrapolated by "
+                      f"pair count to the full K_trans of one structure ({full_pairs:.3g} pairs); descriptor, "
+                      f"Cholesky solve and variance excluded (they favour the CPU figure)"}
+
+
+def _cpu_job(job):
+    kind, is_dot, x1, dx1, e1, x2, dx2, e2 = job
+    from oracle.natives import NativeSet
+    ns = NativeSet("ref" if kind == "reference" else "port")
+    n1, n2, d = len(x1), len(x2), x1.shape[1]
+    i1, i2 = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
+    out = np.zeros((1, 3, 1, 3))
+    c = np.ascontiguousarray
+    if is_dot:
+        ns.call("dot_kff_many", n1, n2, 0, n2, d, 1, 2.0, c(x1), c(dx1), c(e1, np.int32), i1, c(x2), c(dx2),
+                c(e2, np.int32), i2, out)
+    else:
+        ns.call("rbf_kff_many", n1, n2, 0, n2, d, 1, 2.0, 6.25, 1.69, 1e-8, c(x1), c(dx1), c(e1, np.int32), i1,
+                c(x2), c(dx2), c(e2, np.int32), i2, out)
+    return float(out.sum())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--kernel", default="Dot", choices=["Dot", "RBF"])
+    ap.add_argument("--n-train", type=int, default=N_TRAIN)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from gpr_calculator_amd import _lib, device as dev
+    from gpr_calculator_amd.parallel import init_from_env
+    from gpr_calculator_amd.synthetic import neb_images
+    comm = init_from_env()
+    rank, world = comm.rank, comm.size
+    if world == 1:
+        torch.cuda.set_device(0)
+    _lib.require_gpu()
+
+    gp = build_model(args.kernel, args.n_train, comm)
+    fit_ms = time_fit(gp)                          # K assembly (sharded over ranks) + Cholesky + alpha
+    # weak scaling: every rank predicts its own batch of images with the replicated model
+    batch = neb_images(args.batch, seed=100 + 10 * rank)
+    gp.comm = _Serial()      # predict_structures shards a batch over gp.comm; here each rank owns a whole batch
+
+    def step():
+        return gp.predict_structures(batch, return_std=True, f_tol=1e-8)
+
+    for _ in range(args.warmup):
+        step()
+    comm.barrier()
+    torch.cuda.synchronize()
+    dev.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = time.perf_counter() - t0
+    prof = dev.profile_fetch()
+    dev.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(np.isfinite(e) for e in out[0])
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.batch * args.steps / elapsed
+        # roofline of the dominant kernel: force-force block of K_trans (one launch per step)
+        ff_ms, ff_n = prof["ff"]
+        desc = gp.descriptor.calculate_batch_dev(batch)
+        # every seq row (i, j) is one row of atom j's force point; its species is that of centre i
+        ele_rows = np.concatenate([np.asarray(nums)[sq[:, 0]] for nums, sq in zip(desc["numbers"], desc["seq"])])
+        tX, _, tE, _ = gp.train_x["force"]
+        pairs = same_species_pairs(ele_rows, tE)
+        avg_ms = ff_ms / max(ff_n, 1)
+        achieved = pairs * FLOP_PER_PAIR_FF / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "kblock_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                    "kernel": "kblock_kernel<FF> (force-force block of K_trans)", "avg_launch_ms": avg_ms,
+                    "launches": ff_n, "row_pairs_per_launch": pairs, "flop_per_pair": FLOP_PER_PAIR_FF}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(gp, batch)
+        N = gp.alpha_.shape[0]
+        line = {"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": value,
+                "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"cfg3: N_train={args.n_train} force environments + {len(gp.train_x['energy'][-1])} "
+                                       f"energy points (N={N}), {args.kernel} kernel zeta=2, SO3(3,4,5.0), predict "
+                                       f"E/F/sigma batch of {args.batch} 32-atom structures per GPU",
+                           "kernel": args.kernel, "n_train": args.n_train, "batch_per_gpu": args.batch, "N": int(N),
+                           "train_force_rows": int(len(tX)), "fit_ms": fit_ms,
+                           "parallelism": f"replicated model, structure-parallel predict x{world}; fit K sharded x{world}"},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+class _Serial:
+    """stand-in communicator: rank 0 of 1 (each rank predicts its own whole batch in the weak-scaling run)"""
+    rank, size, active = 0, 1, False
+
+    def barrier(self):
+        pass
+
+    def bcast(self, obj, root=0):
+        return obj
+
+
+if __name__ == "__main__":
+    main()

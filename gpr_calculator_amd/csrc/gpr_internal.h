@@ -58,6 +58,9 @@ struct gpr_set {
     double *inv_cnt = nullptr; // [npts] 1/rows of the point, packed order
     gpr_chunk *chunks = nullptr;    // stream only
     int *pt_chunk0 = nullptr;       // stream only [npts+1]
+    int *ir_chunk0 = nullptr;       // stream only [nranges+1] chunk range of each launch range
+    int *ir_pt0 = nullptr;          // stream only [nranges+1] first packed point of each range
+    int nranges = 0;
     gpr_rpoint *rpts = nullptr;     // resident only [npts]
     int nchunks = 0, maxgroups = 0;
     // host mirrors used for launch planning

@@ -310,6 +310,9 @@ static void launch_zg(hipStream_t st, bool z2, bool grad, int nw, int nblocks, c
 }
 
 static thread_local int g_shard_mod = 1, g_shard_rem = 0;
+struct prof_rec { int mode; hipEvent_t start, stop; };
+static thread_local bool g_prof_on = false;
+static thread_local std::vector<prof_rec> g_prof;
 
 extern "C" int gpr_set_shard(int nshards, int shard) {
     GPR_REQUIRE(nshards >= 1 && shard >= 0 && shard < nshards, "gpr_set_shard: bad shard %d of %d", shard, nshards);
@@ -338,37 +341,8 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     if (c.diag_only) nw = 4;
     const int njb = (s2->npts + nw - 1) / nw;
 
-    // stream ranges: consecutive packed points, about RANGE_TILES tiles each
-    const int RANGE_TILES = 128;
-    std::vector<int> ir_chunk0{0}, ir_pt0{0};
-    if (!c.diag_only) {
-        int tiles = 0;
-        for (int p = 0; p < s1->npts; p++) {
-            tiles += s1->h_pt_tiles[p];
-            if (tiles >= RANGE_TILES && p + 1 < s1->npts) {
-                ir_chunk0.push_back(s1->h_pt_chunk0[p + 1]);
-                ir_pt0.push_back(p + 1);
-                tiles = 0;
-            }
-        }
-    }
-    ir_chunk0.push_back(s1->nchunks);
-    ir_pt0.push_back(s1->npts);
-    const int nir = (int)ir_chunk0.size() - 1;
-
-    int *d_meta = nullptr;
-    std::vector<int> meta(ir_chunk0);
-    meta.insert(meta.end(), ir_pt0.begin(), ir_pt0.end());
-    {
-        void *p;
-        int rc = gpr_dev_alloc(&p, meta.size() * sizeof(int), st);
-        if (rc) return rc;
-        d_meta = (int *)p;
-        GPR_HIP_TRY(hipMemcpyAsync(d_meta, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, st));
-        // meta is a host temporary: pageable async copies are staged before return on ROCm, but
-        // be explicit so the vector may die safely
-        GPR_HIP_TRY(hipStreamSynchronize(st));
-    }
+    // stream ranges (consecutive packed points, ~128 tiles each) were laid out at pack time
+    const int nir = c.diag_only ? 1 : s1->nranges;
 
     kb_args a;
     a.a_ops = s1->ops; a.a_ele = s1->ele; a.a_norm = s1->norms; a.a_chunks = s1->chunks;
@@ -376,7 +350,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     a.b_ops = s2->ops; a.b_ele = s2->ele; a.b_norm = s2->norms; a.b_pts = s2->rpts;
     a.b_perm = s2->perm; a.b_inv = s2->inv_cnt;
     a.b_npts = s2->npts; a.a_npts = s1->npts;
-    a.ir_chunk0 = d_meta; a.ir_pt0 = d_meta + (nir + 1);
+    a.ir_chunk0 = s1->ir_chunk0; a.ir_pt0 = s1->ir_pt0;
     a.njb = njb; a.nir = nir;
     a.shard_mod = g_shard_mod; a.shard_rem = g_shard_rem;
     a.symmetric = c.symmetric; a.diag_only = c.diag_only; a.eps_mode = c.eps_mode;
@@ -389,6 +363,12 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     a.out = c.out; a.s_i = c.s_i; a.s_j = c.s_j; a.s_a = c.s_a; a.s_b = c.s_b;
     a.dl = c.dl; a.d_i = c.d_i; a.d_j = c.d_j; a.d_a = c.d_a; a.d_b = c.d_b;
 
+    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
+    if (g_prof_on) {
+        GPR_HIP_TRY(hipEventCreate(&prof_start));
+        GPR_HIP_TRY(hipEventCreate(&prof_stop));
+        GPR_HIP_TRY(hipEventRecord(prof_start, st));
+    }
     const bool z2 = (c.zeta == 2.0);
     const int nblocks = c.diag_only ? njb : njb * nir;
     const bool grad = c.grad != 0;
@@ -403,5 +383,31 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("kblock launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
-    return gpr_dev_free(d_meta, st);
+    if (prof_stop) {
+        GPR_HIP_TRY(hipEventRecord(prof_stop, st));
+        g_prof.push_back(prof_rec{c.diag_only ? 3 : c.mode, prof_start, prof_stop});
+    }
+    return GPR_OK;
+}
+
+extern "C" int gpr_profile_enable(int on) {
+    g_prof_on = on != 0;
+    for (auto &r : g_prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
+    g_prof.clear();
+    return GPR_OK;
+}
+
+// sums the kernel-only durations (ms) and launch counts recorded since gpr_profile_enable(1), per block
+// kind: index 0 = force-force, 1 = energy-force, 2 = energy-energy, 3 = diagonal-only launches; clears the records
+extern "C" int gpr_profile_fetch(double *ms_by_mode, int *launches_by_mode) {
+    for (int k = 0; k < 4; k++) { ms_by_mode[k] = 0.0; launches_by_mode[k] = 0; }
+    for (auto &r : g_prof) {
+        GPR_HIP_TRY(hipEventSynchronize(r.stop));
+        float ms = 0.f;
+        GPR_HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
+        ms_by_mode[r.mode] += ms; launches_by_mode[r.mode] += 1;
+        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
+    }
+    g_prof.clear();
+    return GPR_OK;
 }

@@ -222,6 +222,17 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
     if (role == GPR_ROLE_STREAM) {
         if ((rc = upload(&s->chunks, chunks, st, &bytes))) return fail(rc);
         if ((rc = upload(&s->pt_chunk0, s->h_pt_chunk0, st, &bytes))) return fail(rc);
+        // launch ranges: consecutive packed points, about 128 tiles each (one task = range x point block)
+        std::vector<int> irc{0}, irp{0};
+        int tiles = 0;
+        for (int p = 0; p < npts; p++) {
+            tiles += s->h_pt_tiles[p];
+            if (tiles >= 128 && p + 1 < npts) { irc.push_back(s->h_pt_chunk0[p + 1]); irp.push_back(p + 1); tiles = 0; }
+        }
+        irc.push_back(s->nchunks); irp.push_back(npts);
+        s->nranges = (int)irc.size() - 1;
+        if ((rc = upload(&s->ir_chunk0, irc, st, &bytes))) return fail(rc);
+        if ((rc = upload(&s->ir_pt0, irp, st, &bytes))) return fail(rc);
     } else {
         if ((rc = upload(&s->rpts, rpts, st, &bytes))) return fail(rc);
     }
@@ -267,6 +278,7 @@ extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
     gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
     gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
     gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st);
+    gpr_dev_free(s->ir_chunk0, st); gpr_dev_free(s->ir_pt0, st);
     delete s;
     return GPR_OK;
 }

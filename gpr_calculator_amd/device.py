@@ -228,3 +228,15 @@ def frob_dot(a, b):
     check(_lib.lib().gpr_frob_dot(stream_ptr(), m, n, ptr(a2), max(int(a2.stride(0)), n), ptr(b2),
                                   max(int(b2.stride(0)), n), ptr(out)), "gpr_frob_dot")
     return out
+
+
+def profile_enable(on=True):
+    check(_lib.lib().gpr_profile_enable(int(on)), "gpr_profile_enable")
+
+
+def profile_fetch():
+    """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable()"""
+    ms = (C.c_double * 4)()
+    n = (C.c_int * 4)()
+    check(_lib.lib().gpr_profile_fetch(ms, n), "gpr_profile_fetch")
+    return {k: (ms[i], n[i]) for i, k in enumerate(("ff", "ef", "ee", "diag"))}

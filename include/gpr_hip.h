@@ -119,6 +119,14 @@ int gpr_diag_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
 int gpr_diag_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
                 const gpr_set *set2, double *out);
 
+/* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
+ * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
+ * gpr_profile_fetch sums the durations (ms) and launch counts per block kind
+ * (4 entries: 0 force-force, 1 energy-force, 2 energy-energy, 3 diagonal-only launches) and clears
+ * the records. */
+int gpr_profile_enable(int on);
+int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
+
 /* Multi-GPU sharding of the block calls issued from this host thread: with (nshards, shard) set, a
  * gpr_block_* call evaluates only the point-pair tasks t with t % nshards == shard and leaves every
  * other output element untouched (zero after the call's own zero-fill).  Summing the outputs of all
