@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
     __shared__ double As[BK][LDS_LD];
     __shared__ double Bs[BK][LDS_LD];
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
-    if (lower_only && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
+    if ((lower_only & 1) && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
+    if (lower_only & 2) k = min(k, bm0 + BM);                // op(A) lower triangular: zero beyond the row block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     d4 acc[2][2];
@@ -256,6 +257,17 @@ extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int 
     GPR_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gpr_gemm: negative dimension");
     GPR_REQUIRE(m == 0 || n == 0 || (c && (k == 0 || (a && b))), "gpr_gemm: null pointer");
     return launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
+}
+
+// C[n, nrhs] = T B with T an n x n LOWER-triangular matrix (entries above the diagonal are never
+// read): the k loop of each row block stops at its diagonal.  Used with T = L^-1 for the predictive
+// variance, V = L^-1 K_trans^T (gaussianprocess.py:903-907 evaluates the same quantity through K^-1).
+extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
+                              long long ldb, double *c, long long ldc) {
+    GPR_REQUIRE(n >= 0 && nrhs >= 0, "gpr_trmm_lower: negative dimension");
+    if (n == 0 || nrhs == 0) return GPR_OK;
+    GPR_REQUIRE(t && b && c && ldt >= n && ldb >= nrhs && ldc >= nrhs, "gpr_trmm_lower: bad arguments");
+    return launch_gemm((hipStream_t)stream, 0, 0, n, nrhs, n, 1.0, t, ldt, b, ldb, 0.0, c, ldc, 2);
 }
 
 // Blocked right-looking lower Cholesky: diagonal block (one workgroup), panel solve, then the

@@ -195,6 +195,17 @@ def gemm(a, b, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
     return out
 
 
+def trmm_lower(t, b, out=None):
+    """t @ b with t lower triangular [n, n], b [n, nrhs] (row-major device matrices)"""
+    n, nrhs = b.shape
+    if out is None:
+        out = torch.empty((n, nrhs), dtype=F64, device=b.device)
+    check(_lib.lib().gpr_trmm_lower(stream_ptr(), n, nrhs, ptr(t), max(int(t.stride(0)), n), ptr(b),
+                                    max(int(b.stride(0)), nrhs), ptr(out), max(int(out.stride(0)), nrhs)),
+          "gpr_trmm_lower")
+    return out
+
+
 def add_diag_(a, n_first, add_first, add_rest):
     n = a.shape[0]
     check(_lib.lib().gpr_add_diag(stream_ptr(), n, ptr(a), max(int(a.stride(0)), n), int(n_first), float(add_first),

@@ -82,6 +82,7 @@ class GP():
         self._L_dev = None          # lower Cholesky factor of K + noise  [N, N]
         self._alpha_dev = None      # (K + noise)^-1 y                    [N, 1]
         self._K_inv_dev = None
+        self._Linv_dev = None
         self._host = {}             # lazily downloaded numpy mirrors
 
         self.fits = 0
@@ -137,9 +138,7 @@ class GP():
     def set_K_inv(self):
         """K^-1 = L^-T L^-1 (gaussianprocess.py:128-131), formed on the device only when asked for."""
         if self._K_inv_dev is None and self._L_dev is not None:
-            n = self._L_dev.shape[0]
-            Linv = torch.eye(n, dtype=dev.F64, device=self._L_dev.device)
-            dev.trsm_lower_(self._L_dev, Linv)
+            Linv = self._Linv()
             self._K_inv_dev = dev.gemm(Linv, Linv, transa=True)
 
     # ------------------------------------------------------------------ covariance of the training set
@@ -275,6 +274,7 @@ class GP():
         dev.trsm_lower_(self._L_dev, alpha, trans=True)
         self._alpha_dev = alpha
         self._K_inv_dev = None
+        self._Linv_dev = None
         self._host = {}
         self.logging.info("Cholesky Decomp is Complete")
         self.comm.barrier()
@@ -296,9 +296,19 @@ class GP():
         if not return_std:
             return mean, None
         var = self.kernel.diag_dev(X)
-        dev.trsm_lower_(self._L_dev, Kt)                                          # V = L^-1 K_trans^T
-        var = var - dev.colsumsq(Kt)
+        V = dev.trmm_lower(self._Linv(), Kt)                                      # V = L^-1 K_trans^T
+        var = var - dev.colsumsq(V)
         return mean, torch.clamp_min(var, 0.0)
+
+    def _Linv(self):
+        """L^-1 on the device (lower triangular), built once per fit: the variance of every later
+        prediction is then one triangular matrix product instead of a substitution sweep"""
+        if self._Linv_dev is None:
+            n = self._L_dev.shape[0]
+            Linv = torch.eye(n, dtype=dev.F64, device=self._L_dev.device)
+            dev.trsm_lower_(self._L_dev, Linv)
+            self._Linv_dev = Linv
+        return self._Linv_dev
 
     def predict(self, X, stress=False, total_E=False, return_std=False, return_cov=False):
         """Internal predict function (gaussianprocess.py:319-379)."""
@@ -578,14 +588,7 @@ class GP():
         mine = list(range(rank, nb, size)) if size > 1 else list(range(nb))
         results = {}
         if mine:
-            datas, frees, counts_e, counts_f = [], [], [], []
-            for k in mine:
-                d = self.descriptor.calculate(strucs[k])
-                data, free_ids = self._structure_data(strucs[k], d)
-                datas.append(data)
-                frees.append(free_ids)
-            X = {"energy": _concat_energy([dt["energy"] for dt in datas]),
-                 "force": _concat_force([dt["force"] for dt in datas])}
+            X, frees = self._batch_data_dev([strucs[k] for k in mine])
             mean, var = self._predict_dev(X, self.get_train_x(), f_tol, return_std)
             mean = mean.cpu().numpy()
             std = np.sqrt(var.cpu().numpy()) if return_std else None
@@ -619,6 +622,42 @@ class GP():
             E, F, es, fs = results[k]
             Es.append(E); Fs.append(F); Es_std.append(es); Fs_std.append(fs)
         return Es, Fs, Es_std, Fs_std
+
+    def _batch_data_dev(self, strucs):
+        """the predict_structure data dictionary of a batch of structures, packed on the device straight
+        from the descriptor kernel's output (no host round trip of x / dxdr): energy points = all atoms of
+        each structure; force points = for every free atom a the seq rows with seq[:, 1] == a
+        (gaussianprocess.py:852-870)."""
+        if not hasattr(self.descriptor, "calculate_batch_dev"):
+            datas, frees = [], []
+            for s in strucs:
+                data, free_ids = self._structure_data(s, self.descriptor.calculate(s))
+                datas.append(data); frees.append(free_ids)
+            return {"energy": _concat_energy([dt["energy"] for dt in datas]),
+                    "force": _concat_force([dt["force"] for dt in datas])}, frees
+        desc = self.descriptor.calculate_batch_dev(strucs)
+        ele_atoms = np.concatenate(desc["numbers"]).astype(np.int32)
+        row_idx, centre_idx, counts_f, frees = [], [], [], []
+        for k, s in enumerate(strucs):
+            seq, n = desc["seq"][k], len(s)
+            fix = set(int(i) for i in self._get_fixed_atoms(s))
+            order = np.argsort(seq[:, 1], kind="stable")
+            keep = np.ones(n, dtype=bool)
+            if fix:
+                keep[list(fix)] = False
+            rows = order[keep[seq[order, 1]]]
+            row_idx.append(rows + desc["row0"][k])
+            centre_idx.append(seq[rows, 0] + desc["atom0"][k])
+            counts_f.extend(np.bincount(seq[:, 1], minlength=n)[keep].tolist())
+            frees.append([i for i in range(n) if i not in fix])
+        row_idx = dev.to_dev(np.concatenate(row_idx), torch.int64)
+        centre_host = np.concatenate(centre_idx)
+        centre_idx = dev.to_dev(centre_host, torch.int64)
+        xf = desc["x"].index_select(0, centre_idx)
+        dxf = desc["dxdr"].index_select(0, row_idx)
+        E = dev.SetPair(desc["x"], None, ele_atoms, [len(s) for s in strucs])
+        F = dev.SetPair(xf, dxf, ele_atoms[centre_host], counts_f)
+        return {"energy": E, "force": F}, frees
 
     def add_structure(self, data, N_max=20, tol_e_var=1.2, tol_f_var=1.2, add_force=True):
         """Queue training points from a labelled structure (gaussianprocess.py:921-1002): the energy

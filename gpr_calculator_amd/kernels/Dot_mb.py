@@ -62,12 +62,9 @@ class Dot_mb(DeviceKernel):
         parts = []
         kp = self._kp(self.zeta)
         if "energy" in data and n_points(data["energy"]) > 0:
-            X, ELE, counts = as_energy_tuple(data["energy"])
-            parts.append(dev.diag_ee(kp, dev.SetPair(X, None, ELE, counts, flags=_lib.SET_NUMPY_EPS)))
+            parts.append(dev.diag_ee(kp, self.pack_energy(data["energy"], flags=_lib.SET_NUMPY_EPS)))
         if "force" in data and n_points(data["force"]) > 0:
-            X, dXdR, ELE, counts = as_force_tuple(data["force"])
-            pair = dev.SetPair(X, np.ascontiguousarray(dXdR[:, :, :3]), ELE, counts, flags=_lib.SET_NUMPY_EPS)
-            parts.append(dev.diag_ff(kp, pair))
+            parts.append(dev.diag_ff(kp, self.pack_force(data["force"], flags=_lib.SET_NUMPY_EPS)))
         return torch.cat(parts) if parts else None
 
     # ------------------------------------------------------------------ reference protocol (numpy out)

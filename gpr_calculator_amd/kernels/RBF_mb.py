@@ -57,9 +57,7 @@ class RBF_mb(DeviceKernel):
         cosine of K_ee_RBF (base.py:107-130), forces through kff_C(dat, dat) with its default tol 1e-12."""
         parts = []
         if "energy" in data and n_points(data["energy"]) > 0:
-            X, ELE, counts = as_energy_tuple(data["energy"])
-            pair = dev.SetPair(X, None, ELE, counts, flags=_lib.SET_NUMPY_EPS)
-            parts.append(dev.diag_ee(self._kp(), pair))
+            parts.append(dev.diag_ee(self._kp(), self.pack_energy(data["energy"], flags=_lib.SET_NUMPY_EPS)))
         if "force" in data and n_points(data["force"]) > 0:
             parts.append(dev.diag_ff(self._kp(1e-12), self.pack_force(data["force"])))
         import torch

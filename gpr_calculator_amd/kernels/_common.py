@@ -13,7 +13,10 @@ from ..utilities import list_to_tuple
 
 
 def as_energy_tuple(e):
-    """accept the (X, ELE, counts) tuple or a list of (x, ele) (kee_C: rbf_kernel.py:26-27)"""
+    """accept the (X, ELE, counts) tuple or a list of (x, ele) (kee_C: rbf_kernel.py:26-27), or an
+    already packed device SetPair (its raw device tensors are returned)"""
+    if isinstance(e, dev.SetPair):
+        return (e.stream.x, e.stream.ele, e.counts)
     if isinstance(e, tuple) and len(e) == 3 and not isinstance(e[0], tuple):
         return e
     return list_to_tuple(list(e), mode="energy")
@@ -21,6 +24,8 @@ def as_energy_tuple(e):
 
 def as_force_tuple(f, stress=False):
     """accept (X, dXdR, ELE, counts) or a list / object array of (x, dxdr, ele) (kef_C: rbf_kernel.py:112-113)"""
+    if isinstance(f, dev.SetPair):
+        return (f.stream.x, f.stream.dxdr, f.stream.ele, f.counts)
     if isinstance(f, tuple) and len(f) == 4 and not isinstance(f[0], tuple):
         return f
     return list_to_tuple(list(f), stress=stress)
@@ -28,6 +33,8 @@ def as_force_tuple(f, stress=False):
 
 def n_points(entry):
     """number of points of a data-dict entry in either representation"""
+    if isinstance(entry, dev.SetPair):
+        return entry.npts
     if isinstance(entry, tuple) and len(entry) in (3, 4) and not isinstance(entry[0], tuple):
         return len(entry[-1])
     return len(entry)
@@ -70,11 +77,19 @@ class DeviceKernel:
 
     # ---- packing
     def pack_energy(self, e, flags=0):
+        if isinstance(e, dev.SetPair) and e.stream.flags == flags:
+            return e
         X, ELE, counts = as_energy_tuple(e)
+        if isinstance(X, torch.Tensor):
+            return dev.SetPair(X, None, ELE, counts, flags=flags)
         return self._cache.get(X, ("E", flags), lambda: dev.SetPair(X, None, ELE, counts, flags=flags))
 
     def pack_force(self, f, flags=0):
+        if isinstance(f, dev.SetPair) and f.stream.flags == flags:
+            return f
         X, dXdR, ELE, counts = as_force_tuple(f)
+        if isinstance(X, torch.Tensor):
+            return dev.SetPair(X, dXdR[:, :, :3].contiguous(), ELE, counts, flags=flags)
         if dXdR.shape[-1] != 3:
             dXdR = np.ascontiguousarray(dXdR[:, :, :3])
         return self._cache.get(X, ("F", flags), lambda: dev.SetPair(X, dXdR, ELE, counts, flags=flags))

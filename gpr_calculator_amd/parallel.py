@@ -61,11 +61,13 @@ class Comm:
         """concatenate row slabs [counts[r], ncols] of every rank into [sum(counts), ncols]"""
         if not self.active or self.size == 1:
             return local
-        ncols = local.shape[1]
-        out = torch.empty((int(sum(counts)), ncols), dtype=local.dtype, device=local.device)
-        chunks = list(out.split([int(c) for c in counts], dim=0))
-        dist.all_gather(chunks, local.contiguous(), group=self.group)
-        return out
+        # all_gather wants equal shapes: pad every slab to the largest one, then cut the padding off
+        ncols, cmax = local.shape[1], int(max(counts))
+        padded = torch.zeros((cmax, ncols), dtype=local.dtype, device=local.device)
+        padded[:local.shape[0]] = local
+        parts = [torch.empty_like(padded) for _ in range(self.size)]
+        dist.all_gather(parts, padded, group=self.group)
+        return torch.cat([p[:int(c)] for p, c in zip(parts, counts)], dim=0)
 
     def all_reduce_sum_(self, t):
         if self.active and self.size > 1:

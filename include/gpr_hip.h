@@ -160,6 +160,9 @@ int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
 int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                    double *b, long long ldb);
+/* C[n,nrhs] = T B with T lower triangular n x n (its strict upper triangle is never read) */
+int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
+                   long long ldb, double *c, long long ldc);
 /* C[m,n] = alpha * op(A) op(B) + beta * C, row-major, op = transpose if the flag is set */
 int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
              const double *a, long long lda, const double *b, long long ldb, double beta,
