@@ -205,23 +205,49 @@ class SO3:
         return dict(n=n, centres=centres, numbers=numbers, vec=vec, w=w, seq=seq, centre_pair0=centre_pair0,
                     centre_row0=centre_row0, row_pair0=row_pair0, self_row=self_row)
 
+    def neighbor_index_batch(self, strucs):
+        """neighbour pairs, `seq` and the pair / row maps of a batch of structures through the native
+        host routine gpr_nbr_build (csrc/nbr.hip); same content as neighbor_index, concatenated"""
+        arrs = [atoms_arrays(s) for s in strucs]
+        atom0 = np.concatenate(([0], np.cumsum([len(a[0]) for a in arrs]))).astype(np.int32)
+        numbers = np.ascontiguousarray(np.concatenate([a[0] for a in arrs]), dtype=np.int32)
+        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
+        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
+        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32)
+        L = _lib.lib()
+        h = C.c_void_p()
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        dev.check(L.gpr_nbr_build(C.byref(h), len(strucs), ip(atom0), dp(pos), dp(cells), ip(pbc), ip(numbers),
+                                  float(self.rcut), int(bool(self.weight_on))), "gpr_nbr_build")
+        try:
+            P, S = C.c_int(), C.c_int()
+            dev.check(L.gpr_nbr_sizes(h, C.byref(P), C.byref(S)), "gpr_nbr_sizes")
+            P, S, n = P.value, S.value, int(atom0[-1])
+            out = dict(vec=np.empty((P, 3)), w=np.empty(P), centre_pair0=np.empty(n + 1, np.int32),
+                       centre_row0=np.empty(n + 1, np.int32), row_pair0=np.empty(S + 1, np.int32),
+                       self_row=np.empty(n, np.int32), seq=np.empty((S, 2), np.int32),
+                       row0=np.empty(len(strucs) + 1, np.int32))
+            dev.check(L.gpr_nbr_export(h, dp(out["vec"]), dp(out["w"]), ip(out["centre_pair0"]), ip(out["centre_row0"]),
+                                       ip(out["row_pair0"]), ip(out["self_row"]), ip(out["seq"]), ip(out["row0"])),
+                      "gpr_nbr_export")
+        finally:
+            L.gpr_nbr_destroy(h)
+        out["seq"] = out["seq"].astype(np.int64)
+        out["atom0"], out["numbers"] = atom0.astype(np.int64), numbers.astype(np.int64)
+        out["row0"] = out["row0"].astype(np.int64)
+        return out
+
     def calculate_batch_dev(self, strucs):
         """Descriptors of several structures in one launch.  Returns a dict of device tensors
         x [sum n, d], dxdr [sum S, d, 3] and host arrays: seq [sum S, 2] (local atom ids),
         struct_atom0 / struct_row0 offsets, numbers."""
         if not self.derivative:
             raise NotImplementedError("derivative=False is not used on the GPR hot path")
-        idx = [self.neighbor_index(s) for s in strucs]
-        atom0 = np.concatenate(([0], np.cumsum([i["n"] for i in idx]))).astype(np.int64)
-        row0 = np.concatenate(([0], np.cumsum([len(i["seq"]) for i in idx]))).astype(np.int64)
-        pair0 = np.concatenate(([0], np.cumsum([len(i["vec"]) for i in idx]))).astype(np.int64)
-        vec = np.concatenate([i["vec"] for i in idx], axis=0) if pair0[-1] else np.zeros((0, 3))
-        w = np.concatenate([i["w"] for i in idx])
-        cp0 = np.concatenate([i["centre_pair0"][:-1] + pair0[k] for k, i in enumerate(idx)] + [[pair0[-1]]]).astype(np.int32)
-        cr0 = np.concatenate([i["centre_row0"][:-1] + row0[k] for k, i in enumerate(idx)] + [[row0[-1]]]).astype(np.int32)
-        rp0 = np.concatenate([i["row_pair0"][:-1] + pair0[k] for k, i in enumerate(idx)] + [[pair0[-1]]]).astype(np.int32)
-        sr = np.concatenate([i["self_row"] + row0[k] for k, i in enumerate(idx)]).astype(np.int32)
-        nc, P, S, d = int(atom0[-1]), int(pair0[-1]), int(row0[-1]), self.ncoefs
+        nb = self.neighbor_index_batch(strucs)
+        atom0, row0, numbers = nb["atom0"], nb["row0"], nb["numbers"]
+        vec, w, cp0, cr0, rp0, sr = nb["vec"], nb["w"], nb["centre_pair0"], nb["centre_row0"], nb["row_pair0"], nb["self_row"]
+        nc, P, S, d = int(atom0[-1]), len(w), int(row0[-1]), self.ncoefs
         rq, G, nq = self._device_tables()
         D = dev.device()
         x = torch.empty((nc, d), dtype=dev.F64, device=D)
@@ -235,8 +261,9 @@ class SO3:
             dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nq, dev.ptr(G), dev.ptr(rq),
             nc, P, S, dev.ptr(d_vec), dev.ptr(d_w), dev.ptr(d_cp0), dev.ptr(d_cr0), dev.ptr(d_rp0), dev.ptr(d_sr),
             dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
-        return dict(x=x, dxdr=dxdr, seq=[i["seq"] for i in idx], numbers=[i["numbers"] for i in idx],
-                    atom0=atom0, row0=row0)
+        seq = nb["seq"]
+        return dict(x=x, dxdr=dxdr, seq=[seq[row0[k]:row0[k + 1]] for k in range(len(strucs))],
+                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))], atom0=atom0, row0=row0)
 
     def calculate(self, atoms, atom_ids=None, use_mpi=False):
         '''

@@ -17,8 +17,8 @@
 // operands of one 16-row group of it in registers; the workgroup streams the tiles of the
 // stream ("set 1") points through double-buffered LDS; each wavefront accumulates the bin (i, j)
 // in registers and, at the last tile of point i, reduces over its 64 lanes and adds the 3x3
-// (3, 1) result to the output with a plain read-modify-write (exactly one wavefront ever touches a
-// bin, so no atomics and a deterministic summation order).
+// (3, 1) result to the output with no-return FP64 atomic adds (exactly one wavefront ever touches a
+// bin and adds to it in program order, so the summation order is deterministic).
 #include "gpr_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -128,42 +128,36 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
         // ---- stage the first chunk
         float4 regs[NLD];
         int ereg = 0; double nreg = 0.0;
-        auto stage_load = [&](int c) {
-            const gpr_chunk ch = P.a_chunks[c];
-            const char *src = (const char *)(P.a_ops + (size_t)ch.tile0 * GPR_PLANE);
-            const int bytes = ch.ntiles * GPR_PLANE * 8;
-#pragma unroll
-            for (int i = 0; i < NLD; i++) {
-                int off = (i * NTHREADS + tid) * 16;
-                if (off < bytes) regs[i] = *(const float4 *)(src + off);
-            }
-            if (tid < ch.ntiles * AROWS) {
-                ereg = P.a_ele[ch.tile0 * AROWS + tid];
-                if (MODE == GPR_MODE_EE) nreg = P.a_norm[ch.tile0 * AROWS + tid];
-            }
-        };
-        auto stage_store = [&](int c, int buf) {
-            const gpr_chunk ch = P.a_chunks[c];
-            const int bytes = ch.ntiles * GPR_PLANE * 8;
-            char *dst = (char *)sA[buf];
-#pragma unroll
-            for (int i = 0; i < NLD; i++) {
-                int off = (i * NTHREADS + tid) * 16;
-                if (off < bytes) *(float4 *)(dst + off) = regs[i];
-            }
-            if (tid < ch.ntiles * AROWS) {
-                sEle[buf][tid] = ereg;
-                if (MODE == GPR_MODE_EE) sNorm[buf][tid] = nreg;
-            }
-        };
-        stage_load(c0);
-        stage_store(c0, 0);
+        // global -> registers (issued before the tile loop) and registers -> LDS (after it); macros rather
+        // than lambdas so that the staging registers are never address-taken (no scratch)
+#define GPR_STAGE_LOAD(C_)                                                                              \
+        {   const gpr_chunk ch_ = P.a_chunks[(C_)];                                                      \
+            const char *src_ = (const char *)(P.a_ops + (size_t)ch_.tile0 * GPR_PLANE);                  \
+            const int bytes_ = ch_.ntiles * GPR_PLANE * 8;                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < NLD; i_++) {                                         \
+                const int off_ = (i_ * NTHREADS + tid) * 16;                                             \
+                regs[i_] = (off_ < bytes_) ? *(const float4 *)(src_ + off_) : make_float4(0.f, 0.f, 0.f, 0.f); } \
+            if (tid < ch_.ntiles * AROWS) {                                                              \
+                ereg = P.a_ele[ch_.tile0 * AROWS + tid];                                                 \
+                if (MODE == GPR_MODE_EE) nreg = P.a_norm[ch_.tile0 * AROWS + tid]; } }
+#define GPR_STAGE_STORE(C_, BUF_)                                                                       \
+        {   const gpr_chunk ch_ = P.a_chunks[(C_)];                                                      \
+            const int bytes_ = ch_.ntiles * GPR_PLANE * 8;                                               \
+            char *dst_ = (char *)sA[(BUF_)];                                                             \
+            _Pragma("unroll") for (int i_ = 0; i_ < NLD; i_++) {                                         \
+                const int off_ = (i_ * NTHREADS + tid) * 16;                                             \
+                if (off_ < bytes_) *(float4 *)(dst_ + off_) = regs[i_]; }                                \
+            if (tid < ch_.ntiles * AROWS) {                                                              \
+                sEle[(BUF_)][tid] = ereg;                                                                \
+                if (MODE == GPR_MODE_EE) sNorm[(BUF_)][tid] = nreg; } }
+        GPR_STAGE_LOAD(c0)
+        GPR_STAGE_STORE(c0, 0)
         __syncthreads();
 
         for (int c = c0; c < c1; ++c) {
             const int buf = (c - c0) & 1;
             const gpr_chunk ch = P.a_chunks[c];
-            if (c + 1 < c1) stage_load(c + 1);
+            if (c + 1 < c1) GPR_STAGE_LOAD(c + 1)
 
             bool mine = has;
             if (P.symmetric && ch.pt > jp) mine = false;     // below the diagonal
@@ -254,43 +248,69 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                 if (ch.last) {
                     const int i_orig = P.a_perm[ch.pt];
                     const double fac = fac_j * (P.norm1 ? P.a_inv[ch.pt] : 1.0);
-                    double mineV = 0.0, mineD = 0.0;
-#pragma unroll
-                    for (int k = 0; k < NOUT; k++) {
-                        const double tot = wave_sum(bin[k]);
-                        mineV = (lane == k) ? tot : mineV;
-                        bin[k] = 0.0;
-                        if (GRAD) {
-                            const double tot2 = wave_sum(bin2[k]);
-                            mineD = (lane == k) ? tot2 : mineD;
-                            bin2[k] = 0.0;
-                        }
+                    // halving reduction, in place on the bin registers: the first NH (power of two) values are reduced
+                    // in log2(NH) exchange steps that each keep half of them, then plain xor steps; the value(s) beyond NH
+                    // take the plain 6-step butterfly.  Afterwards lane l holds in bin[0] the total of value `idx`
+                    // (bits of l above log2(64/NH)), and every lane holds the totals of the values >= NH.
+                    constexpr int NH = (NOUT >= 8) ? 8 : (NOUT >= 2 ? 2 : 1);
+                    int idx = 0;
+#define GPR_HALVE(ARR, OFF, HALF)                                                                 \
+                    {   const bool up_ = (lane & (OFF)) != 0;                                      \
+                        _Pragma("unroll") for (int k_ = 0; k_ < (HALF); k_++) {                    \
+                            const double send_ = up_ ? ARR[k_] : ARR[k_ + (HALF)];                 \
+                            const double keep_ = up_ ? ARR[k_ + (HALF)] : ARR[k_];                 \
+                            ARR[k_] = keep_ + __shfl_xor(send_, (OFF), 64); } }
+#define GPR_PLAIN(X, FROM)                                                                        \
+                    { _Pragma("unroll") for (int o_ = (FROM); o_ > 0; o_ >>= 1) X += __shfl_xor(X, o_, 64); }
+                    if (NH == 8) {
+                        idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
+                        GPR_HALVE(bin, 32, 4) GPR_HALVE(bin, 16, 2) GPR_HALVE(bin, 8, 1) GPR_PLAIN(bin[0], 4)
+                        if (GRAD) { GPR_HALVE(bin2, 32, 4) GPR_HALVE(bin2, 16, 2) GPR_HALVE(bin2, 8, 1) GPR_PLAIN(bin2[0], 4) }
+                    } else if (NH == 2) {
+                        idx = (lane >> 5) & 1;
+                        GPR_HALVE(bin, 32, 1) GPR_PLAIN(bin[0], 16)
+                        if (GRAD) { GPR_HALVE(bin2, 32, 1) GPR_PLAIN(bin2[0], 16) }
+                    } else {
+                        GPR_PLAIN(bin[0], 32)
+                        if (GRAD) { GPR_PLAIN(bin2[0], 32) }
                     }
-                    if (lane < NOUT) {
-                        const int a = (MODE == GPR_MODE_FF) ? lane / 3 : 0;
-                        const int b = (MODE == GPR_MODE_FF) ? lane % 3 : lane;
+#pragma unroll
+                    for (int k = NH; k < NOUT; k++) { GPR_PLAIN(bin[k], 32) if (GRAD) { GPR_PLAIN(bin2[k], 32) } }
+#undef GPR_HALVE
+#undef GPR_PLAIN
+                    constexpr int SHARE = 64 / NH;
+                    // writer lanes: (l % SHARE == 0) owns value idx < NH; lane 1 owns the extra value NH (if any)
+                    const bool w_main = (lane & (SHARE - 1)) == 0;
+                    const bool w_extra = (NOUT > NH) && lane == 1;
+                    if (w_extra) idx = NH;
+                    double v[1] = {w_extra ? bin[NOUT - 1] : bin[0]};
+                    double v2[1] = {GRAD ? (w_extra ? bin2[NOUT - 1] : bin2[0]) : 0.0};
+#pragma unroll
+                    for (int k = 0; k < NOUT; k++) { bin[k] = 0.0; if (GRAD) bin2[k] = 0.0; }
+                    // one lane per value adds it to the output.  The hardware FP64 atomic add returns nothing, so the
+                    // wavefront does not wait for memory; exactly one wavefront ever adds to a given element and its
+                    // adds are issued in program order, so the result does not depend on scheduling.
+                    if ((w_main || w_extra) && idx < NOUT) {
+                        const int a = (MODE == GPR_MODE_FF) ? idx / 3 : 0;
+                        const int b = (MODE == GPR_MODE_FF) ? idx % 3 : idx;
+                        const double val = v[0] * fac * P.scale;
                         if (P.diag_only) {
-                            if (a == b) P.out[(long long)j_orig * P.s_j + b * P.s_b] += mineV * fac * P.scale;
+                            if (a == b) unsafeAtomicAdd(P.out + (long long)j_orig * P.s_j + b * P.s_b, val);
                         } else {
-                            double *o = P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b;
-                            *o += mineV * fac * P.scale;
-                            if (P.symmetric && ch.pt != jp) {
-                                double *o2 = P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b;
-                                *o2 += mineV * fac * P.scale;
-                            }
+                            unsafeAtomicAdd(P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b, val);
+                            if (P.symmetric && ch.pt != jp)
+                                unsafeAtomicAdd(P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b, val);
                             if (GRAD) {
-                                double *q = P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b;
-                                *q += mineD * fac * P.dl_scale;
-                                if (P.symmetric && ch.pt != jp) {
-                                    double *q2 = P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b;
-                                    *q2 += mineD * fac * P.dl_scale;
-                                }
+                                const double vald = v2[0] * fac * P.dl_scale;
+                                unsafeAtomicAdd(P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b, vald);
+                                if (P.symmetric && ch.pt != jp)
+                                    unsafeAtomicAdd(P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b, vald);
                             }
                         }
                     }
                 }
             }
-            if (c + 1 < c1) stage_store(c + 1, buf ^ 1);
+            if (c + 1 < c1) GPR_STAGE_STORE(c + 1, buf ^ 1)
             __syncthreads();
         }
     }

@@ -135,6 +135,23 @@ int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
  * RBF_mb.py:257-269, 471-481. */
 int gpr_set_shard(int nshards, int shard);
 
+/* ------------------------------------------------------------------ neighbour bookkeeping (host) */
+/* Periodic neighbour search of a batch of structures with the semantics of the reference's
+ * ase NeighborList(cutoffs = rcut/2, bothways, no self interaction, skin 0) use (SO3.py:348-407) and the
+ * (centre, neighbour) row table `seq` (SO3.py:386-399).  Host arrays in, host arrays out (plain index
+ * work; the arithmetic on the pairs happens in gpr_so3_power_spectrum).
+ *   atom0[nstruct+1] atom offsets; positions[natoms,3]; cells[nstruct,9] row vectors; pbc[nstruct,3];
+ *   numbers[natoms]; weight_on: neighbours of another species get weight -Z (SO3.py:381-385).         */
+typedef struct gpr_nbr gpr_nbr;
+int gpr_nbr_build(gpr_nbr **out, int nstruct, const int *atom0, const double *positions,
+                  const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on);
+int gpr_nbr_sizes(const gpr_nbr *nb, int *npairs, int *nrows);
+/* vec[P,3], w[P], centre_pair0[natoms+1], centre_row0[natoms+1], row_pair0[S+1], self_row[natoms],
+ * seq[S,2] (structure-local atom ids), struct_row0[nstruct+1]; any pointer may be NULL */
+int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *centre_pair0, int *centre_row0,
+                   int *row_pair0, int *self_row, int *seq, int *struct_row0);
+int gpr_nbr_destroy(gpr_nbr *nb);
+
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
 /* x[ncentres, d] and dxdr[nrows, d, 3] (d = nmax(nmax+1)/2 (lmax+1)) from neighbour pairs grouped by
  * centre atom and, inside a centre, by `seq` row (gpr_calc/SO3.py:186-323, 608-727).

@@ -39,3 +39,30 @@ def test_compat_offsets_reproduce_vectors():
 
 def test_periodic_table_lookup():
     assert atomic_number("Pd") == 46 and atomic_number("Au") == 79 and symbol_of(13) == "Al"
+
+
+def test_native_batch_index_matches_numpy_index():
+    """the C++ host routine behind SO3.calculate_batch_dev (csrc/nbr.hip) against the numpy bookkeeping"""
+    from gpr_calculator_amd.SO3 import SO3
+    rng = np.random.default_rng(5)
+    cell = np.array([[4.1, 0.0, 0.0], [1.2, 3.8, 0.0], [0.3, 0.9, 4.4]])
+    strucs = [SimpleAtoms(rng.choice([8, 12, 46], 6), rng.uniform(-0.2, 1.2, (6, 3)) @ cell, cell, pbc)
+              for pbc in [(True, True, True), (True, False, True), (False, False, False)]]
+    strucs.append(SimpleAtoms([46], [[0.1, 0.2, 0.3]], np.eye(3) * 3.0, True))     # one atom, only self images
+    for weight_on in (False, True):
+        des = SO3(nmax=3, lmax=4, rcut=5.0, weight_on=weight_on)
+        nb = des.neighbor_index_batch(strucs)
+        p0 = 0
+        for k, s in enumerate(strucs):
+            ref = des.neighbor_index(s)
+            r0, r1 = nb["row0"][k], nb["row0"][k + 1]
+            a0, a1 = nb["atom0"][k], nb["atom0"][k + 1]
+            assert np.array_equal(nb["seq"][r0:r1], ref["seq"])
+            P = len(ref["w"])
+            assert np.abs(nb["vec"][p0:p0 + P] - ref["vec"]).max() < 1e-12 if P else True
+            assert np.array_equal(nb["w"][p0:p0 + P], ref["w"])
+            assert np.array_equal(nb["centre_pair0"][a0:a1 + 1] - p0, ref["centre_pair0"])
+            assert np.array_equal(nb["centre_row0"][a0:a1 + 1] - r0, ref["centre_row0"])
+            assert np.array_equal(nb["row_pair0"][r0:r1 + 1] - p0, ref["row_pair0"])
+            assert np.array_equal(nb["self_row"][a0:a1] - r0, ref["self_row"])
+            p0 += P
