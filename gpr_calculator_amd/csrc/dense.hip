@@ -87,6 +87,104 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
             }
 }
 
+// Large-tile variant: 128x128 C tile per 256-thread workgroup, each wavefront a 64x64 quadrant =
+// 4x4 MFMA tiles (16 accumulators), k-tiles of 16 double-buffered in LDS with the next tile's global
+// loads in flight during the MFMAs.  LDS images keep the operand's storage order (so the stores are
+// conflict free) and are padded so that the 64 lanes of an MFMA operand read hit 64 distinct banks:
+//   stored [row][k]  (A not transposed, B transposed):  row stride 17 doubles
+//   stored [k][col]  (A transposed, B not transposed):  row stride 144 doubles
+constexpr int GM = 128, GN = 128, GK = 16, GLDK = GM + 16, GLDR = GK + 1;
+constexpr int GBUF = (GK * GLDK > GM * GLDR) ? GK * GLDK : GM * GLDR;
+
+template <bool TA, bool TB>
+__global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, double alpha,
+                                                       const double *__restrict__ A, long long lda,
+                                                       const double *__restrict__ B, long long ldb,
+                                                       double beta, double *__restrict__ C, long long ldc,
+                                                       int lower_only) {
+    __shared__ double As[2][GBUF];
+    __shared__ double Bs[2][GBUF];
+    const int bm0 = blockIdx.y * GM, bn0 = blockIdx.x * GN;
+    if ((lower_only & 1) && bn0 > bm0 + GM - 1) return;
+    if (lower_only & 2) k = min(k, bm0 + GM);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    d4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+    double ra[8], rb[8];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            int mm, kk;
+            if (!TA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
+            else     { mm = tid & 127; kk = (tid >> 7) + 2 * i; }
+            const int gm = bm0 + mm, gk = k0 + kk;
+            ra[i] = (gm < m && gk < k) ? (TA ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk]) : 0.0;
+            int nn, kb;
+            if (!TB) { nn = tid & 127; kb = (tid >> 7) + 2 * i; }
+            else     { kb = tid & 15; nn = (tid >> 4) + 16 * i; }
+            const int gn = bn0 + nn, gk2 = k0 + kb;
+            rb[i] = (gn < n && gk2 < k) ? (TB ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn]) : 0.0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            if (!TA) { const int kk = tid & 15, mm = (tid >> 4) + 16 * i; As[buf][mm * GLDR + kk] = ra[i]; }
+            else     { const int mm = tid & 127, kk = (tid >> 7) + 2 * i; As[buf][kk * GLDK + mm] = ra[i]; }
+            if (!TB) { const int nn = tid & 127, kb = (tid >> 7) + 2 * i; Bs[buf][kb * GLDK + nn] = rb[i]; }
+            else     { const int kb = tid & 15, nn = (tid >> 4) + 16 * i; Bs[buf][nn * GLDR + kb] = rb[i]; }
+        }
+    };
+    const int nkt = (k + GK - 1) / GK;
+    if (nkt > 0) { load_tile(0); store_tile(0); }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt++) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) load_tile((kt + 1) * GK);
+#pragma unroll
+        for (int ks = 0; ks < GK / 4; ks++) {
+            const int kr = ks * 4 + (lane >> 4);
+            double a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int mm = wm + i * 16 + (lane & 15);
+                a[i] = TA ? As[buf][kr * GLDK + mm] : As[buf][mm * GLDR + kr];
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int nn = wn + j * 16 + (lane & 15);
+                b[j] = TB ? Bs[buf][nn * GLDR + kr] : Bs[buf][kr * GLDK + nn];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int gm = bm0 + wm + i * 16 + (lane >> 4) + 4 * r;
+                const int gn = bn0 + wn + j * 16 + (lane & 15);
+                if (gm < m && gn < n) {
+                    double *c = C + (long long)gm * ldc + gn;
+                    const double v = alpha * acc[i][j][r];
+                    *c = (beta == 0.0) ? v : v + beta * *c;
+                }
+            }
+}
+
 // unblocked Cholesky of the kb x kb diagonal block at a (lower), one workgroup
 __global__ void __launch_bounds__(256) potrf_diag_kernel(double *a, long long lda, int kb, int k0, int *info) {
     __shared__ double T[NB][NB + 1];
@@ -235,6 +333,16 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(int n, const double *
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
+    if (m >= 256 && n >= 256) {      // enough tiles to fill the chip with the 128x128 kernel
+        dim3 g2((n + GN - 1) / GN, (m + GM - 1) / GM), b2(256);
+        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { gpr_set_error("gemm128 launch failed: %s", hipGetErrorString(e2)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
     dim3 grid((n + BN - 1) / BN, (m + BM - 1) / BM), block(256);
     if (!ta && !tb) hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
     else if (!ta && tb) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
@@ -259,8 +367,8 @@ extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int 
     return launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
 }
 
-// C[n, nrhs] = T B with T an n x n LOWER-triangular matrix (entries above the diagonal are never
-// read): the k loop of each row block stops at its diagonal.  Used with T = L^-1 for the predictive
+// C[n, nrhs] = T B with T an n x n LOWER-triangular matrix (zeros above the diagonal): the k loop of
+// each 128-row block stops at the end of its diagonal block.  Used with T = L^-1 for the predictive
 // variance, V = L^-1 K_trans^T (gaussianprocess.py:903-907 evaluates the same quantity through K^-1).
 extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
                               long long ldb, double *c, long long ldc) {

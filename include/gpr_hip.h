@@ -177,7 +177,8 @@ int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
 int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                    double *b, long long ldb);
-/* C[n,nrhs] = T B with T lower triangular n x n (its strict upper triangle is never read) */
+/* C[n,nrhs] = T B with T lower triangular n x n: the strict upper triangle of T must hold zeros; whole
+ * 128-column blocks to the right of a row block's diagonal block are skipped (never read) */
 int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
                    long long ldb, double *c, long long ldc);
 /* C[m,n] = alpha * op(A) op(B) + beta * C, row-major, op = transpose if the flag is set */

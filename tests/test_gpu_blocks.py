@@ -134,5 +134,24 @@ def test_dense_linear_algebra(gpu):
     tA, tB = torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda")
     assert rel(dev.gemm(tA, tB).cpu().numpy(), A @ B) < 1e-14
     assert rel(dev.gemm(tB, tA, transa=True, transb=True).cpu().numpy(), B.T @ A.T) < 1e-14
+    # the 128x128-tile kernel (m, n >= 256), ragged sizes, all transposes, beta and the triangular product
+    m, n, k = 300, 333, 257
+    for ta in (False, True):
+        for tb in (False, True):
+            A = rng.standard_normal((k, m) if ta else (m, k)); B = rng.standard_normal((n, k) if tb else (k, n))
+            C0 = rng.standard_normal((m, n))
+            ref = 0.5 * (A.T if ta else A) @ (B.T if tb else B) - 2.0 * C0
+            out = dev.gemm(torch.tensor(A, device="cuda"), torch.tensor(B, device="cuda"), transa=ta, transb=tb,
+                           alpha=0.5, beta=-2.0, out=torch.tensor(C0, device="cuda"))
+            assert rel(out.cpu().numpy(), ref) < 1e-13
+    T = np.tril(rng.standard_normal((420, 420))); Bm = rng.standard_normal((420, 301))
+    Td = T.copy()                          # columns beyond a row block's own 128-wide diagonal block are never read
+    for r0 in range(0, 420, 128):
+        Td[r0:r0 + 128, r0 + 128:] = np.nan
+    dirty = torch.tensor(Td, device="cuda")
+    assert rel(dev.trmm_lower(dirty, torch.tensor(Bm, device="cuda")).cpu().numpy(), T @ Bm) < 1e-13
+    a = rng.standard_normal((700, 700)); spd = a @ a.T + 700 * np.eye(700)
+    t = torch.tensor(spd, device="cuda")
+    assert int(dev.potrf_lower_(t).item()) == 0 and rel(t.cpu().numpy(), cholesky(spd, lower=True)) < 1e-12
     bad = torch.tensor(np.array([[1.0, 2.0], [2.0, 1.0]]), device="cuda")
     assert int(dev.potrf_lower_(bad).item()) == 2          # not positive definite: pivot 2
