@@ -43,6 +43,8 @@ _L1_SIGNATURES = {
     "gpr_diag_ee": ([_vp, C.POINTER(KernelParams), _vp, _vp, _vp], _i),
     "gpr_potrf_lower": ([_vp, _i, _vp, _ll, _vp], _i),
     "gpr_trsm_lower": ([_vp, _i, _i, _i, _vp, _ll, _vp, _ll], _i),
+    "gpr_potrf_lower_dinv": ([_vp, _i, _vp, _ll, _vp, _vp], _i),
+    "gpr_trsm_lower_dinv": ([_vp, _i, _i, _i, _vp, _ll, _vp, _vp, _ll], _i),
     "gpr_gemm": ([_vp, _i, _i, _i, _i, _i, _d, _vp, _ll, _vp, _ll, _d, _vp, _ll], _i),
     "gpr_trmm_lower": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll], _i),
     "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),

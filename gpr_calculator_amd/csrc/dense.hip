@@ -259,6 +259,86 @@ __global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double 
     for (int i = 0; i < kb; i++) b[(long long)i * ldb + col] = x[i];
 }
 
+// Cholesky of one kb x kb diagonal block (kb <= 64) in LDS by a single workgroup, followed by the inverse
+// of the factor.  Writes L back (upper part zeroed) and L^-1 as a zero-padded 64 x 64 row-major block to
+// `dinv`: panel solves and triangular solves then become small matrix products (tri_apply_kernel).
+__global__ void __launch_bounds__(256) potrf_diag_inv_kernel(double *a, long long lda, int kb, int k0, int *info,
+                                                              double *dinv) {
+    __shared__ double T[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6;
+    for (int i = ty; i < NB; i += 4) {
+        double v = (i == c) ? 1.0 : 0.0;                       // identity padding beyond kb
+        if (i < kb && c < kb) v = (c <= i) ? a[(long long)i * lda + c] : 0.0;
+        T[i][c] = v;
+    }
+    __syncthreads();
+    for (int j = 0; j < kb; j++) {
+        const double ajj = T[j][j];
+        if (tid == 0 && !(ajj > 0.0) && info) atomicCAS(info, 0, k0 + j + 1);
+        const double piv = sqrt(ajj);
+        __syncthreads();
+        if (ty == 0) { if (c == j) T[j][j] = piv; else if (c > j && c < kb) T[c][j] /= piv; }
+        __syncthreads();
+        for (int i = j + 1 + ty; i < kb; i += 4)               // row i, column c in (j, i]
+            if (c > j && c <= i) T[i][c] -= T[i][j] * T[c][j];
+        __syncthreads();
+    }
+    // inverse: thread c < 64 solves L x = e_c by forward substitution (rows >= c only)
+    if (ty == 0) {
+        for (int i = 0; i < NB; i++) X[i][c] = 0.0;
+        for (int i = c; i < NB; i++) {
+            double v = (i == c) ? 1.0 : 0.0;
+            for (int q = c; q < i; q++) v -= T[i][q] * X[q][c];
+            X[i][c] = v / T[i][i];
+        }
+    }
+    __syncthreads();
+    for (int i = ty; i < NB; i += 4) {
+        if (i < kb && c < kb) a[(long long)i * lda + c] = (c <= i) ? T[i][c] : 0.0;
+        dinv[i * NB + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
+    }
+}
+
+// 64-wide slabs times a 64 x 64 block W (= L_kk^-1, zero padded):
+//   mode 0: P[rows, kb] <- P W^T        (Cholesky panel: X L^T = P), one workgroup per 64 rows
+//   mode 1: B[kb, ncols] <- W B         (forward solve of a diagonal block), one workgroup per 64 columns
+//   mode 2: B[kb, ncols] <- W^T B       (backward solve)
+__global__ void __launch_bounds__(256) tri_apply_kernel(int mode, const double *w, double *t, long long ld, int kb,
+                                                         int extent) {
+    __shared__ double Ws[NB][NB + 1];
+    __shared__ double Ts[NB][NB + 1];
+    const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6, s0 = blockIdx.x * NB;
+    for (int i = ty; i < NB; i += 4) {
+        Ws[i][c] = w[i * NB + c];
+        double v = 0.0;
+        if (mode == 0) { if (s0 + i < extent && c < kb) v = t[(long long)(s0 + i) * ld + c]; }
+        else           { if (i < kb && s0 + c < extent) v = t[(long long)i * ld + s0 + c]; }
+        Ts[i][c] = v;
+    }
+    __syncthreads();
+    double acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) acc[u] = 0.0;
+    for (int q = 0; q < NB; q++) {
+        if (mode == 0) {
+            const double wv = Ws[c][q];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc[u] += Ts[ty + 4 * u][q] * wv;
+        } else {
+            const double tv = Ts[q][c];
+#pragma unroll
+            for (int u = 0; u < 16; u++) acc[u] += (mode == 1 ? Ws[ty + 4 * u][q] : Ws[q][ty + 4 * u]) * tv;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+        const int i = ty + 4 * u;
+        if (mode == 0) { if (s0 + i < extent && c < kb) t[(long long)(s0 + i) * ld + c] = acc[u]; }
+        else           { if (i < kb && s0 + c < extent) t[(long long)i * ld + s0 + c] = acc[u]; }
+    }
+}
+
 __global__ void zero_upper_kernel(int n, double *a, long long lda) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j < n && j > i) a[(long long)i * lda + j] = 0.0;
@@ -378,24 +458,42 @@ extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, lo
     return launch_gemm((hipStream_t)stream, 0, 0, n, nrhs, n, 1.0, t, ldt, b, ldb, 0.0, c, ldc, 2);
 }
 
-// Blocked right-looking lower Cholesky: diagonal block (one workgroup), panel solve, then the
-// trailing update A22 -= P P^T on the matrix cores (lower tiles only).
-extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
+// Blocked right-looking lower Cholesky with two block levels: inside a 256-wide outer panel the 64-wide
+// steps (diagonal factor + inverse, panel product with the inverse, update of the rest of the panel)
+// touch only the panel's columns; the trailing matrix is then updated once per outer panel with a
+// k = 256 product on the matrix cores (lower tiles only).  `dinv` (device, ceil(n/64) * 4096 doubles)
+// receives the inverse of every 64 x 64 diagonal block of L for gpr_trsm_lower_dinv.
+extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
     hipStream_t st = (hipStream_t)stream;
-    GPR_REQUIRE(n >= 0 && (n == 0 || a) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
+    GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
     if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-    for (int k0 = 0; k0 < n; k0 += NB) {
-        const int kb = (n - k0 < NB) ? n - k0 : NB;
-        double *akk = a + (long long)k0 * lda + k0;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, st, akk, lda, kb, k0, info_dev);
-        LAUNCH_CHECK("potrf_diag");
-        const int rows = n - k0 - kb;
-        if (rows > 0) {
-            double *p = a + (long long)(k0 + kb) * lda + k0;
-            hipLaunchKernelGGL(potrf_panel_kernel, dim3((rows + 255) / 256), dim3(256), 0, st, akk, p, lda, kb, rows);
-            LAUNCH_CHECK("potrf_panel");
-            double *a22 = a + (long long)(k0 + kb) * lda + (k0 + kb);
-            int rc = launch_gemm(st, 0, 1, rows, rows, kb, -1.0, p, lda, p, lda, 1.0, a22, lda, 1);
+    constexpr int OB = 256;
+    for (int K0 = 0; K0 < n; K0 += OB) {
+        const int KB = (n - K0 < OB) ? n - K0 : OB;
+        for (int k0 = K0; k0 < K0 + KB; k0 += NB) {
+            const int kb = (K0 + KB - k0 < NB) ? K0 + KB - k0 : NB;
+            double *akk = a + (long long)k0 * lda + k0;
+            double *wk = dinv + (size_t)(k0 / NB) * NB * NB;
+            hipLaunchKernelGGL(potrf_diag_inv_kernel, dim3(1), dim3(256), 0, st, akk, lda, kb, k0, info_dev, wk);
+            LAUNCH_CHECK("potrf_diag_inv");
+            const int rows = n - k0 - kb;
+            if (rows > 0) {
+                double *p = a + (long long)(k0 + kb) * lda + k0;
+                hipLaunchKernelGGL(tri_apply_kernel, dim3((rows + NB - 1) / NB), dim3(256), 0, st, 0, wk, p, lda, kb, rows);
+                LAUNCH_CHECK("tri_apply(panel)");
+                const int w = K0 + KB - (k0 + kb);              // columns of the outer panel still to update
+                if (w > 0) {
+                    int rc = launch_gemm(st, 0, 1, rows, w, kb, -1.0, p, lda, p, lda, 1.0,
+                                         a + (long long)(k0 + kb) * lda + (k0 + kb), lda, 0);
+                    if (rc) return rc;
+                }
+            }
+        }
+        const int R = n - K0 - KB;
+        if (R > 0) {
+            const double *p2 = a + (long long)(K0 + KB) * lda + K0;
+            int rc = launch_gemm(st, 0, 1, R, R, KB, -1.0, p2, lda, p2, lda, 1.0,
+                                 a + (long long)(K0 + KB) * lda + (K0 + KB), lda, 1);
             if (rc) return rc;
         }
     }
@@ -406,8 +504,22 @@ extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, in
     return GPR_OK;
 }
 
-extern "C" int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
-                              double *b, long long ldb) {
+extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return GPR_OK;
+    void *tmp;
+    int rc = gpr_dev_alloc(&tmp, (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(double), st);
+    if (rc) return rc;
+    rc = gpr_potrf_lower_dinv(stream, n, a, lda, info_dev, (double *)tmp);
+    int rc2 = gpr_dev_free(tmp, st);
+    return rc ? rc : rc2;
+}
+
+// Blocked triangular solve L X = B (trans 0) / L^T X = B (trans 1), in place.  With `dinv` (from
+// gpr_potrf_lower_dinv) the diagonal-block solves are 64 x 64 products; without it they fall back to
+// per-column substitution.
+extern "C" int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
+                                   const double *dinv, double *b, long long ldb) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(n >= 0 && nrhs >= 0, "gpr_trsm_lower: negative dimension");
     if (n == 0 || nrhs == 0) return GPR_OK;
@@ -418,8 +530,14 @@ extern "C" int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const do
         const int k0 = blk * NB, kb = (n - k0 < NB) ? n - k0 : NB;
         const double *lkk = l + (long long)k0 * ldl + k0;
         double *bk = b + (long long)k0 * ldb;
-        hipLaunchKernelGGL(trsm_diag_kernel, dim3((nrhs + 255) / 256), dim3(256), 0, st, trans, lkk, ldl, kb, bk, ldb, nrhs);
-        LAUNCH_CHECK("trsm_diag");
+        if (dinv) {
+            hipLaunchKernelGGL(tri_apply_kernel, dim3((nrhs + NB - 1) / NB), dim3(256), 0, st, trans ? 2 : 1,
+                               dinv + (size_t)blk * NB * NB, bk, ldb, kb, nrhs);
+            LAUNCH_CHECK("tri_apply(solve)");
+        } else {
+            hipLaunchKernelGGL(trsm_diag_kernel, dim3((nrhs + 255) / 256), dim3(256), 0, st, trans, lkk, ldl, kb, bk, ldb, nrhs);
+            LAUNCH_CHECK("trsm_diag");
+        }
         int rc = GPR_OK;
         if (!trans) {
             const int rows = n - k0 - kb;     // B[k0+kb:, :] -= L[k0+kb:, k0:k0+kb] X_k
@@ -433,6 +551,11 @@ extern "C" int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const do
         if (rc) return rc;
     }
     return GPR_OK;
+}
+
+extern "C" int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
+                              double *b, long long ldb) {
+    return gpr_trsm_lower_dinv(stream, trans, n, nrhs, l, ldl, nullptr, b, ldb);
 }
 
 extern "C" int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, double add_first,

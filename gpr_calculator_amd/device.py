@@ -163,20 +163,22 @@ def diag_ee(kp, pair, out=None):
 
 
 # ------------------------------------------------------------------ dense linear algebra
-def potrf_lower_(a):
-    """in-place lower Cholesky of a square row-major device matrix; returns info (0 = ok)"""
+def potrf_lower_(a, want_dinv=False):
+    """in-place lower Cholesky of a square row-major device matrix; returns info (0 = ok), and with
+    want_dinv also the inverses of the 64 x 64 diagonal blocks of L (for trsm_lower_)"""
     n = a.shape[0]
     info = torch.zeros(1, dtype=torch.int32, device=a.device)
-    check(_lib.lib().gpr_potrf_lower(stream_ptr(), n, ptr(a), int(a.stride(0)) if n > 1 else n, ptr(info)),
-          "gpr_potrf_lower")
-    return info
+    dinv = torch.empty(((n + 63) // 64) * 4096, dtype=F64, device=a.device)
+    check(_lib.lib().gpr_potrf_lower_dinv(stream_ptr(), n, ptr(a), int(a.stride(0)) if n > 1 else n, ptr(info),
+                                          ptr(dinv)), "gpr_potrf_lower_dinv")
+    return (info, dinv) if want_dinv else info
 
 
-def trsm_lower_(l, b, trans=False):
+def trsm_lower_(l, b, trans=False, dinv=None):
     """b <- L^-1 b (trans False) or L^-T b (trans True); b is [n, nrhs] row-major, in place"""
     n, nrhs = b.shape
-    check(_lib.lib().gpr_trsm_lower(stream_ptr(), int(trans), n, nrhs, ptr(l), int(l.stride(0)) if n > 1 else n,
-                                    ptr(b), int(b.stride(0)) if n > 1 else nrhs), "gpr_trsm_lower")
+    check(_lib.lib().gpr_trsm_lower_dinv(stream_ptr(), int(trans), n, nrhs, ptr(l), int(l.stride(0)) if n > 1 else n,
+                                         ptr(dinv), ptr(b), int(b.stride(0)) if n > 1 else nrhs), "gpr_trsm_lower_dinv")
     return b
 
 

@@ -188,20 +188,20 @@ class GP():
         N = K.shape[0]
         NE = self._n_energy_points(self.train_x)
         dev.add_diag_(K, NE, noise_e ** 2, noise_f ** 2)
-        info = dev.potrf_lower_(K)                       # K now holds L
+        info, dinv = dev.potrf_lower_(K, want_dinv=True)      # K now holds L
         if int(info.item()) != 0:
             return (-np.inf, np.zeros_like(params)) if eval_gradient else -np.inf
         L = K
         y = dev.to_dev(self.y_train)
         alpha = y.clone()
-        dev.trsm_lower_(L, alpha)
-        dev.trsm_lower_(L, alpha, trans=True)
+        dev.trsm_lower_(L, alpha, dinv=dinv)
+        dev.trsm_lower_(L, alpha, trans=True, dinv=dinv)
         MLL = -0.5 * dev.frob_dot(y, alpha).item() - dev.sum_log_diag(L).item() - N / 2 * np.log(2 * np.pi)
         if not eval_gradient:
             return MLL
         # gradient: 0.5 * tr((alpha alpha^T - K^-1) dK/dtheta)   (GPML eq. 5.9; gaussianprocess.py:188-200)
         Linv = torch.eye(N, dtype=dev.F64, device=L.device)
-        dev.trsm_lower_(L, Linv)
+        dev.trsm_lower_(L, Linv, dinv=dinv)
         Kinv = dev.gemm(Linv, Linv, transa=True)
         grads = []
         for dK in (dK0, dK1):
@@ -265,13 +265,13 @@ class GP():
         K = self._train_K()
         NE = self._n_energy_points(self.train_x)
         dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
-        info = dev.potrf_lower_(K)
+        info, self._dinv_dev = dev.potrf_lower_(K, want_dinv=True)
         if int(info.item()) != 0:
             raise np.linalg.LinAlgError(f"{int(info.item())}-th leading minor of K + noise is not positive definite")
         self._L_dev = K
         alpha = dev.to_dev(self.y_train).clone()
-        dev.trsm_lower_(self._L_dev, alpha)
-        dev.trsm_lower_(self._L_dev, alpha, trans=True)
+        dev.trsm_lower_(self._L_dev, alpha, dinv=self._dinv_dev)
+        dev.trsm_lower_(self._L_dev, alpha, trans=True, dinv=self._dinv_dev)
         self._alpha_dev = alpha
         self._K_inv_dev = None
         self._Linv_dev = None
@@ -306,7 +306,7 @@ class GP():
         if self._Linv_dev is None:
             n = self._L_dev.shape[0]
             Linv = torch.eye(n, dtype=dev.F64, device=self._L_dev.device)
-            dev.trsm_lower_(self._L_dev, Linv)
+            dev.trsm_lower_(self._L_dev, Linv, dinv=getattr(self, "_dinv_dev", None))
             self._Linv_dev = Linv
         return self._Linv_dev
 

@@ -174,9 +174,15 @@ int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double
  * semantics, gaussianprocess.py:297).  info_dev (device int, may be NULL) receives 0 or the
  * 1-based index of the first non-positive pivot. */
 int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev);
+/* same, and additionally stores the inverse of every 64 x 64 diagonal block of L (zero padded, row-major,
+ * block b at dinv + b*4096) into the device buffer dinv[ceil(n/64)*4096] */
+int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv);
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
 int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                    double *b, long long ldb);
+/* same with the diagonal-block inverses of gpr_potrf_lower_dinv: every block solve is a small product */
+int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
+                        const double *dinv, double *b, long long ldb);
 /* C[n,nrhs] = T B with T lower triangular n x n: the strict upper triangle of T must hold zeros; whole
  * 128-column blocks to the right of a row block's diagonal block are skipped (never read) */
 int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,

@@ -125,9 +125,14 @@ def test_dense_linear_algebra(gpu):
         L = cholesky(spd, lower=True)
         assert int(info.item()) == 0 and rel(t.cpu().numpy(), L) < 1e-13
         b = rng.standard_normal((n, 45))
+        t2 = torch.tensor(spd, device="cuda")
+        info2, dinv = dev.potrf_lower_(t2, want_dinv=True)
         for trans in (False, True):
+            ref = solve_triangular(L, b, lower=True, trans=1 if trans else 0)
             x = dev.trsm_lower_(t, torch.tensor(b, device="cuda"), trans=trans).cpu().numpy()
-            assert rel(x, solve_triangular(L, b, lower=True, trans=1 if trans else 0)) < 1e-11
+            assert rel(x, ref) < 1e-11
+            x = dev.trsm_lower_(t2, torch.tensor(b, device="cuda"), trans=trans, dinv=dinv).cpu().numpy()
+            assert rel(x, ref) < 1e-11
         assert rel(dev.colsumsq(torch.tensor(b, device="cuda")).cpu().numpy(), (b * b).sum(0)) < 1e-14
         assert abs(dev.sum_log_diag(t).item() - np.log(np.diag(L)).sum()) < 1e-12 * max(1, n)
     A, B = rng.standard_normal((70, 33)), rng.standard_normal((33, 51))
