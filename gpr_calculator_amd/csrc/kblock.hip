@@ -206,9 +206,9 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                             const double bw = beta * acc[3][p];
                             const double bw2 = GRAD ? beta2 * acc[3][p] : 0.0;
 #pragma unroll
-                            for (int q = 0; q < 3; q++) {
-                                bin[p * 3 + q] += alpha * acc[q][p] + bw * acc[q][3];
-                                if (GRAD) bin2[p * 3 + q] += alpha2 * acc[q][p] + bw2 * acc[q][3];
+                            for (int q = 0; q < 3; q++) {      // two fused multiply-adds per output
+                                bin[p * 3 + q] = fma(bw, acc[q][3], fma(alpha, acc[q][p], bin[p * 3 + q]));
+                                if (GRAD) bin2[p * 3 + q] = fma(bw2, acc[q][3], fma(alpha2, acc[q][p], bin2[p * 3 + q]));
                             }
                         }
                     } else {

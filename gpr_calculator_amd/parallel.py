@@ -85,9 +85,12 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            # GPR_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
+            # one-GPU box: RCCL refuses two ranks on the same device)
+            backend = os.environ.get("GPR_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            ndev = max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % ndev)
         dist.init_process_group(backend=backend)
     return Comm()
 
