@@ -1,0 +1,108 @@
+"""GPU, BASELINE.json sizes (cfg3: N_train = 2000 force environments + 63 energies, N = 6063): size-independent
+properties of the hot path, plus oracle parity on randomly drawn sub-blocks of the full matrices."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model():
+    import bench
+    from gpr_calculator_amd.parallel import Comm
+    gp = bench.build_model("RBF", 2000, Comm())
+    gp.fit(show=False, opt=False)
+    return gp
+
+
+def test_factor_reconstructs_K_and_K_is_symmetric(model):
+    import torch
+    from gpr_calculator_amd import device as dev
+    gp = model
+    K = gp.kernel.k_total_dev(gp.train_x)
+    N = K.shape[0]
+    assert N == 6063
+    scale = K.abs().max().item()
+    assert (K - K.T).abs().max().item() / scale < 1e-13
+    assert (torch.diagonal(K) > 0).all()
+    NE = len(gp.train_x["energy"][-1])
+    dev.add_diag_(K, NE, gp.noise_e ** 2, gp.noise_f ** 2)
+    L = gp._L_dev
+    assert torch.equal(torch.triu(L, 1), torch.zeros_like(L))
+    rec = dev.gemm(L, L, transb=True)
+    assert (rec - K).abs().max().item() / scale < 1e-13
+    # alpha solves (K + noise) alpha = y
+    res = dev.gemm(K, gp._alpha_dev) - dev.to_dev(gp.y_train)
+    assert res.abs().max().item() < 1e-8 * max(1.0, np.abs(gp.y_train).max())
+    # L^-1 L = I
+    LiL = dev.trmm_lower(gp._Linv(), L)
+    assert (LiL - torch.eye(N, dtype=torch.float64, device=L.device)).abs().max().item() < 1e-9
+
+
+def test_random_subblocks_match_oracle(model, port_natives):
+    from oracle import gp_numpy as og
+    gp = model
+    rng = np.random.default_rng(0)
+    okern = og.OracleRBF(para=tuple(gp.kernel.parameters()), zeta=gp.kernel.zeta, natives=port_natives)
+    K = gp.kernel.k_total(gp.train_x)
+    X, dX, ELE, cnt = gp.train_x["force"]
+    eX, eELE, ecnt = gp.train_x["energy"]
+    off = np.concatenate(([0], np.cumsum(cnt)))
+    eoff = np.concatenate(([0], np.cumsum(ecnt)))
+    NE = len(ecnt)
+    fi, fj = rng.choice(len(cnt), 5, replace=False), rng.choice(len(cnt), 6, replace=False)
+    ei = rng.choice(NE, 3, replace=False)
+    pick_f = lambda ids: (np.concatenate([X[off[i]:off[i + 1]] for i in ids]), np.concatenate([dX[off[i]:off[i + 1]] for i in ids]),
+                          np.concatenate([ELE[off[i]:off[i + 1]] for i in ids]), [cnt[i] for i in ids])
+    pick_e = lambda ids: (np.concatenate([eX[eoff[i]:eoff[i + 1]] for i in ids]),
+                          np.concatenate([eELE[eoff[i]:eoff[i + 1]] for i in ids]), [ecnt[i] for i in ids])
+    sub = okern.k_total({"energy": pick_e(ei), "force": pick_f(fi)}, {"energy": pick_e(ei), "force": pick_f(fj)})
+    rows = np.concatenate((ei, np.concatenate([NE + 3 * i + np.arange(3) for i in fi])))
+    cols = np.concatenate((ei, np.concatenate([NE + 3 * j + np.arange(3) for j in fj])))
+    got = K[np.ix_(rows, cols)]
+    assert np.abs(got - sub).max() / np.abs(sub).max() < 1e-12
+
+
+def test_prediction_properties(model):
+    from gpr_calculator_amd.synthetic import fcc_cell, neb_images, lj_energy_forces
+    gp = model
+    # training structures are reproduced to within the noise scale
+    s0 = fcc_cell(seed=0)
+    E0, F0 = lj_energy_forces(s0)
+    E, F, _, E_std, F_std = gp.predict_structure(s0, stress=False, return_std=True)
+    assert abs(E - E0) / len(s0) < 5 * gp.noise_e
+    assert np.abs(F - F0).mean() < 0.5 * np.abs(F0).mean()          # fixed, un-optimised hyper-parameters
+    # variances: non-negative, below the prior, small on training data and larger on unseen data
+    prior = gp.kernel.diag(gp._structure_data(s0, gp.descriptor.calculate(s0))[0])
+    assert E_std >= 0 and (F_std >= 0).all() and E_std ** 2 <= prior[0] and (F_std.reshape(-1) ** 2 <= prior[1:] + 1e-12).all()
+    batch = neb_images(6, seed=300)
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True)
+    far = fcc_cell(seed=900, sigma=0.45)                              # far from anything in the training set
+    assert gp.predict_structure(far, stress=False, return_std=True)[4].mean() > 2 * F_std.mean()
+    # batched path == one-by-one path
+    for k in (0, 5):
+        e1, f1, _, es1, fs1 = gp.predict_structure(batch[k], stress=False, return_std=True)
+        assert abs(Es[k] - e1) < 1e-8 and np.abs(Fs[k] - f1).max() < 1e-8 and np.abs(Fs_std[k] - fs1).max() < 1e-7
+    # linearity of the mean in the labels: doubling y doubles alpha and the prediction
+    import torch
+    from gpr_calculator_amd import device as dev
+    a0 = gp._alpha_dev.clone()
+    y2 = dev.to_dev(2.0 * gp.y_train).clone()
+    dev.trsm_lower_(gp._L_dev, y2, dinv=gp._dinv_dev)
+    dev.trsm_lower_(gp._L_dev, y2, trans=True, dinv=gp._dinv_dev)
+    assert (y2 - 2 * a0).abs().max().item() <= 1e-12 * a0.abs().max().item()
+
+
+def test_sharded_assembly_is_exact_at_full_size(model):
+    import torch
+    from gpr_calculator_amd import device as dev
+    gp = model
+    full = gp.kernel.k_total_dev(gp.train_x)
+    acc = torch.zeros_like(full)
+    try:
+        for r in range(4):
+            dev.set_shard(4, r)
+            acc += gp.kernel.k_total_dev(gp.train_x)
+    finally:
+        dev.set_shard(1, 0)
+    assert torch.equal(acc, full)
