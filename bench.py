@@ -176,30 +176,47 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
-        # roofline of the dominant kernel: force-force block of K_trans (one launch per step)
-        ff_ms, ff_n = prof["ff"]
+        # roofline of the dominant kernel of the timed region (largest summed HIP-event time)
         desc = gp.descriptor.calculate_batch_dev(batch)
         # every seq row (i, j) is one row of atom j's force point; its species is that of centre i
         ele_rows = np.concatenate([np.asarray(nums)[sq[:, 0]] for nums, sq in zip(desc["numbers"], desc["seq"])])
         tX, _, tE, _ = gp.train_x["force"]
-        pairs = same_species_pairs(ele_rows, tE)
-        avg_ms = ff_ms / max(ff_n, 1)
-        achieved = pairs * FLOP_PER_PAIR_FF / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        N = gp.alpha_.shape[0]
+        m_rows = sum(1 + 3 * len(s) for s in batch)                    # predicted quantities per step
+        n_nbr = int(gp.descriptor.neighbor_index_batch(batch)["w"].shape[0])
+        F = (30 * 31 // 2 + 1) * len(set(np.concatenate(desc["numbers"]).tolist()))
+        per_step = {k: (ms / args.steps, n / args.steps) for k, (ms, n) in prof.items() if n}
+        work = {   # algorithmic FP64 operations of one step per kernel kind (SURVEY.md section 8d where it defines them)
+            "ff": ("kblock_kernel<FF>: force-force block of K_trans", same_species_pairs(ele_rows, tE) * FLOP_PER_PAIR_FF,
+                   "1.10 kflop per same-species row pair"),
+            "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
+                     "N^2 m (triangular-solve form of the variance)"),
+            "gemm": ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
+                     2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N"),
+            "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives", n_nbr * 21.0e3,
+                    "~21 kflop per neighbour pair (80-node radial quadrature x 5 Bessel orders, Y_lm, dP contraction)"),
+            "features": ("dot2_features_kernel: explicit degree-2 feature map", float(len(ele_rows)) * 465 * 12,
+                         "12 flop per row and packed (k,m) index"),
+        }
+        dom = max((k for k in per_step if k in work), key=lambda k: per_step[k][0])
+        name, flops, unit_note = work[dom]
+        avg_ms = per_step[dom][0] / max(per_step[dom][1], 1e-9)
+        achieved = flops / max(per_step[dom][1], 1e-9) / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "kblock_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                    "kernel": "kblock_kernel<FF> (force-force block of K_trans)", "avg_launch_ms": avg_ms,
-                    "launches": ff_n, "row_pairs_per_launch": pairs, "flop_per_pair": FLOP_PER_PAIR_FF}
+                    "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
+                    "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "flop_per_step": flops,
+                    "work_unit": unit_note,
+                    "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(gp, batch)
-        N = gp.alpha_.shape[0]
         line = {"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": value,
                 "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

@@ -54,6 +54,7 @@ _L1_SIGNATURES = {
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),
     "gpr_nbr_export": ([_vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p], _i),
     "gpr_nbr_destroy": ([_vp], _i),
+    "gpr_dot2_features": ([_vp, _vp, _i, c_int_p, _d, _vp, _ll], _i),
     "gpr_set_shard": ([_i, _i], _i),
     "gpr_profile_enable": ([_i], _i),
     "gpr_profile_fetch": ([c_double_p, c_int_p], _i),

@@ -444,7 +444,10 @@ extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int 
                         double *c, long long ldc) {
     GPR_REQUIRE(m >= 0 && n >= 0 && k >= 0, "gpr_gemm: negative dimension");
     GPR_REQUIRE(m == 0 || n == 0 || (c && (k == 0 || (a && b))), "gpr_gemm: null pointer");
-    return launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
+    const int pid = gpr_prof_begin((hipStream_t)stream, GPR_PROF_GEMM);
+    const int rc = launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
+    gpr_prof_end((hipStream_t)stream, pid);
+    return rc;
 }
 
 // C[n, nrhs] = T B with T an n x n LOWER-triangular matrix (zeros above the diagonal): the k loop of
@@ -455,7 +458,10 @@ extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, lo
     GPR_REQUIRE(n >= 0 && nrhs >= 0, "gpr_trmm_lower: negative dimension");
     if (n == 0 || nrhs == 0) return GPR_OK;
     GPR_REQUIRE(t && b && c && ldt >= n && ldb >= nrhs && ldc >= nrhs, "gpr_trmm_lower: bad arguments");
-    return launch_gemm((hipStream_t)stream, 0, 0, n, nrhs, n, 1.0, t, ldt, b, ldb, 0.0, c, ldc, 2);
+    const int pid = gpr_prof_begin((hipStream_t)stream, GPR_PROF_TRMM);
+    const int rc = launch_gemm((hipStream_t)stream, 0, 0, n, nrhs, n, 1.0, t, ldt, b, ldb, 0.0, c, ldc, 2);
+    gpr_prof_end((hipStream_t)stream, pid);
+    return rc;
 }
 
 // Blocked right-looking lower Cholesky with two block levels: inside a 256-wide outer panel the 64-wide

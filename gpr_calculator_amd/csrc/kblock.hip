@@ -383,12 +383,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     a.out = c.out; a.s_i = c.s_i; a.s_j = c.s_j; a.s_a = c.s_a; a.s_b = c.s_b;
     a.dl = c.dl; a.d_i = c.d_i; a.d_j = c.d_j; a.d_a = c.d_a; a.d_b = c.d_b;
 
-    hipEvent_t prof_start = nullptr, prof_stop = nullptr;
-    if (g_prof_on) {
-        GPR_HIP_TRY(hipEventCreate(&prof_start));
-        GPR_HIP_TRY(hipEventCreate(&prof_stop));
-        GPR_HIP_TRY(hipEventRecord(prof_start, st));
-    }
+    const int prof_id = gpr_prof_begin(st, c.diag_only ? GPR_PROF_DIAG : c.mode);
     const bool z2 = (c.zeta == 2.0);
     const int nblocks = c.diag_only ? njb : njb * nir;
     const bool grad = c.grad != 0;
@@ -403,11 +398,21 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("kblock launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
-    if (prof_stop) {
-        GPR_HIP_TRY(hipEventRecord(prof_stop, st));
-        g_prof.push_back(prof_rec{c.diag_only ? 3 : c.mode, prof_start, prof_stop});
-    }
+    gpr_prof_end(st, prof_id);
     return GPR_OK;
+}
+
+// HIP events around one launch (or launch sequence) on its stream; no-ops unless profiling is enabled
+int gpr_prof_begin(hipStream_t st, int kind) {
+    if (!g_prof_on) return -1;
+    prof_rec r{kind, nullptr, nullptr};
+    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return -1;
+    (void)hipEventRecord(r.start, st);
+    g_prof.push_back(r);
+    return (int)g_prof.size() - 1;
+}
+void gpr_prof_end(hipStream_t st, int id) {
+    if (id >= 0 && id < (int)g_prof.size()) (void)hipEventRecord(g_prof[id].stop, st);
 }
 
 extern "C" int gpr_profile_enable(int on) {
@@ -418,9 +423,9 @@ extern "C" int gpr_profile_enable(int on) {
 }
 
 // sums the kernel-only durations (ms) and launch counts recorded since gpr_profile_enable(1), per block
-// kind: index 0 = force-force, 1 = energy-force, 2 = energy-energy, 3 = diagonal-only launches; clears the records
+// kind (gpr_prof_kind, GPR_PROF_NKINDS entries); clears the records
 extern "C" int gpr_profile_fetch(double *ms_by_mode, int *launches_by_mode) {
-    for (int k = 0; k < 4; k++) { ms_by_mode[k] = 0.0; launches_by_mode[k] = 0; }
+    for (int k = 0; k < GPR_PROF_NKINDS; k++) { ms_by_mode[k] = 0.0; launches_by_mode[k] = 0; }
     for (auto &r : g_prof) {
         GPR_HIP_TRY(hipEventSynchronize(r.stop));
         float ms = 0.f;

@@ -255,7 +255,9 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
         a.rpad = s->rpad; a.tile_rows = s->tile_rows;
         a.numpy_eps = (flags & GPR_SET_NUMPY_EPS) ? 1 : 0;
         a.pad_code = (role == GPR_ROLE_STREAM) ? GPR_ELE_PAD_STREAM : GPR_ELE_PAD_RESIDENT;
+        const int pid = gpr_prof_begin(st, GPR_PROF_PACK);
         hipLaunchKernelGGL(pack_rows_kernel, dim3((s->rpad + 255) / 256), dim3(256), 0, st, a);
+        gpr_prof_end(st, pid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
             gpr_set_error("pack_rows_kernel launch failed: %s", hipGetErrorString(e));

@@ -295,7 +295,9 @@ extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double r
     A.nmax = nmax; A.lmax = lmax; A.nq = nq; A.d = d; A.rcut = rcut; A.alpha = alpha;
     A.G = G; A.rq = rq; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr; A.dc = (double2 *)scratch;
+    const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
     hipLaunchKernelGGL(so3_centre_kernel, dim3(ncentres), dim3(256), 0, st, A);
+    gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("so3_centre_kernel launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
     return GPR_OK;

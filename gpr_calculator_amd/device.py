@@ -249,7 +249,21 @@ def profile_enable(on=True):
 
 def profile_fetch():
     """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable()"""
-    ms = (C.c_double * 4)()
-    n = (C.c_int * 4)()
+    names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack")
+    ms = (C.c_double * len(names))()
+    n = (C.c_int * len(names))()
     check(_lib.lib().gpr_profile_fetch(ms, n), "gpr_profile_fetch")
-    return {k: (ms[i], n[i]) for i, k in enumerate(("ff", "ef", "ee", "diag"))}
+    return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+
+
+def dot2_features(pset, species, sigma0, out=None):
+    """Psi rows (Dot kernel, zeta = 2) of a STREAM-packed set: [npts, F] for energies, [3*npts, F] for forces"""
+    species = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
+    ns = len(species)
+    F = ns * (pset.d * (pset.d + 1) // 2 + 1)
+    rows = pset.npts * (3 if pset.width else 1)
+    if out is None:
+        out = torch.empty((rows, F), dtype=F64, device=device())
+    check(_lib.lib().gpr_dot2_features(stream_ptr(), pset.handle, ns, species.ctypes.data_as(_lib.c_int_p),
+                                       float(sigma0), ptr(out), max(int(out.stride(0)), F)), "gpr_dot2_features")
+    return out

@@ -147,26 +147,11 @@ class GP():
         return n_points(e) if len(e) > 0 else 0
 
     def _train_K(self, grad=False):
-        """K(train, train) on the device, assembled in shards over the ranks (each point-pair bin is
-        evaluated by exactly one rank, the others hold exact zeros, so the all-reduce is exact)."""
-        sharded = self.comm.size > 1
-        if sharded:
-            dev.set_shard(self.comm.size, self.comm.rank)
-        try:
-            if grad:
-                out = self.kernel.k_total_with_grad_dev(self.train_x)
-            else:
-                out = (self.kernel.k_total_dev(self.train_x),)
-        finally:
-            if sharded:
-                dev.set_shard(1, 0)
-        if sharded:
-            for t in out[:3]:
-                if isinstance(t, torch.Tensor):
-                    self.comm.all_reduce_sum_(t)
-            if grad and self.kernel.name == 'Dot':
-                out = (out[0], out[1], out[2] / self.comm.size, out[3])   # constant slice is not sharded
-        return out if grad else out[0]
+        """K(train, train) on the device.  Over several ranks the kernel object shards the point-pair tasks
+        and sums the partial matrices with one all-reduce (kernels/_common.py:_assemble)."""
+        if grad:
+            return self.kernel.k_total_with_grad_dev(self.train_x, comm=self.comm)
+        return self.kernel.k_total_dev(self.train_x, comm=self.comm)
 
     def log_marginal_likelihood(self, params, eval_gradient=False, clone_kernel=False):
         """Log marginal likelihood and its gradient (gaussianprocess.py:133-202) evaluated on the

@@ -41,16 +41,71 @@ class Dot_mb(DeviceKernel):
         return dev.kernel_params(_lib.KERNEL_DOT, zeta, self.sigma, 1.0, self.sigma0, 0.0)
 
     # ------------------------------------------------------------------ device-resident entry points
-    def k_total_dev(self, data1, data2=None, tol=1e-12, transpose=False):
+    # ------------------------------------------------------------------ zeta = 2: explicit feature map
+    use_feature_map = True      # set False to force the row-pair (MFMA block) kernels at zeta = 2 as well
+
+    def _species_of(self, *datas):
+        """sorted species over the energy / force entries of the given dictionaries (host ints)"""
+        out = set()
+        for data in datas:
+            for key in ("energy", "force"):
+                if key in data and n_points(data[key]) > 0:
+                    ent = data[key]
+                    ele = ent.stream.ele if isinstance(ent, dev.SetPair) else \
+                        (as_energy_tuple(ent)[1] if key == "energy" else as_force_tuple(ent)[2])
+                    if isinstance(ele, torch.Tensor):
+                        out.update(torch.unique(ele).cpu().tolist())
+                    else:
+                        out.update(np.unique(np.asarray(ele)).tolist())
+        return tuple(sorted(int(z) for z in out))
+
+    def _psi(self, data, species):
+        """Psi = [Psi_E ; Psi_F] of a data dictionary (csrc/features.hip), cached with the packed sets"""
+        parts = []
+        if "energy" in data and n_points(data["energy"]) > 0:
+            pair = self.pack_energy(data["energy"])
+            key = ("psiE", species, self.sigma0)
+            if getattr(pair, "_psi_key", None) != key:
+                pair._psi, pair._psi_key = dev.dot2_features(pair.stream, species, self.sigma0), key
+            parts.append(pair._psi)
+        if "force" in data and n_points(data["force"]) > 0:
+            pair = self.pack_force(data["force"])
+            key = ("psiF", species)
+            if getattr(pair, "_psi_key", None) != key:
+                pair._psi, pair._psi_key = dev.dot2_features(pair.stream, species, 0.0), key
+            parts.append(pair._psi)
+        return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+
+    def _feature_path(self, data1, data2, zeta_ee):
+        if not self.use_feature_map or float(zeta_ee) != 2.0:
+            return None
+        species = self._species_of(data1, data2 if data2 is not None else data1)
+        return species if 1 <= len(species) <= 4 else None
+
+    def k_total_dev(self, data1, data2=None, tol=1e-12, transpose=False, comm=None):
         """Dot_mb.k_total (Dot_mb.py:87-119).  The reference calls kef_C / kff_C with zeta in the
         sigma0 slot, so those blocks silently use zeta = 2.0 while K_ee uses self.zeta
-        (SURVEY.md Appendix A.13); reproduced here."""
-        return self._assemble(data1, data2, self._kp(self.zeta), self._kp(2.0), self._kp(2.0), transpose=transpose)
+        (SURVEY.md Appendix A.13); reproduced here.  With self.zeta == 2 the whole matrix is a degree-2
+        polynomial kernel and is assembled as sigma^2 Psi Psi'^T by one GEMM (csrc/features.hip)."""
+        species = self._feature_path(data1, data2, self.zeta)
+        if species is not None:
+            P1 = self._psi(data1, species)
+            P2 = P1 if data2 is None else self._psi(data2, species)
+            if transpose:
+                return dev.gemm(P2, P1, transb=True, alpha=self.sigma ** 2)
+            return dev.gemm(P1, P2, transb=True, alpha=self.sigma ** 2)
+        return self._assemble(data1, data2, self._kp(self.zeta), self._kp(2.0), self._kp(2.0), transpose=transpose,
+                              comm=comm)
 
-    def k_total_with_grad_dev(self, data1):
+    def k_total_with_grad_dev(self, data1, comm=None):
         """(K, dK/dsigma, dK/dsigma0, nE) (Dot_mb.py:121-148; all blocks use self.zeta here)."""
         kp = self._kp(self.zeta)
-        K = self._assemble(data1, None, kp, kp, kp)
+        species = self._feature_path(data1, None, self.zeta)
+        if species is not None:
+            P = self._psi(data1, species)
+            K = dev.gemm(P, P, transb=True, alpha=self.sigma ** 2)
+        else:
+            K = self._assemble(data1, None, kp, kp, kp, comm=comm)
         nE = n_points(data1["energy"]) if "energy" in data1 else 0
         K2 = torch.zeros_like(K)
         K2[:nE, :nE] = 0.8 * 2 * self.sigma ** 2 * self.sigma0          # dot_kernel.py:58 (sic)

@@ -41,15 +41,15 @@ class RBF_mb(DeviceKernel):
         return dev.kernel_params(_lib.KERNEL_RBF, self.zeta, self.sigma, self.l, 0.0, tol)
 
     # ------------------------------------------------------------------ device-resident entry points
-    def k_total_dev(self, data1, data2=None, f_tol=1e-10, transpose=False):
+    def k_total_dev(self, data1, data2=None, f_tol=1e-10, transpose=False, comm=None):
         kp = self._kp(f_tol)
-        return self._assemble(data1, data2, kp, kp, kp, transpose=transpose)
+        return self._assemble(data1, data2, kp, kp, kp, transpose=transpose, comm=comm)
 
-    def k_total_with_grad_dev(self, data1, f_tol=1e-10):
+    def k_total_with_grad_dev(self, data1, f_tol=1e-10, comm=None):
         """(K, dK/dsigma, dK/dl, nE) on the device (RBF_mb.py:173-204; the gradient natives have
         no tol skip, rbf_kernel.cpp:534-536)."""
         kp = self._kp(f_tol)
-        K, Kl, nE = self._assemble(data1, None, kp, kp, kp, grad=True)
+        K, Kl, nE = self._assemble(data1, None, kp, kp, kp, grad=True, comm=comm)
         return K, K * (2.0 / self.sigma), Kl, nE
 
     def diag_dev(self, data):

@@ -95,11 +95,22 @@ class DeviceKernel:
         return self._cache.get(X, ("F", flags), lambda: dev.SetPair(X, dXdR, ELE, counts, flags=flags))
 
     # ---- block assembly
-    def _assemble(self, data1, data2, kp_ee, kp_ef, kp_ff, grad=False, transpose=False):
+    def _assemble(self, data1, data2, kp_ee, kp_ef, kp_ff, grad=False, transpose=False, comm=None):
         """K (and dK/dl when grad) of data1 x data2 on the device.
 
         transpose=True returns K(data1, data2)^T, computed directly in that layout, with data1
-        still on the streamed side (predict: data1 = structures, data2 = training set)."""
+        still on the streamed side (predict: data1 = structures, data2 = training set).
+        comm (parallel.Comm of size > 1): the point-pair tasks of every block are dealt round-robin to the
+        ranks and the partial matrices summed with one all-reduce (exact: each element has one owner)."""
+        if comm is not None and comm.size > 1:
+            dev.set_shard(comm.size, comm.rank)
+            try:
+                out = self._assemble(data1, data2, kp_ee, kp_ef, kp_ff, grad=grad, transpose=transpose)
+            finally:
+                dev.set_shard(1, 0)
+            for t in (out[:2] if grad else (out,)):
+                comm.all_reduce_sum_(t)
+            return out
         same = data2 is None
         if same:
             data2 = data1

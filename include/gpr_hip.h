@@ -119,11 +119,19 @@ int gpr_diag_ff(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
 int gpr_diag_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
                 const gpr_set *set2, double *out);
 
+/* Explicit feature map of the Dot kernel at zeta = 2 (a degree-2 polynomial kernel): K = sigma^2 Psi Psi'^T with
+ * per-point features Psi, so the covariance assembly is one GEMM (csrc/features.hip for the algebra; reference
+ * natives dot_kee/kef/kff_many, dot_kernel.cpp:5-336).  out[npts, F] (energy set) or out[3*npts, F] (force
+ * set, row 3*j+q), F = ns*(d(d+1)/2 + 1), device, caller's point order; species_host[ns] (ns <= 4) lists the
+ * atomic numbers that receive a feature block. */
+int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const int *species_host, double sigma0,
+                      double *out, long long ld);
+
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
- * gpr_profile_fetch sums the durations (ms) and launch counts per block kind
- * (4 entries: 0 force-force, 1 energy-force, 2 energy-energy, 3 diagonal-only launches) and clears
- * the records. */
+ * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 9 entries
+ * (0 force-force block, 1 energy-force, 2 energy-energy, 3 diagonal-only block launches, 4 triangular product
+ * gpr_trmm_lower, 5 gpr_gemm, 6 SO3 descriptor, 7 Dot feature map, 8 row packing) and clears the records. */
 int gpr_profile_enable(int on);
 int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
 

@@ -78,6 +78,13 @@ def test_dot_kernel_object_matches_oracle(gpu, port_natives, zeta):
     o = OracleDot(para=(2.0, 2.0), zeta=zeta, natives=port_natives)
     assert rel(k.k_total(train), o.k_total(train)) < REL          # includes the zeta=2 quirk of ef/ff
     assert rel(k.k_total(new, train), o.k_total(new, train)) < REL
+    assert rel(k.k_total_dev(new, train, transpose=True).cpu().numpy().T, o.k_total(new, train)) < REL
+    if zeta == 2.0:      # the explicit feature map (GEMM) and the row-pair MFMA blocks give the same matrix
+        k.use_feature_map = False
+        assert rel(k.k_total(train), o.k_total(train)) < REL and rel(k.k_total(new, train), o.k_total(new, train)) < REL
+        k.use_feature_map = True
+        for sub in ({"force": new["force"]}, {"energy": new["energy"]}):
+            assert rel(k.k_total(sub, train), o.k_total(sub, train)) < REL
     Kg, dK = k.k_total_with_grad(train)
     Kgo, dKo = o.k_total_with_grad(train)
     assert rel(Kg, Kgo) < REL and rel(dK[:, :, 0], dKo[:, :, 0]) < REL
