@@ -410,6 +410,17 @@ __global__ void __launch_bounds__(256) sum_partials_kernel(int n, const double *
     if (threadIdx.x == 0) out[0] = red[0];
 }
 
+// out[i] = sum_j a[i*lda+j] * b[i*ldb+j]: one wavefront per row, fixed summation order
+__global__ void __launch_bounds__(256) rowdot_kernel(int m, int n, const double *a, long long lda, const double *b,
+                                                      long long ldb, double *out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    double acc = 0.0;
+    for (int j = lane; j < n; j += 64) acc += a[(long long)row * lda + j] * b[(long long)row * ldb + j];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) out[row] = acc;
+}
+
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
@@ -615,4 +626,13 @@ extern "C" int gpr_frob_dot(void *stream, int m, int n, const double *a, long lo
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, st, nblk, (const double *)part, out);
     LAUNCH_CHECK("sum_partials");
     return gpr_dev_free(part, st);
+}
+
+extern "C" int gpr_rowdot(void *stream, int m, int n, const double *a, long long lda, const double *b, long long ldb,
+                          double *out) {
+    if (m <= 0) return GPR_OK;
+    GPR_REQUIRE(out && (n == 0 || (a && b && lda >= n && ldb >= n)), "gpr_rowdot: bad arguments");
+    hipLaunchKernelGGL(rowdot_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, a, lda, b, ldb, out);
+    LAUNCH_CHECK("rowdot");
+    return GPR_OK;
 }

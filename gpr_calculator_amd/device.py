@@ -267,3 +267,13 @@ def dot2_features(pset, species, sigma0, out=None):
     check(_lib.lib().gpr_dot2_features(stream_ptr(), pset.handle, ns, species.ctypes.data_as(_lib.c_int_p),
                                        float(sigma0), ptr(out), max(int(out.stride(0)), F)), "gpr_dot2_features")
     return out
+
+
+def rowdot(a, b):
+    """out[i] = sum_j a[i, j] * b[i, j] for two equally shaped row-major device matrices"""
+    assert a.shape == b.shape and a.dim() == 2
+    m, n = a.shape
+    out = torch.empty(m, dtype=F64, device=a.device)
+    check(_lib.lib().gpr_rowdot(stream_ptr(), m, n, ptr(a), max(int(a.stride(0)), n), ptr(b), max(int(b.stride(0)), n),
+                                ptr(out)), "gpr_rowdot")
+    return out

@@ -83,6 +83,7 @@ class GP():
         self._alpha_dev = None      # (K + noise)^-1 y                    [N, 1]
         self._K_inv_dev = None
         self._Linv_dev = None
+        self._ws_cache = None
         self._host = {}             # lazily downloaded numpy mirrors
 
         self.fits = 0
@@ -260,6 +261,7 @@ class GP():
         self._alpha_dev = alpha
         self._K_inv_dev = None
         self._Linv_dev = None
+        self._ws_cache = None
         self._host = {}
         self.logging.info("Cholesky Decomp is Complete")
         self.comm.barrier()
@@ -281,9 +283,32 @@ class GP():
         if not return_std:
             return mean, None
         var = self.kernel.diag_dev(X)
-        V = dev.trmm_lower(self._Linv(), Kt)                                      # V = L^-1 K_trans^T
-        var = var - dev.colsumsq(V)
+        ws = self._weight_space()
+        if ws is not None:
+            # Dot kernel at zeta = 2: k = sigma^2 Psi psi, so |L^-1 k|^2 = psi^T M psi with the F x F matrix
+            # M = (L^-1 sigma^2 Psi)^T (L^-1 sigma^2 Psi) built once per fit: no N-sized work per prediction
+            species, M = ws
+            P = self.kernel._psi(X, species)
+            var = var - dev.rowdot(dev.gemm(P, M), P)
+        else:
+            V = dev.trmm_lower(self._Linv(), Kt)                                  # V = L^-1 K_trans^T
+            var = var - dev.colsumsq(V)
         return mean, torch.clamp_min(var, 0.0)
+
+    def _weight_space(self):
+        """(species, M) for kernels with an explicit feature map (Dot_mb at zeta = 2), else None"""
+        if not hasattr(self.kernel, "_feature_path"):
+            return None
+        if self._ws_cache is None:
+            train_x = self.get_train_x()
+            species = self.kernel._feature_path(train_x, None, self.kernel.zeta)
+            if species is None:
+                self._ws_cache = False
+            else:
+                W = self.kernel._psi(train_x, species) * (self.kernel.sigma ** 2)
+                dev.trsm_lower_(self._L_dev, W, dinv=self._dinv_dev)
+                self._ws_cache = (species, dev.gemm(W, W, transa=True))
+        return self._ws_cache or None
 
     def _Linv(self):
         """L^-1 on the device (lower triangular), built once per fit: the variance of every later

@@ -204,6 +204,10 @@ int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, dou
                  double add_rest);
 /* out[j] = sum_i v[i*ldv + j]^2  (j < ncols): column sums of squares of an n x ncols matrix */
 int gpr_colsumsq(void *stream, int n, int ncols, const double *v, long long ldv, double *out);
+/* out[i] = sum_j a[i*lda+j] * b[i*ldb+j], i < m: row-wise inner products (weight-space variance of the Dot
+ * kernel: psi^T M psi for every predicted quantity) */
+int gpr_rowdot(void *stream, int m, int n, const double *a, long long lda, const double *b, long long ldb,
+               double *out);
 /* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
  * gaussianprocess.py:196-198), deterministic reduction order */
 int gpr_frob_dot(void *stream, int m, int n, const double *a, long long lda, const double *b,
