@@ -65,6 +65,12 @@ struct gpr_set {
     int nchunks = 0, maxgroups = 0;
     // host mirrors used for launch planning
     std::vector<int> h_perm, h_cnt, h_pt_chunk0, h_pt_tiles, h_groups;
+    // host sources of the asynchronous uploads: kept alive with the set so that no stream
+    // synchronisation is needed at creation time
+    std::vector<int> hk_src_row, hk_irc, hk_irp;
+    std::vector<double> hk_inv_cnt;
+    std::vector<gpr_chunk> hk_chunks;
+    std::vector<gpr_rpoint> hk_rpts;
     long long bytes = 0;
 };
 

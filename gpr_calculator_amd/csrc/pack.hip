@@ -175,11 +175,13 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
 
     s->h_perm = order;
     s->h_cnt.resize(npts);
-    std::vector<int> src_row;
+    std::vector<int> &src_row = s->hk_src_row;
     src_row.reserve((size_t)nrows + 16 * (size_t)npts);
-    std::vector<double> inv_cnt(npts);
-    std::vector<gpr_chunk> chunks;
-    std::vector<gpr_rpoint> rpts(npts);
+    std::vector<double> &inv_cnt = s->hk_inv_cnt;
+    inv_cnt.assign(npts, 0.0);
+    std::vector<gpr_chunk> &chunks = s->hk_chunks;
+    std::vector<gpr_rpoint> &rpts = s->hk_rpts;
+    rpts.assign(npts, gpr_rpoint{0, 0});
     s->h_pt_chunk0.assign(npts + 1, 0);
     s->h_pt_tiles.assign(npts, 0);
     s->h_groups.assign(npts, 0);
@@ -223,7 +225,8 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
         if ((rc = upload(&s->chunks, chunks, st, &bytes))) return fail(rc);
         if ((rc = upload(&s->pt_chunk0, s->h_pt_chunk0, st, &bytes))) return fail(rc);
         // launch ranges: consecutive packed points, about 128 tiles each (one task = range x point block)
-        std::vector<int> irc{0}, irp{0};
+        std::vector<int> &irc = s->hk_irc, &irp = s->hk_irp;
+        irc.assign(1, 0); irp.assign(1, 0);
         int tiles = 0;
         for (int p = 0; p < npts; p++) {
             tiles += s->h_pt_tiles[p];
@@ -264,12 +267,7 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
             return fail(GPR_ERR_HIP);
         }
     }
-    // src_row (host vector) feeds an async copy: finish it before the vector dies
-    if (hipStreamSynchronize(st) != hipSuccess) {
-        gpr_set_error("gpr_set_create: stream synchronize failed: %s", hipGetErrorString(hipGetLastError()));
-        return fail(GPR_ERR_HIP);
-    }
-    gpr_dev_free(d_src, st);
+    gpr_dev_free(d_src, st);          // stream-ordered: released after the pack kernel has read it
     *out = s;
     return GPR_OK;
 }
@@ -277,6 +275,7 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
 extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
     if (!s) return GPR_OK;
     hipStream_t st = (hipStream_t)stream;
+    (void)hipStreamSynchronize(st);   // the host vectors below may still feed an upload; kernels may still read the set
     gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
     gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
     gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st);
