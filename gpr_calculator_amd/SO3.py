@@ -263,7 +263,8 @@ class SO3:
             dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
         seq = nb["seq"]
         return dict(x=x, dxdr=dxdr, seq=[seq[row0[k]:row0[k + 1]] for k in range(len(strucs))],
-                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))], atom0=atom0, row0=row0)
+                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))], atom0=atom0, row0=row0,
+                    seq_all=seq, numbers_all=numbers)
 
     def calculate(self, atoms, atom_ids=None, use_mpi=False):
         '''

@@ -646,26 +646,31 @@ class GP():
             return {"energy": _concat_energy([dt["energy"] for dt in datas]),
                     "force": _concat_force([dt["force"] for dt in datas])}, frees
         desc = self.descriptor.calculate_batch_dev(strucs)
-        ele_atoms = np.concatenate(desc["numbers"]).astype(np.int32)
-        row_idx, centre_idx, counts_f, frees = [], [], [], []
+        ele_atoms = desc["numbers_all"].astype(np.int32)
+        atom0, row0, seq = desc["atom0"], desc["row0"], desc["seq_all"]
+        natoms = int(atom0[-1])
+        nper = np.diff(atom0)
+        row_off = np.repeat(atom0[:-1], np.diff(row0))            # atom offset of the structure of every seq row
+        gi, gj = seq[:, 0] + row_off, seq[:, 1] + row_off          # global centre / moving-atom ids
+        keep = np.ones(natoms, dtype=bool)
+        frees = []
         for k, s in enumerate(strucs):
-            seq, n = desc["seq"][k], len(s)
-            fix = set(int(i) for i in self._get_fixed_atoms(s))
-            order = np.argsort(seq[:, 1], kind="stable")
-            keep = np.ones(n, dtype=bool)
-            if fix:
-                keep[list(fix)] = False
-            rows = order[keep[seq[order, 1]]]
-            row_idx.append(rows + desc["row0"][k])
-            centre_idx.append(seq[rows, 0] + desc["atom0"][k])
-            counts_f.extend(np.bincount(seq[:, 1], minlength=n)[keep].tolist())
-            frees.append([i for i in range(n) if i not in fix])
-        row_idx = dev.to_dev(np.concatenate(row_idx), torch.int64)
-        centre_host = np.concatenate(centre_idx)
+            fix = self._get_fixed_atoms(s)
+            if len(fix):
+                keep[atom0[k] + np.asarray(fix, dtype=np.int64)] = False
+                fixset = set(int(i) for i in fix)
+                frees.append([i for i in range(int(nper[k])) if i not in fixset])
+            else:
+                frees.append(list(range(int(nper[k]))))
+        order = np.argsort(gj, kind="stable")                      # rows grouped by the atom that moves
+        rows = order[keep[gj[order]]]
+        centre_host = gi[rows]
+        counts_f = np.bincount(gj, minlength=natoms)[keep]
+        row_idx = dev.to_dev(rows, torch.int64)
         centre_idx = dev.to_dev(centre_host, torch.int64)
         xf = desc["x"].index_select(0, centre_idx)
         dxf = desc["dxdr"].index_select(0, row_idx)
-        E = dev.SetPair(desc["x"], None, ele_atoms, [len(s) for s in strucs])
+        E = dev.SetPair(desc["x"], None, ele_atoms, nper)
         F = dev.SetPair(xf, dxf, ele_atoms[centre_host], counts_f)
         return {"energy": E, "force": F}, frees
 
