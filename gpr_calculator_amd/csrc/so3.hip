@@ -41,28 +41,37 @@ __device__ __forceinline__ cplx cscale(cplx a, double s) { return {a.re * s, a.i
 __device__ __forceinline__ cplx cadd(cplx a, cplx b) { return {a.re + b.re, a.im + b.im}; }
 
 // modified spherical Bessel functions of the first kind i_0 .. i_lt(x), x > 0
-// (scipy.special.spherical_in in the reference, SO3.py:563-565).  Power series for small x, closed
-// forms + upward recurrence once x is large enough for the recurrence to be well conditioned.
+// (scipy.special.spherical_in in the reference, SO3.py:563-565).  Miller's downward recurrence for small x,
+// closed forms + upward recurrence once x is large enough for the recurrence to be well conditioned.
 __device__ void sph_in_table(double x, int lt, double *b) {
     const double xs = fmax(6.0, 2.0 * lt);
     if (x < xs) {
-        const double h = 0.5 * x * x;
-        double pw = 1.0;                                    // x^l / (2l+1)!!
-        for (int l = 0; l <= lt; l++) {
-            if (l > 0) pw *= x / (2 * l + 1);
-            double t = pw, s = pw;
-            for (int k = 1; k < 200; k++) {
-                t *= h / (double(k) * (2 * l + 2 * k + 1));
-                s += t;
-                if (t < 1e-18 * s) break;
+        // Miller's downward recurrence t_{l-1} = t_{l+1} + (2l+1)/x t_l from l = lt+16 (all terms positive, so
+        // no cancellation), normalised by i_0 = sinh(x)/x; agrees with scipy to ~3e-14 relative for x < 12
+        const double ix = 1.0 / x;
+        double tp = 0.0, t = 1e-300;
+#pragma unroll
+        for (int l = SO3_LCAP - 1 + 16; l > 0; l--) {        // fully unrolled: every index below is static
+            if (l <= lt + 16) {
+                const double tm = tp + (2 * l + 1) * ix * t;
+                tp = t; t = tm;
+                if (l - 1 <= SO3_LCAP - 1 && l - 1 <= lt) b[l - 1 <= SO3_LCAP - 1 ? l - 1 : 0] = t;
             }
-            b[l] = s;
         }
+        double s0;
+        if (x > 0.5) { const double e = exp(x); s0 = 0.5 * (e - 1.0 / e) * ix; }
+        else { const double x2 = x * x; s0 = 1.0 + x2 / 6.0 * (1.0 + x2 / 20.0 * (1.0 + x2 / 42.0 * (1.0 + x2 / 72.0 * (1.0 + x2 / 110.0)))); }
+        const double sc = s0 / b[0];
+#pragma unroll
+        for (int l = 0; l < SO3_LCAP; l++) if (l <= lt) b[l] *= sc;
     } else {
+        // two divisions in all: 1/x and 1/e^x
+        const double ix = 1.0 / x;
         const double e = exp(x), em = 1.0 / e, sh = 0.5 * (e - em), ch = 0.5 * (e + em);
-        b[0] = sh / x;
-        if (lt >= 1) b[1] = (x * ch - sh) / (x * x);
-        for (int l = 1; l < lt; l++) b[l + 1] = b[l - 1] - (2 * l + 1) / x * b[l];
+        b[0] = sh * ix;
+        if (lt >= 1) b[1] = (ch - b[0]) * ix;
+#pragma unroll
+        for (int l = 1; l < SO3_LCAP - 1; l++) if (l < lt) b[l + 1] = b[l - 1] - (2 * l + 1) * ix * b[l];
     }
 }
 
@@ -71,7 +80,7 @@ __device__ void sph_in_table(double x, int lt, double *b) {
 //   sGY [4][L][M][3] cplx | sCw [4][NLM] cplx | sSelf [4][96];   phase 2 re-uses the sB/sD area per wave as
 //   the staging buffer of one pair's dC (NLM*3 complex), which the host checks to fit.
 struct so3_lds {
-    int oG, orq, oB, oD, oI, odI, oY, oGY, oC, oSelf, total, bstride, ystride, gystride, cstride;
+    int oG, orq, oB, oD, oI, odI, oY, oGY, oC, oSelf, oNY, oCG, oNL, total, bstride, ystride, gystride, cstride;
 };
 __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, int nq) {
     const int L = lmax + 1, M = 2 * lmax + 1, LT = lmax + 2, NLM = nmax * L * M;
@@ -96,6 +105,9 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, int nq) {
     o.cstride = NLM * 2;
     o.oC = off; off += SO3_WAVES * o.cstride;
     o.oSelf = off; off += SO3_WAVES * 96;
+    o.oNY = off; off += LT * LT;            // Y_l^m normalisation, l <= lmax+1, m >= 0
+    o.oCG = off; off += L * M * 6;          // the six coefficients of grad Y_l^m (SO3.py:682-707)
+    o.oNL = off; off += L;                  // norm_l = sqrt(2 sqrt2 pi / sqrt(2l+1)) (SO3.py:206)
     o.total = off;
     return o;
 }
@@ -116,6 +128,33 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
     double *sSelf = smem + lay.oSelf;
     const int ic = blockIdx.x;
     const int p0 = A.centre_pair0[ic], p1 = A.centre_pair0[ic + 1];
+    double *sNY = smem + lay.oNY, *sCG = smem + lay.oCG, *sNL = smem + lay.oNL;
+    // constant tables (square roots and factorial ratios) evaluated once per workgroup
+    for (int e = tid; e < (LT + 1) * (LT + 1); e += 256) {
+        const int l = e / (LT + 1), m = e % (LT + 1);
+        double v = 0.0;
+        if (m <= l) {
+            double ratio = 1.0;                          // (l-m)! / (l+m)!
+            for (int k = l - m + 1; k <= l + m; k++) ratio /= k;
+            v = sqrt((2 * l + 1) / (4.0 * M_PI) * ratio);
+        }
+        sNY[e] = v;
+    }
+    for (int e = tid; e < L * M; e += 256) {
+        const int l = e / M, m = e % M - A.lmax;
+        double c[6] = {0, 0, 0, 0, 0, 0};
+        if (l >= 1 && m >= -l && m <= l) {
+            const double dl = l;
+            c[0] = -sqrt(((dl + 1) * (dl + 1) - m * m) / (2 * dl + 1) / (2 * dl + 3)) * dl;
+            if (abs(m) <= l - 1) c[1] = sqrt((dl * dl - m * m) / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1);
+            c[2] = -sqrt((dl + m + 1) * (dl + m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl;
+            if (abs(m + 1) <= l - 1) c[3] = -sqrt((dl - m - 1) * (dl - m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1);
+            c[4] = -sqrt((dl - m + 1) * (dl - m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl;
+            if (abs(m - 1) <= l - 1) c[5] = -sqrt((dl + m - 1) * (dl + m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1);
+        }
+        for (int k = 0; k < 6; k++) sCG[e * 6 + k] = c[k];
+    }
+    for (int e = tid; e < L; e += 256) sNL[e] = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * e + 1.0));
     for (int e = tid; e < A.nmax * A.nq; e += 256) sG[e] = A.G[e];
     for (int e = tid; e < A.nq; e += 256) srq[e] = A.rq[e];
     for (int e = lane; e < NLM; e += 64) sCw[e] = {0.0, 0.0};
@@ -145,30 +184,22 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
                 else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
                 else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) / (l - m);
                 if (l > m) { plm2 = plm1; plm1 = plm; }
-                double ratio = 1.0;                          // (l-m)! / (l+m)!
-                for (int k = l - m + 1; k <= l + m; k++) ratio /= k;
-                const double nrm = sqrt((2 * l + 1) / (4.0 * M_PI) * ratio);
+                const double nrm = sNY[l * YW + m];
                 sY[l * YW + m] = {nrm * plm * cm, nrm * plm * sm};
             }
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
         // gradient of Y_l^m from its covariant spherical components (SO3.py:682-707)
+        const double inv_r = 1.0 / r;
         for (int e = lane; e < L * M; e += 64) {
             const int l = e / M, m = e % M - A.lmax;
             cplx g0 = {0, 0}, gp = {0, 0}, gm = {0, 0};
             if (l >= 1 && m >= -l && m <= l) {
-                const double dl = l;
-                const double inv_r = 1.0 / r;
-                g0 = cscale(Ylm(l + 1, m), -sqrt(((dl + 1) * (dl + 1) - m * m) / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
-                if (abs(m) <= l - 1)
-                    g0 = cadd(g0, cscale(Ylm(l - 1, m), sqrt((dl * dl - m * m) / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
-                gp = cscale(Ylm(l + 1, m + 1), -sqrt((dl + m + 1) * (dl + m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
-                if (abs(m + 1) <= l - 1)
-                    gp = cadd(gp, cscale(Ylm(l - 1, m + 1), -sqrt((dl - m - 1) * (dl - m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
-                gm = cscale(Ylm(l + 1, m - 1), -sqrt((dl - m + 1) * (dl - m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl * inv_r);
-                if (abs(m - 1) <= l - 1)
-                    gm = cadd(gm, cscale(Ylm(l - 1, m - 1), -sqrt((dl + m - 1) * (dl + m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1) * inv_r));
+                const double *cg = sCG + e * 6;
+                g0 = cadd(cscale(Ylm(l + 1, m), cg[0] * inv_r), cscale(Ylm(l - 1, m), cg[1] * inv_r));
+                gp = cadd(cscale(Ylm(l + 1, m + 1), cg[2] * inv_r), cscale(Ylm(l - 1, m + 1), cg[3] * inv_r));
+                gm = cadd(cscale(Ylm(l + 1, m - 1), cg[4] * inv_r), cscale(Ylm(l - 1, m - 1), cg[5] * inv_r));
             }
             const double is2 = 0.70710678118654752440;
             cplx dmp = {gm.re - gp.re, gm.im - gp.im}, smp = {gm.re + gp.re, gm.im + gp.im};
@@ -194,11 +225,12 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
             const double xarg = 2.0 * A.alpha * r * rqq;
             sph_in_table(xarg, lt, b);
             const double chain = 2.0 * A.alpha * rqq;           // d/dr of the argument
+            const double ixarg = 1.0 / xarg;
 #pragma unroll
             for (int l = 0; l <= SO3_LCAP - 1; l++)
                 if (l <= A.lmax) {
                     sB[l * A.nq + q] = b[l];
-                    const double db = (l == 0) ? b[1] : b[l - 1] - (l + 1) / xarg * b[l];   // scipy _spherical_in_d
+                    const double db = (l == 0) ? b[1] : b[l - 1] - (l + 1) * ixarg * b[l];   // scipy _spherical_in_d
                     sD[l * A.nq + q] = db * chain;
                 }
         }
@@ -236,7 +268,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
                 const int n = e / (L * M), l = (e / M) % L, mi = e % M, m = mi - A.lmax;
                 cplx cval = {0, 0}, dcv[3] = {{0, 0}, {0, 0}, {0, 0}};
                 if (m >= -l && m <= l) {
-                    const double norm = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * l + 1.0)) * w;     // SO3.py:206, 221
+                    const double norm = sNL[l] * w;                                               // SO3.py:206, 221
                     const double In = sI[n * L + l], dIn = sdI[n * L + l];
                     const cplx Y = Ylm(l, m);
                     const cplx yin = cscale(Y, In);
@@ -309,7 +341,15 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
         for (int p = q0; p < q1; p++) {
             const double2 *dp = A.dc + (size_t)p * NLM * 3;
             __builtin_amdgcn_wave_barrier();
-            for (int t = lane; t < NLM * 3; t += 64) stage[t] = dp[t];       // coalesced copy of the pair's dC
+            {   // coalesced copy of the pair's dC: all loads in flight before the first LDS store
+                double2 tmp[8];
+                const int nt = NLM * 3;
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int t = lane + 64 * u; if (t < nt) tmp[u] = dp[t]; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) { const int t = lane + 64 * u; if (t < nt) stage[t] = tmp[u]; }
+                for (int t = lane + 512; t < nt; t += 64) stage[t] = dp[t];
+            }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
 #pragma unroll
