@@ -193,6 +193,7 @@ def main():
                      "N^2 m (triangular-solve form of the variance)"),
             "gemm": ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
                      2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N"),
+            "gemv": ("gemv_t_partial_kernel: K_trans alpha", 2.0 * m_rows * N, "2 m N"),
             "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives", n_nbr * 21.0e3,
                     "~21 kflop per neighbour pair (80-node radial quadrature x 5 Bessel orders, Y_lm, dP contraction)"),
             "features": ("dot2_features_kernel: explicit degree-2 feature map", float(len(ele_rows)) * 465 * 12,

@@ -59,6 +59,7 @@ _L1_SIGNATURES = {
     "gpr_profile_enable": ([_i], _i),
     "gpr_profile_fetch": ([c_double_p, c_int_p], _i),
     "gpr_so3_power_spectrum": ([_vp, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _i] + [_vp] * 9, _i),
+    "gpr_gemv_t": ([_vp, _i, _i, _vp, _ll, _vp, _vp], _i),
     "gpr_rowdot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
     "gpr_frob_dot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
 }

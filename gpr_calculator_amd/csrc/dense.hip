@@ -421,6 +421,17 @@ __global__ void __launch_bounds__(256) rowdot_kernel(int m, int n, const double 
     if (lane == 0) out[row] = acc;
 }
 
+// partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
+__global__ void gemv_t_partial_kernel(int n, int ncols, const double *a, long long lda, const double *x, double *part,
+                                      int rows_per) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= ncols) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
+    double acc = 0.0;
+    for (int i = r0; i < r1; i++) acc += a[(long long)i * lda + j] * x[i];
+    part[(long long)blockIdx.y * ncols + j] = acc;
+}
+
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
@@ -635,4 +646,26 @@ extern "C" int gpr_rowdot(void *stream, int m, int n, const double *a, long long
     hipLaunchKernelGGL(rowdot_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, a, lda, b, ldb, out);
     LAUNCH_CHECK("rowdot");
     return GPR_OK;
+}
+
+// out[j] = sum_i a[i*lda+j] * x[i]  (A^T x for a row-major n x ncols matrix): the predictive mean K_trans alpha
+// with K_trans^T stored [N, m] (gaussianprocess.py:880); bandwidth bound, deterministic summation order
+extern "C" int gpr_gemv_t(void *stream, int n, int ncols, const double *a, long long lda, const double *x, double *out) {
+    hipStream_t st = (hipStream_t)stream;
+    if (ncols <= 0) return GPR_OK;
+    GPR_REQUIRE(out && (n == 0 || (a && x && lda >= ncols)), "gpr_gemv_t: bad arguments");
+    const int rows_per = 128;
+    const int nparts = n > 0 ? (n + rows_per - 1) / rows_per : 1;
+    void *part;
+    int rc = gpr_dev_alloc(&part, (size_t)nparts * ncols * 8, st);
+    if (rc) return rc;
+    const int pid = gpr_prof_begin(st, GPR_PROF_GEMV);
+    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, a, lda, x,
+                       (double *)part, rows_per);
+    LAUNCH_CHECK("gemv_t_partial");
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
+                       (const double *)part, out);
+    LAUNCH_CHECK("colsum_final");
+    gpr_prof_end(st, pid);
+    return gpr_dev_free(part, st);
 }

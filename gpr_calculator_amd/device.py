@@ -249,7 +249,7 @@ def profile_enable(on=True):
 
 def profile_fetch():
     """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable()"""
-    names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack")
+    names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack", "gemv")
     ms = (C.c_double * len(names))()
     n = (C.c_int * len(names))()
     check(_lib.lib().gpr_profile_fetch(ms, n), "gpr_profile_fetch")
@@ -276,4 +276,13 @@ def rowdot(a, b):
     out = torch.empty(m, dtype=F64, device=a.device)
     check(_lib.lib().gpr_rowdot(stream_ptr(), m, n, ptr(a), max(int(a.stride(0)), n), ptr(b), max(int(b.stride(0)), n),
                                 ptr(out)), "gpr_rowdot")
+    return out
+
+
+def gemv_t(a, x):
+    """a^T x for a row-major [n, ncols] device matrix and an [n] / [n, 1] vector -> [ncols]"""
+    n, ncols = a.shape
+    out = torch.empty(ncols, dtype=F64, device=a.device)
+    check(_lib.lib().gpr_gemv_t(stream_ptr(), n, ncols, ptr(a), max(int(a.stride(0)), ncols), ptr(x.reshape(-1)),
+                                ptr(out)), "gpr_gemv_t")
     return out

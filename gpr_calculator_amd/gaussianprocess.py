@@ -275,28 +275,39 @@ class GP():
     def _predict_dev(self, X, train_x, f_tol, return_std):
         """mean [m] (and variance [m]) of the quantities in X on the device.
         K(train, X) = K_trans^T is built directly (structures streamed, training set resident)."""
-        if self.kernel.name == 'RBF':
-            Kt = self.kernel.k_total_dev(X, train_x, f_tol, transpose=True)      # [N, m]
+        ws = self._weight_space()
+        Kt = None
+        if ws is not None and self.weight_space_mean:
+            # Dot kernel at zeta = 2: K_trans alpha = Psi* (sigma^2 Psi^T alpha) = Psi* w, w built once per fit
+            mean = dev.gemm(self.kernel._psi(X, ws[0]), ws[2]).reshape(-1)
         else:
-            Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
-        mean = dev.gemm(Kt, self._alpha_dev, transa=True).reshape(-1)             # K_trans alpha
+            if self.kernel.name == 'RBF':
+                Kt = self.kernel.k_total_dev(X, train_x, f_tol, transpose=True)  # [N, m]
+            else:
+                Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
+            mean = dev.gemv_t(Kt, self._alpha_dev)                                # K_trans alpha
         if not return_std:
             return mean, None
         var = self.kernel.diag_dev(X)
-        ws = self._weight_space()
         if ws is not None:
             # Dot kernel at zeta = 2: k = sigma^2 Psi psi, so |L^-1 k|^2 = psi^T M psi with the F x F matrix
             # M = (L^-1 sigma^2 Psi)^T (L^-1 sigma^2 Psi) built once per fit: no N-sized work per prediction
-            species, M = ws
+            species, M = ws[0], ws[1]
             P = self.kernel._psi(X, species)
             var = var - dev.rowdot(dev.gemm(P, M), P)
         else:
+            if Kt is None:
+                Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
             V = dev.trmm_lower(self._Linv(), Kt)                                  # V = L^-1 K_trans^T
             var = var - dev.colsumsq(V)
         return mean, torch.clamp_min(var, 0.0)
 
+    # mean of the Dot feature path evaluated in weight space (Psi* w) instead of K_trans alpha: same number,
+    # summed over features instead of training points
+    weight_space_mean = True
+
     def _weight_space(self):
-        """(species, M) for kernels with an explicit feature map (Dot_mb at zeta = 2), else None"""
+        """(species, M, w) for kernels with an explicit feature map (Dot_mb at zeta = 2), else None"""
         if not hasattr(self.kernel, "_feature_path"):
             return None
         if self._ws_cache is None:
@@ -305,9 +316,11 @@ class GP():
             if species is None:
                 self._ws_cache = False
             else:
-                W = self.kernel._psi(train_x, species) * (self.kernel.sigma ** 2)
+                Psi = self.kernel._psi(train_x, species)
+                w = dev.gemm(Psi, self._alpha_dev, transa=True, alpha=self.kernel.sigma ** 2)     # [F, 1]
+                W = Psi * (self.kernel.sigma ** 2)
                 dev.trsm_lower_(self._L_dev, W, dinv=self._dinv_dev)
-                self._ws_cache = (species, dev.gemm(W, W, transa=True))
+                self._ws_cache = (species, dev.gemm(W, W, transa=True), w)
         return self._ws_cache or None
 
     def _Linv(self):

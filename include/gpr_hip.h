@@ -129,9 +129,10 @@ int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const int *speci
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
- * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 9 entries
+ * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 10 entries
  * (0 force-force block, 1 energy-force, 2 energy-energy, 3 diagonal-only block launches, 4 triangular product
- * gpr_trmm_lower, 5 gpr_gemm, 6 SO3 descriptor, 7 Dot feature map, 8 row packing) and clears the records. */
+ * gpr_trmm_lower, 5 gpr_gemm, 6 SO3 descriptor, 7 Dot feature map, 8 row packing, 9 gpr_gemv_t) and clears the
+ * records. */
 int gpr_profile_enable(int on);
 int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
 
@@ -199,6 +200,8 @@ int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt
 int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
              const double *a, long long lda, const double *b, long long ldb, double beta,
              double *c, long long ldc);
+/* out[j] = sum_i a[i*lda+j] * x[i], j < ncols (A^T x of a row-major n x ncols matrix) */
+int gpr_gemv_t(void *stream, int n, int ncols, const double *a, long long lda, const double *x, double *out);
 /* a[i*lda+i] += (i < n_first ? add_first : add_rest): the noise diagonal (gaussianprocess.py:290-294) */
 int gpr_add_diag(void *stream, int n, double *a, long long lda, int n_first, double add_first,
                  double add_rest);

@@ -98,6 +98,12 @@ def test_fit_predict_structure_matches_oracle(kind, port_natives):
     assert abs(E_std - std[0]) < E_TOL
     assert np.abs(F_std[free] - std[1:].reshape(-1, 3)).max() < F_TOL and S is None
 
+    if kind == "Dot":       # weight-space mean (Psi* w) and training-point mean (K_trans alpha) are the same number
+        gp.weight_space_mean = False
+        E2, F2, _ = gp.predict_structure(new, stress=False, return_std=False, f_tol=1e-8)
+        gp.weight_space_mean = True
+        assert abs(E2 - E) < 1e-8 and np.abs(F2 - F).max() < 1e-8
+
     # batched predict of several structures equals the one-by-one path
     batch = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(3)]
     Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True, f_tol=1e-8)
