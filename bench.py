@@ -177,7 +177,7 @@ def main():
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.batch * args.steps / elapsed
         # roofline of the dominant kernel of the timed region (largest summed HIP-event time)
-        desc = gp.descriptor.calculate_batch_dev(batch)
+        desc = gp.descriptor.calculate_batch_dev(batch, host_index=True)
         # every seq row (i, j) is one row of atom j's force point; its species is that of centre i
         ele_rows = np.concatenate([np.asarray(nums)[sq[:, 0]] for nums, sq in zip(desc["numbers"], desc["seq"])])
         tX, _, tE, _ = gp.train_x["force"]

@@ -238,33 +238,48 @@ class SO3:
         out["row0"] = out["row0"].astype(np.int64)
         return out
 
-    def calculate_batch_dev(self, strucs):
+    def neighbor_batch_dev(self, strucs):
+        """device-resident neighbour pairs / seq rows of a batch (gpr_nbr_build_device); NeighborBatch"""
+        return NeighborBatch(strucs, float(self.rcut), bool(self.weight_on))
+
+    def calculate_batch_dev(self, strucs, host_index=False):
         """Descriptors of several structures in one launch.  Returns a dict of device tensors
-        x [sum n, d], dxdr [sum S, d, 3] and host arrays: seq [sum S, 2] (local atom ids),
-        struct_atom0 / struct_row0 offsets, numbers."""
+        x [sum n, d], dxdr [sum S, d, 3] plus `nbr` (the NeighborBatch the rows refer to) and the host
+        offsets atom0 / row0 / numbers_all.  With host_index=True the neighbour search runs on the host
+        (gpr_nbr_build) and the per-structure `seq` lists are returned as numpy arrays as well."""
         if not self.derivative:
             raise NotImplementedError("derivative=False is not used on the GPR hot path")
-        nb = self.neighbor_index_batch(strucs)
-        atom0, row0, numbers = nb["atom0"], nb["row0"], nb["numbers"]
-        vec, w, cp0, cr0, rp0, sr = nb["vec"], nb["w"], nb["centre_pair0"], nb["centre_row0"], nb["row_pair0"], nb["self_row"]
-        nc, P, S, d = int(atom0[-1]), len(w), int(row0[-1]), self.ncoefs
         rq, G, nq = self._device_tables()
         D = dev.device()
+        d = self.ncoefs
+        nlm = self.nmax * (self.lmax + 1) * (2 * self.lmax + 1)
+        if host_index:
+            nb = self.neighbor_index_batch(strucs)
+            atom0, row0, numbers = nb["atom0"], nb["row0"], nb["numbers"]
+            nc, P, S = int(atom0[-1]), len(nb["w"]), int(row0[-1])
+            t = lambda a, dt: dev.to_dev(a, dt)
+            keep = [t(nb["vec"], dev.F64), t(nb["w"], dev.F64)] + \
+                   [t(nb[k], torch.int32) for k in ("centre_pair0", "centre_row0", "row_pair0", "self_row")]
+            ptrs = [dev.ptr(a) for a in keep]
+            nbr = None
+        else:
+            nbr = self.neighbor_batch_dev(strucs)
+            atom0, row0, numbers = nbr.atom0, nbr.row0, nbr.numbers
+            nc, P, S = nbr.natoms, nbr.P, nbr.S
+            ptrs = [nbr.ptrs[k] for k in ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row")]
         x = torch.empty((nc, d), dtype=dev.F64, device=D)
         dxdr = torch.empty((S, d, 3), dtype=dev.F64, device=D)
-        nlm = self.nmax * (self.lmax + 1) * (2 * self.lmax + 1)
         scratch = torch.empty((max(P, 1) * nlm * 3, 2), dtype=dev.F64, device=D)
-        t = lambda a, dt: dev.to_dev(a, dt)
-        d_vec, d_w = t(vec, dev.F64), t(w, dev.F64)
-        d_cp0, d_cr0, d_rp0, d_sr = (t(a, torch.int32) for a in (cp0, cr0, rp0, sr))
         dev.check(_lib.lib().gpr_so3_power_spectrum(
             dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nq, dev.ptr(G), dev.ptr(rq),
-            nc, P, S, dev.ptr(d_vec), dev.ptr(d_w), dev.ptr(d_cp0), dev.ptr(d_cr0), dev.ptr(d_rp0), dev.ptr(d_sr),
-            dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
-        seq = nb["seq"]
-        return dict(x=x, dxdr=dxdr, seq=[seq[row0[k]:row0[k + 1]] for k in range(len(strucs))],
-                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))], atom0=atom0, row0=row0,
-                    seq_all=seq, numbers_all=numbers)
+            nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
+        out = dict(x=x, dxdr=dxdr, atom0=atom0, row0=row0, numbers_all=numbers, nbr=nbr,
+                   numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))])
+        if host_index:
+            seq = nb["seq"]
+            out["seq_all"] = seq
+            out["seq"] = [seq[row0[k]:row0[k + 1]] for k in range(len(strucs))]
+        return out
 
     def calculate(self, atoms, atom_ids=None, use_mpi=False):
         '''
@@ -278,8 +293,95 @@ class SO3:
         if self._stress:
             raise NotImplementedError("stress=True (rdxdr) belongs to the path the reference marks obsolete "
                                       "(RBF_mb.py:210); not built on the GPU yet")
-        out = self.calculate_batch_dev([atoms])
+        out = self.calculate_batch_dev([atoms], host_index=True)
         numbers = out["numbers"][0]
         symbols = list(atoms.symbols) if hasattr(atoms, "symbols") else [symbol_of(z) for z in numbers]
         return {'x': out["x"].cpu().numpy(), 'dxdr': out["dxdr"].cpu().numpy(), 'rdxdr': None,
                 'elements': [str(s) for s in symbols], 'seq': out["seq"][0]}
+
+
+class NeighborBatch:
+    """Neighbour pairs and `seq` rows of a batch of structures, built and kept on the device
+    (csrc/nbr.hip: gpr_nbr_build_device).  Host side: atom0 / row0 offsets, numbers, centre_row0."""
+
+    def __init__(self, strucs, rcut, weight_on):
+        arrs = [atoms_arrays(s) for s in strucs]
+        self.nstruct = len(arrs)
+        self.atom0 = np.zeros(self.nstruct + 1, dtype=np.int64)
+        np.cumsum([len(a[0]) for a in arrs], out=self.atom0[1:])
+        atom0 = self.atom0.astype(np.int32)
+        self.numbers = np.concatenate([a[0] for a in arrs]).astype(np.int64) if arrs else np.zeros(0, np.int64)
+        numbers = np.ascontiguousarray(self.numbers, dtype=np.int32)
+        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
+        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
+        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32)
+        L = _lib.lib()
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        self._h = C.c_void_p()
+        self.natoms = int(atom0[-1])
+        dev.check(L.gpr_nbr_build_device(C.byref(self._h), dev.stream_ptr(), self.nstruct, ip(atom0), dp(pos), dp(cells),
+                                         ip(pbc), ip(numbers), rcut, int(weight_on)), "gpr_nbr_build_device")
+        P, S = C.c_int(), C.c_int()
+        dev.check(L.gpr_nbr_sizes(self._h, C.byref(P), C.byref(S)), "gpr_nbr_sizes")
+        self.P, self.S = P.value, S.value
+        self.centre_row0 = np.empty(self.natoms + 1, np.int32)
+        row0 = np.empty(self.nstruct + 1, np.int32)
+        dev.check(L.gpr_nbr_export(self._h, None, None, None, ip(self.centre_row0), None, None, None, ip(row0)),
+                  "gpr_nbr_export")
+        self.row0 = row0.astype(np.int64)
+        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers")
+        raw = [C.c_void_p() for _ in names]
+        dev.check(L.gpr_nbr_device_arrays(self._h, *[C.byref(r) for r in raw]), "gpr_nbr_device_arrays")
+        self.ptrs = dict(zip(names, raw))
+
+    def force_rows(self, atoms):
+        """(counts, row_index, x_index) of the force points of the moving atoms `atoms` (global ids):
+        device int32 index arrays into dxdr rows / x rows (gpr_nbr_force_rows)"""
+        atoms = np.ascontiguousarray(atoms, dtype=np.int32)
+        counts = (self.centre_row0[1:] - self.centre_row0[:-1])[atoms]
+        meta = np.empty(2 * len(atoms) + 1, dtype=np.int32)        # [atoms | pt_row0] in one upload
+        meta[:len(atoms)] = atoms
+        meta[len(atoms)] = 0
+        np.cumsum(counts, out=meta[len(atoms) + 1:])
+        nrows = int(meta[-1])
+        d_meta = dev.to_dev(meta, torch.int32)
+        idx = torch.empty((2, max(nrows, 1)), dtype=torch.int32, device=dev.device())
+        dev.check(_lib.lib().gpr_nbr_force_rows(self._h, len(atoms), dev.ptr(d_meta),
+                                                C.c_void_p(d_meta.data_ptr() + 4 * len(atoms)), nrows,
+                                                dev.ptr(idx[0]), dev.ptr(idx[1])), "gpr_nbr_force_rows")
+        return counts, idx[0, :nrows], idx[1, :nrows]
+
+    def numbers_dev(self):
+        """int32 device view of the atomic numbers is not exposed as a tensor; upload the host copy"""
+        return dev.to_dev(self.numbers, torch.int32)
+
+    def check(self):
+        n = C.c_int()
+        dev.check(_lib.lib().gpr_nbr_check(self._h, C.byref(n)), "gpr_nbr_check")
+        if n.value:
+            raise RuntimeError(f"neighbour table is not symmetric: {n.value} force rows missing")
+
+    def export(self):
+        """host copies in the layout of SO3.neighbor_index_batch (tests, debugging)"""
+        out = dict(vec=np.empty((self.P, 3)), w=np.empty(self.P), centre_pair0=np.empty(self.natoms + 1, np.int32),
+                   centre_row0=np.empty(self.natoms + 1, np.int32), row_pair0=np.empty(self.S + 1, np.int32),
+                   self_row=np.empty(self.natoms, np.int32), seq=np.empty((self.S, 2), np.int32),
+                   row0=np.empty(self.nstruct + 1, np.int32))
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        dev.check(_lib.lib().gpr_nbr_export(self._h, dp(out["vec"]), dp(out["w"]), ip(out["centre_pair0"]),
+                                            ip(out["centre_row0"]), ip(out["row_pair0"]), ip(out["self_row"]),
+                                            ip(out["seq"]), ip(out["row0"])), "gpr_nbr_export")
+        return out
+
+    def close(self):
+        if self._h:
+            _lib.lib().gpr_nbr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

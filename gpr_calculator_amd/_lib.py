@@ -50,6 +50,11 @@ _L1_SIGNATURES = {
     "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),
     "gpr_colsumsq": ([_vp, _i, _i, _vp, _ll, _vp], _i),
     "gpr_sum_log_diag": ([_vp, _i, _vp, _ll, _vp], _i),
+    "gpr_set_create_gather": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _vp, _vp, _i], _i),
+    "gpr_nbr_build_device": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
+    "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 8, _i),
+    "gpr_nbr_force_rows": ([_vp, _i, _vp, _vp, _i, _vp, _vp], _i),
+    "gpr_nbr_check": ([_vp, c_int_p], _i),
     "gpr_nbr_build": ([C.POINTER(_vp), _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),
     "gpr_nbr_export": ([_vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p], _i),

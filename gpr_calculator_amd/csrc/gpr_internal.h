@@ -103,3 +103,4 @@ void gpr_prof_end(hipStream_t st, int id);
 // small helpers
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
 int gpr_dev_free(void *p, hipStream_t st);
+void gpr_reap_sets();   // frees the host side of destroyed sets whose stream work has completed

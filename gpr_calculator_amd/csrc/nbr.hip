@@ -1,12 +1,16 @@
-// nbr.hip -- host-side (C++) periodic neighbour search and `seq` bookkeeping for batches of
-// structures: the index arithmetic SO3.build_neighbor_list does through ase.neighborlist.NeighborList
+// nbr.hip -- periodic neighbour search and `seq` bookkeeping for batches of structures: the index
+// arithmetic SO3.build_neighbor_list does through ase.neighborlist.NeighborList
 // (gpr_calc/SO3.py:348-407: cutoffs rcut/2 per atom, bothways, no self interaction, skin 0).
-// No floating-point model arithmetic happens here beyond the distance predicate; the outputs feed
-// gpr_so3_power_spectrum.
+// Two builders with identical output: gpr_nbr_build (host threads, host arrays) and
+// gpr_nbr_build_device (one wavefront per centre atom, results stay in HBM and feed
+// gpr_so3_power_spectrum and the force-point gather of gpr_set_create_gather without a host round
+// trip).  No floating-point model arithmetic happens here beyond the distance predicate.
 #include <algorithm>
 #include <cmath>
 #include <thread>
 #include "gpr_internal.h"
+
+struct nbr_sinfo { int atom0, n, img0, nimg, zero_img, pad; };
 
 struct gpr_nbr {
     int nstruct = 0, natoms = 0;
@@ -16,32 +20,40 @@ struct gpr_nbr {
     std::vector<int> self_row;                  // [natoms]
     std::vector<int> seq;                       // [S,2] structure-local atom ids
     std::vector<int> struct_row0;               // [nstruct+1]
+    // device-built variant: everything above except centre_row0 / struct_row0 stays empty on the host
+    bool on_device = false;
+    hipStream_t st = nullptr;
+    int P = 0, S = 0;
+    char *d_in = nullptr;                       // uploaded geometry blob
+    const double *d_wpos = nullptr, *d_shift = nullptr;
+    const int *d_numbers = nullptr, *d_sid = nullptr;
+    const nbr_sinfo *d_sinfo = nullptr;
+    int *d_off = nullptr;                       // [centre_row0 (natoms+1) | centre_pair0 (natoms+1) | counts | err]
+    double *d_vec = nullptr, *d_w = nullptr;
+    int *d_rp0 = nullptr, *d_self = nullptr, *d_seq = nullptr, *d_err = nullptr;
 };
 
 static void cross3(const double *a, const double *b, double *c) {
     c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// per-structure result (structure-local pair / row numbering), merged afterwards
-struct nbr_local {
-    std::vector<double> vec, w;
-    std::vector<int> centre_pair0, centre_row0, row_pair0, self_row, seq;   // offsets start at 0
+// wrapped positions and the periodic image table of one structure (shared by both builders)
+struct nbr_geom {
+    std::vector<double> wrapped, shifts;
+    int nimg = 0, zero_img = 0;
     bool singular = false;
 };
 
-static void nbr_one(int n, const double *positions, const double *cell, const int *pb, const int *numbers,
-                    double rcut, int weight_on, nbr_local &out) {
-    const double rc2 = rcut * rcut;
+static void nbr_geometry(int n, const double *positions, const double *cell, const int *pb, double rcut, nbr_geom &g) {
     const bool any = pb[0] || pb[1] || pb[2];
-    std::vector<double> wrapped(positions, positions + 3 * (size_t)n), shifts;
-    std::vector<int> imgs;
+    g.wrapped.assign(positions, positions + 3 * (size_t)n);
     int nimg[3] = {0, 0, 0};
     if (any) {
         double c01[3], c12[3], c20[3];
         cross3(cell, cell + 3, c01); cross3(cell + 3, cell + 6, c12); cross3(cell + 6, cell, c20);
         const double det = cell[0] * c12[0] + cell[1] * c12[1] + cell[2] * c12[2];
         const double vol = std::fabs(det);
-        if (vol < 1e-12) { out.singular = true; return; }
+        if (vol < 1e-12) { g.singular = true; return; }
         const double *perp[3] = {c12, c20, c01};     // normal of the plane spanned by the other two
         for (int k = 0; k < 3; k++)
             if (pb[k]) {
@@ -49,7 +61,7 @@ static void nbr_one(int n, const double *positions, const double *cell, const in
                 nimg[k] = (int)std::ceil(rcut / (vol / area));
             }
         for (int i = 0; i < n; i++) {
-            double *p = &wrapped[3 * i];
+            double *p = &g.wrapped[3 * i];
             double f[3];
             for (int k = 0; k < 3; k++) f[k] = (p[0] * perp[k][0] + p[1] * perp[k][1] + p[2] * perp[k][2]) / det;
             for (int k = 0; k < 3; k++)
@@ -62,10 +74,27 @@ static void nbr_one(int n, const double *positions, const double *cell, const in
     for (int a = -nimg[0]; a <= nimg[0]; a++)
         for (int b = -nimg[1]; b <= nimg[1]; b++)
             for (int c = -nimg[2]; c <= nimg[2]; c++) {
-                imgs.push_back((a == 0 && b == 0 && c == 0) ? 1 : 0);
-                for (int k = 0; k < 3; k++) shifts.push_back(a * cell[k] + b * cell[3 + k] + c * cell[6 + k]);
+                if (a == 0 && b == 0 && c == 0) g.zero_img = g.nimg;
+                for (int k = 0; k < 3; k++) g.shifts.push_back(a * cell[k] + b * cell[3 + k] + c * cell[6 + k]);
+                g.nimg++;
             }
-    const int nI = (int)imgs.size();
+}
+
+// per-structure result (structure-local pair / row numbering), merged afterwards
+struct nbr_local {
+    std::vector<double> vec, w;
+    std::vector<int> centre_pair0, centre_row0, row_pair0, self_row, seq;   // offsets start at 0
+    bool singular = false;
+};
+
+static void nbr_one(int n, const double *positions, const double *cell, const int *pb, const int *numbers,
+                    double rcut, int weight_on, nbr_local &out) {
+    const double rc2 = rcut * rcut;
+    nbr_geom g;
+    nbr_geometry(n, positions, cell, pb, rcut, g);
+    if (g.singular) { out.singular = true; return; }
+    const std::vector<double> &wrapped = g.wrapped, &shifts = g.shifts;
+    const int nI = g.nimg;
     out.centre_pair0.push_back(0); out.centre_row0.push_back(0); out.row_pair0.push_back(0);
     for (int i = 0; i < n; i++) {
         const double *pi = &wrapped[3 * i];
@@ -73,9 +102,11 @@ static void nbr_one(int n, const double *positions, const double *cell, const in
             const double *pj = &wrapped[3 * j];
             int found = 0;
             for (int im = 0; im < nI; im++) {
-                if (i == j && imgs[im]) continue;
-                const double dx = pj[0] + shifts[3 * im] - pi[0], dy = pj[1] + shifts[3 * im + 1] - pi[1],
-                             dz = pj[2] + shifts[3 * im + 2] - pi[2];
+                if (i == j && im == g.zero_img) continue;
+                // (pj - pi) + shift: exactly antisymmetric under (i <-> j, image -> -image), so the neighbour
+                // relation is symmetric bit for bit (the device path relies on it)
+                const double dx = (pj[0] - pi[0]) + shifts[3 * im], dy = (pj[1] - pi[1]) + shifts[3 * im + 1],
+                             dz = (pj[2] - pi[2]) + shifts[3 * im + 2];
                 if (dx * dx + dy * dy + dz * dz < rc2) {
                     out.vec.push_back(dx); out.vec.push_back(dy); out.vec.push_back(dz);
                     double wgt = numbers[j];
@@ -134,14 +165,282 @@ extern "C" int gpr_nbr_build(gpr_nbr **out, int nstruct, const int *atom0, const
         for (int v : l.self_row) nb->self_row.push_back(v + r0);
         nb->struct_row0.push_back((int)nb->seq.size() / 2);
     }
+    nb->P = (int)nb->w.size(); nb->S = (int)nb->seq.size() / 2;
     *out = nb;
+    return GPR_OK;
+}
+
+// ================================================================ device builder
+namespace {
+
+struct nbrk_args {
+    const double *wpos, *shift;
+    const int *numbers, *sid;
+    const nbr_sinfo *sinfo;
+    int *cnt_pairs, *cnt_rows;       // count pass: per-centre totals
+    const int *cr0, *cp0;            // fill pass: exclusive offsets
+    double *vec, *w;
+    int *rp0, *self_row, *seq;
+    double rc2;
+    int natoms, weight_on;
+};
+
+__device__ inline int wave_incl_scan(int v, int lane) {
+    for (int o = 1; o < 64; o <<= 1) {
+        int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+
+// One wavefront per centre atom i; lane l looks at neighbours j = l, l + 64, ...; pairs of a centre are
+// ordered by (j, image) and rows by j, like the host builder.  FILL = false only counts.
+template <bool FILL>
+__global__ void __launch_bounds__(64) nbr_centre_kernel(nbrk_args a) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    const nbr_sinfo si = a.sinfo[a.sid[i]];
+    const int il = i - si.atom0;
+    const double pix = a.wpos[3 * (size_t)i], piy = a.wpos[3 * (size_t)i + 1], piz = a.wpos[3 * (size_t)i + 2];
+    const int zi = a.numbers[i];
+    const double *sh = a.shift + 3 * (size_t)si.img0;
+    int pair_run = FILL ? a.cp0[i] : 0, row_run = FILL ? a.cr0[i] : 0;
+    for (int jb = 0; jb < si.n; jb += 64) {
+        const int j = jb + lane;
+        const bool live = j < si.n;
+        double dx0 = 0.0, dy0 = 0.0, dz0 = 0.0;
+        if (live) {
+            const double *pj = a.wpos + 3 * (size_t)(si.atom0 + j);
+            dx0 = pj[0] - pix; dy0 = pj[1] - piy; dz0 = pj[2] - piz;
+        }
+        int found = 0;
+        if (live)
+            for (int im = 0; im < si.nimg; im++) {
+                if (j == il && im == si.zero_img) continue;
+                const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                // no fused multiply-add: the predicate has to agree with the host builder to the bit
+                const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                if (r2 < a.rc2) found++;
+            }
+        const int isrow = (live && (found > 0 || j == il)) ? 1 : 0;
+        const int pincl = wave_incl_scan(found, lane), rincl = wave_incl_scan(isrow, lane);
+        if (FILL) {
+            int p = pair_run + pincl - found;
+            const int row = row_run + rincl - isrow;
+            if (isrow) {
+                a.seq[2 * (size_t)row] = il; a.seq[2 * (size_t)row + 1] = j;
+                a.rp0[row] = p;
+                if (j == il) a.self_row[i] = row;
+            }
+            if (found) {
+                const int zj = a.numbers[si.atom0 + j];
+                const double wgt = (a.weight_on && zj != zi) ? -(double)zj : (double)zj;     // SO3.py:381-385
+                for (int im = 0; im < si.nimg; im++) {
+                    if (j == il && im == si.zero_img) continue;
+                    const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                    const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                    if (r2 < a.rc2) {
+                        a.vec[3 * (size_t)p] = dx; a.vec[3 * (size_t)p + 1] = dy; a.vec[3 * (size_t)p + 2] = dz;
+                        a.w[p] = wgt;
+                        p++;
+                    }
+                }
+            }
+        }
+        pair_run += __shfl(pincl, 63);
+        row_run += __shfl(rincl, 63);
+    }
+    if (!FILL && lane == 0) { a.cnt_pairs[i] = pair_run; a.cnt_rows[i] = row_run; }
+}
+
+// exclusive scans of the per-centre counts: off = [cr0 (n+1) | cp0 (n+1)]; one workgroup
+__global__ void __launch_bounds__(1024) nbr_scan_kernel(int n, const int *cnt_rows, const int *cnt_pairs, int *off) {
+    __shared__ int wsum[2][16];
+    __shared__ int carry[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 2) carry[tid] = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int k = base + tid;
+        const int vr = k < n ? cnt_rows[k] : 0, vp = k < n ? cnt_pairs[k] : 0;
+        const int ir = wave_incl_scan(vr, lane), ip = wave_incl_scan(vp, lane);
+        if (lane == 63) { wsum[0][wave] = ir; wsum[1][wave] = ip; }
+        __syncthreads();
+        int wr = 0, wp = 0;
+        for (int q = 0; q < wave; q++) { wr += wsum[0][q]; wp += wsum[1][q]; }
+        const int cr = carry[0], cp = carry[1];
+        if (k < n) { off[k] = cr + wr + ir - vr; off[n + 1 + k] = cp + wp + ip - vp; }
+        __syncthreads();
+        if (tid == 1023) { carry[0] = cr + wr + ir; carry[1] = cp + wp + ip; }
+        __syncthreads();
+    }
+    if (tid == 0) { off[n] = carry[0]; off[2 * n + 1] = carry[1]; }
+}
+
+struct frow_args {
+    const int *atoms, *pt_row0;      // [npts], [npts+1]
+    const int *cr0, *seq, *sid;
+    const nbr_sinfo *sinfo;
+    int *row_index, *x_index, *err;
+    int npts, nrows;
+};
+
+// output row q = k-th row of force point p (moving atom a): the k-th neighbour i of a (rows of centre a are
+// ordered by neighbour) and the seq row (i, a) found among the rows of centre i
+__global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= f.nrows) return;
+    int lo = 0, hi = f.npts;                   // last p with pt_row0[p] <= q
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (f.pt_row0[mid] <= q) lo = mid; else hi = mid;
+    }
+    const int a = f.atoms[lo], k = q - f.pt_row0[lo];
+    const int atom0 = f.sinfo[f.sid[a]].atom0, al = a - atom0;
+    const int i = atom0 + f.seq[2 * (size_t)(f.cr0[a] + k) + 1];
+    int r0 = f.cr0[i], r1 = f.cr0[i + 1], found = -1;
+    while (r0 < r1) {
+        const int mid = (r0 + r1) >> 1, jm = f.seq[2 * (size_t)mid + 1];
+        if (jm == al) { found = mid; break; }
+        if (jm < al) r0 = mid + 1; else r1 = mid;
+    }
+    if (found < 0) atomicAdd(f.err, 1);
+    f.row_index[q] = found;
+    f.x_index[q] = i;
+}
+
+}  // namespace
+
+extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                    const double *cells, const int *pbc, const int *numbers, double rcut,
+                                    int weight_on) {
+    GPR_REQUIRE(out && atom0 && (nstruct == 0 || (positions && cells && pbc && numbers)), "gpr_nbr_build_device: null pointer");
+    GPR_REQUIRE(rcut > 0.0, "gpr_nbr_build_device: rcut must be positive");
+    hipStream_t st = (hipStream_t)stream;
+    const int natoms = nstruct ? atom0[nstruct] : 0;
+    // host: wrap positions, image tables; one blob [wpos | shifts | sinfo | numbers | sid]
+    std::vector<nbr_sinfo> sinfo(nstruct);
+    std::vector<double> wpos, shifts;
+    wpos.reserve(3 * (size_t)natoms);
+    std::vector<int> sid(natoms);
+    for (int s = 0; s < nstruct; s++) {
+        const int n = atom0[s + 1] - atom0[s];
+        GPR_REQUIRE(n >= 0, "gpr_nbr_build_device: atom0 not ascending at structure %d", s);
+        nbr_geom g;
+        nbr_geometry(n, positions + 3 * (size_t)atom0[s], cells + 9 * s, pbc + 3 * s, rcut, g);
+        if (g.singular) { gpr_set_error("gpr_nbr_build_device: periodic structure %d has a singular cell", s); return GPR_ERR_ARG; }
+        sinfo[s] = nbr_sinfo{atom0[s], n, (int)(shifts.size() / 3), g.nimg, g.zero_img, 0};
+        wpos.insert(wpos.end(), g.wrapped.begin(), g.wrapped.end());
+        shifts.insert(shifts.end(), g.shifts.begin(), g.shifts.end());
+        for (int k = 0; k < n; k++) sid[atom0[s] + k] = s;
+    }
+    const size_t b_wpos = wpos.size() * 8, b_shift = shifts.size() * 8, b_sinfo = sinfo.size() * sizeof(nbr_sinfo),
+                 b_num = (size_t)natoms * 4;
+    std::vector<char> blob(b_wpos + b_shift + b_sinfo + 2 * b_num);
+    char *bp = blob.data();
+    if (b_wpos) memcpy(bp, wpos.data(), b_wpos);
+    if (b_shift) memcpy(bp + b_wpos, shifts.data(), b_shift);
+    if (b_sinfo) memcpy(bp + b_wpos + b_shift, sinfo.data(), b_sinfo);
+    if (b_num) { memcpy(bp + b_wpos + b_shift + b_sinfo, numbers, b_num); memcpy(bp + b_wpos + b_shift + b_sinfo + b_num, sid.data(), b_num); }
+
+    gpr_nbr *nb = new gpr_nbr();
+    nb->on_device = true; nb->st = st; nb->nstruct = nstruct; nb->natoms = natoms;
+    auto fail = [&](int code) { gpr_nbr_destroy(nb); return code; };
+    int rc;
+    void *p;
+    if ((rc = gpr_dev_alloc(&p, blob.size() + 16, st))) return fail(rc);
+    nb->d_in = (char *)p;
+    if (!blob.empty()) {
+        // pageable source: the runtime stages it before returning, `blob` may die afterwards
+        hipError_t e = hipMemcpyAsync(nb->d_in, blob.data(), blob.size(), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: upload failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+    }
+    nb->d_wpos = (const double *)nb->d_in;
+    nb->d_shift = (const double *)(nb->d_in + b_wpos);
+    nb->d_sinfo = (const nbr_sinfo *)(nb->d_in + b_wpos + b_shift);
+    nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
+    nb->d_sid = nb->d_numbers + natoms;
+    if ((rc = gpr_dev_alloc(&p, (size_t)(4 * natoms + 4) * sizeof(int), st))) return fail(rc);
+    nb->d_off = (int *)p;                       // [cr0 | cp0 | cnt_rows | cnt_pairs | err]
+    int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
+    nb->d_err = cnt_pairs + natoms;
+    if ((rc = gpr_dev_alloc(&p, (size_t)std::max(natoms, 1) * sizeof(int), st))) return fail(rc);
+    nb->d_self = (int *)p;
+
+    nbrk_args a{};
+    a.wpos = nb->d_wpos; a.shift = nb->d_shift; a.numbers = nb->d_numbers; a.sid = nb->d_sid; a.sinfo = nb->d_sinfo;
+    a.cnt_pairs = cnt_pairs; a.cnt_rows = cnt_rows; a.rc2 = rcut * rcut; a.natoms = natoms; a.weight_on = weight_on;
+    nb->centre_row0.assign(natoms + 1, 0);
+    std::vector<int> h_off(2 * (size_t)natoms + 2, 0);
+    {
+        hipError_t e = hipMemsetAsync(nb->d_err, 0, sizeof(int), st);
+        if (e == hipSuccess && natoms > 0) {
+            hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
+            hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off);
+            e = hipMemcpyAsync(h_off.data(), nb->d_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);      // the sizes decide every later allocation
+        }
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: count pass failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+    }
+    std::copy(h_off.begin(), h_off.begin() + natoms + 1, nb->centre_row0.begin());
+    nb->S = h_off[natoms]; nb->P = h_off[2 * natoms + 1];
+    nb->struct_row0.resize(nstruct + 1);
+    for (int s = 0; s <= nstruct; s++) nb->struct_row0[s] = nb->centre_row0[atom0[s]];
+    if ((rc = gpr_dev_alloc(&p, (size_t)std::max(nb->P, 1) * 4 * sizeof(double), st))) return fail(rc);
+    nb->d_vec = (double *)p; nb->d_w = nb->d_vec + 3 * (size_t)std::max(nb->P, 1);
+    if ((rc = gpr_dev_alloc(&p, ((size_t)3 * nb->S + 4) * sizeof(int), st))) return fail(rc);
+    nb->d_seq = (int *)p; nb->d_rp0 = nb->d_seq + 2 * (size_t)nb->S;
+    if (natoms > 0) {
+        a.cr0 = nb->d_off; a.cp0 = nb->d_off + natoms + 1;
+        a.vec = nb->d_vec; a.w = nb->d_w; a.rp0 = nb->d_rp0; a.self_row = nb->d_self; a.seq = nb->d_seq;
+        hipLaunchKernelGGL(nbr_centre_kernel<true>, dim3(natoms), dim3(64), 0, st, a);
+        // row_pair0[S] = P
+        hipError_t e = hipMemcpyAsync(nb->d_rp0 + nb->S, nb->d_off + 2 * natoms + 1, sizeof(int), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fill pass failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+    }
+    *out = nb;
+    return GPR_OK;
+}
+
+extern "C" int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
+                                     const int **centre_row0, const int **row_pair0, const int **self_row,
+                                     const int **seq, const int **numbers) {
+    GPR_REQUIRE(nb && nb->on_device, "gpr_nbr_device_arrays: handle was not built by gpr_nbr_build_device");
+    if (vec) *vec = nb->d_vec;
+    if (w) *w = nb->d_w;
+    if (centre_pair0) *centre_pair0 = nb->d_off + nb->natoms + 1;
+    if (centre_row0) *centre_row0 = nb->d_off;
+    if (row_pair0) *row_pair0 = nb->d_rp0;
+    if (self_row) *self_row = nb->d_self;
+    if (seq) *seq = nb->d_seq;
+    if (numbers) *numbers = nb->d_numbers;
+    return GPR_OK;
+}
+
+extern "C" int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const int *pt_row0_dev, int nrows,
+                                  int *row_index_dev, int *x_index_dev) {
+    GPR_REQUIRE(nb && nb->on_device, "gpr_nbr_force_rows: handle was not built by gpr_nbr_build_device");
+    GPR_REQUIRE(npts >= 0 && nrows >= 0, "gpr_nbr_force_rows: negative sizes");
+    if (nrows == 0 || npts == 0) return GPR_OK;
+    GPR_REQUIRE(atoms_dev && pt_row0_dev && row_index_dev && x_index_dev, "gpr_nbr_force_rows: null device pointer");
+    frow_args f{atoms_dev, pt_row0_dev, nb->d_off, nb->d_seq, nb->d_sid, nb->d_sinfo, row_index_dev, x_index_dev, nb->d_err,
+                npts, nrows};
+    hipLaunchKernelGGL(nbr_force_rows_kernel, dim3((nrows + 255) / 256), dim3(256), 0, nb->st, f);
+    GPR_HIP_TRY(hipGetLastError());
+    return GPR_OK;
+}
+
+extern "C" int gpr_nbr_check(const gpr_nbr *nb, int *nmissing) {
+    GPR_REQUIRE(nb && nb->on_device && nmissing, "gpr_nbr_check: needs a device-built handle");
+    GPR_HIP_TRY(hipMemcpyAsync(nmissing, nb->d_err, sizeof(int), hipMemcpyDeviceToHost, nb->st));
+    GPR_HIP_TRY(hipStreamSynchronize(nb->st));
     return GPR_OK;
 }
 
 extern "C" int gpr_nbr_sizes(const gpr_nbr *nb, int *npairs, int *nrows) {
     GPR_REQUIRE(nb, "gpr_nbr_sizes: null handle");
-    if (npairs) *npairs = (int)nb->w.size();
-    if (nrows) *nrows = (int)nb->seq.size() / 2;
+    if (npairs) *npairs = nb->P;
+    if (nrows) *nrows = nb->S;
     return GPR_OK;
 }
 
@@ -149,12 +448,35 @@ extern "C" int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *ce
                               int *row_pair0, int *self_row, int *seq, int *struct_row0) {
     GPR_REQUIRE(nb, "gpr_nbr_export: null handle");
     auto cp = [](auto *dst, const auto &src) { if (dst && !src.empty()) std::copy(src.begin(), src.end(), dst); };
-    cp(vec, nb->vec); cp(w, nb->w); cp(centre_pair0, nb->centre_pair0); cp(centre_row0, nb->centre_row0);
-    cp(row_pair0, nb->row_pair0); cp(self_row, nb->self_row); cp(seq, nb->seq); cp(struct_row0, nb->struct_row0);
+    cp(centre_row0, nb->centre_row0); cp(struct_row0, nb->struct_row0);
+    if (!nb->on_device) {
+        cp(vec, nb->vec); cp(w, nb->w); cp(centre_pair0, nb->centre_pair0);
+        cp(row_pair0, nb->row_pair0); cp(self_row, nb->self_row); cp(seq, nb->seq);
+        return GPR_OK;
+    }
+    // device-built: download what was asked for (a synchronising debug / single-structure path)
+    const int n = nb->natoms, P = nb->P, S = nb->S;
+    hipStream_t st = nb->st;
+    auto dl = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        if (!dst || bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st);
+    };
+    GPR_HIP_TRY(dl(vec, nb->d_vec, (size_t)P * 24));
+    GPR_HIP_TRY(dl(w, nb->d_w, (size_t)P * 8));
+    GPR_HIP_TRY(dl(centre_pair0, nb->d_off + n + 1, (size_t)(n + 1) * 4));
+    GPR_HIP_TRY(dl(row_pair0, nb->d_rp0, (size_t)(S + 1) * 4));
+    GPR_HIP_TRY(dl(self_row, nb->d_self, (size_t)n * 4));
+    GPR_HIP_TRY(dl(seq, nb->d_seq, (size_t)S * 8));
+    GPR_HIP_TRY(hipStreamSynchronize(st));
     return GPR_OK;
 }
 
 extern "C" int gpr_nbr_destroy(gpr_nbr *nb) {
+    if (!nb) return GPR_OK;
+    if (nb->on_device) {      // stream-ordered frees: kernels already queued on the stream still see the arrays
+        gpr_dev_free(nb->d_in, nb->st); gpr_dev_free(nb->d_off, nb->st); gpr_dev_free(nb->d_self, nb->st);
+        gpr_dev_free(nb->d_vec, nb->st); gpr_dev_free(nb->d_seq, nb->st);
+    }
     delete nb;
     return GPR_OK;
 }

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <numeric>
+#include <mutex>
 #include "gpr_internal.h"
 
 // ---------------------------------------------------------------- errors / misc
@@ -53,6 +54,7 @@ int gpr_dev_free(void *p, hipStream_t st) {
 struct pack_args {
     const double *x, *dxdr;
     const int *ele, *src_row;
+    const int *x_index, *d_index;   // optional gather: caller row r reads x[x_index[r]], dxdr[d_index[r]], ele[x_index[r]]
     double *ops, *norms;
     int *ele_out;
     int d, width, col0, nc, role, rpad, tile_rows;
@@ -85,8 +87,12 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
     double n = 0.0;
     bool live = src >= 0;
     const double *xr = nullptr;
+    int xsrc = src, dsrc = src;
+    if (live && a.x_index) xsrc = a.x_index[src];
+    if (live && a.d_index) dsrc = a.d_index[src];
+    if (xsrc < 0 || dsrc < 0) live = false;
     if (live) {
-        xr = a.x + (size_t)src * a.d;
+        xr = a.x + (size_t)xsrc * a.d;
         double acc = 0.0;
         for (int k = 0; k < a.d; k++) acc += xr[k] * xr[k];
         n = sqrt(acc);
@@ -103,7 +109,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
     const double inv = 1.0 / n;
     const int row_comp = a.nc - 1;                  // plane / comp index of the a~ row
     if (a.nc == 4) {
-        const double *D = a.dxdr + (size_t)src * a.d * a.width + a.col0;
+        const double *D = a.dxdr + (size_t)dsrc * a.d * a.width + a.col0;
         double proj[3] = {0.0, 0.0, 0.0};
         for (int k = 0; k < a.d; k++) {
             double ak = xr[k] * inv;
@@ -119,7 +125,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
     }
     for (int k = 0; k < a.d; k++) a.ops[slot(row_comp, k)] = xr[k] * inv;
     for (int k = a.d; k < GPR_KPAD; k++) a.ops[slot(row_comp, k)] = 0.0;
-    a.ele_out[r] = a.ele[src];
+    a.ele_out[r] = a.ele[xsrc];
     a.norms[r] = n;
 }
 
@@ -138,7 +144,16 @@ static int upload(T **dev, const std::vector<T> &h, hipStream_t st, long long *b
 extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int width, int col0,
                               int nrows, int npts, const int *counts_host, const double *x_dev,
                               const double *dxdr_dev, const int *ele_dev, int flags) {
+    return gpr_set_create_gather(out, stream, role, d, width, col0, nrows, npts, counts_host, x_dev, dxdr_dev, ele_dev,
+                                 nullptr, nullptr, flags);
+}
+
+extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int d, int width, int col0,
+                                     int nrows, int npts, const int *counts_host, const double *x_dev,
+                                     const double *dxdr_dev, const int *ele_dev, const int *x_index_dev,
+                                     const int *dxdr_index_dev, int flags) {
     hipStream_t st = (hipStream_t)stream;
+    gpr_reap_sets();
     GPR_REQUIRE(out != nullptr, "gpr_set_create: out is null");
     *out = nullptr;
     GPR_REQUIRE(role == GPR_ROLE_STREAM || role == GPR_ROLE_RESIDENT, "gpr_set_create: bad role %d", role);
@@ -253,6 +268,7 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
     if (s->rpad > 0) {
         pack_args a;
         a.x = x_dev; a.dxdr = dxdr_dev; a.ele = ele_dev; a.src_row = d_src;
+        a.x_index = x_index_dev; a.d_index = dxdr_index_dev;
         a.ops = s->ops; a.norms = s->norms; a.ele_out = s->ele;
         a.d = d; a.width = width; a.col0 = col0; a.nc = s->nc; a.role = role;
         a.rpad = s->rpad; a.tile_rows = s->tile_rows;
@@ -272,15 +288,44 @@ extern "C" int gpr_set_create(gpr_set **out, void *stream, int role, int d, int 
     return GPR_OK;
 }
 
+// Destroyed sets whose host vectors may still feed an asynchronous upload: the device memory is released
+// in stream order at once, the host object when an event recorded at destroy time has completed (polled
+// from later create / destroy calls), so that destroying a set never blocks the host on the stream.
+namespace {
+struct dead_set { hipEvent_t ev; gpr_set *s; };
+std::mutex g_dead_mu;
+std::vector<dead_set> g_dead;
+}
+
+void gpr_reap_sets() {
+    std::lock_guard<std::mutex> lk(g_dead_mu);
+    size_t keep = 0;
+    for (size_t k = 0; k < g_dead.size(); k++) {
+        if (hipEventQuery(g_dead[k].ev) == hipErrorNotReady) { g_dead[keep++] = g_dead[k]; continue; }
+        (void)hipEventDestroy(g_dead[k].ev);
+        delete g_dead[k].s;
+    }
+    g_dead.resize(keep);
+}
+
 extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
     if (!s) return GPR_OK;
     hipStream_t st = (hipStream_t)stream;
-    (void)hipStreamSynchronize(st);   // the host vectors below may still feed an upload; kernels may still read the set
+    // stream-ordered frees: kernels already queued on `st` still see the arrays
     gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
     gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
     gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st);
     gpr_dev_free(s->ir_chunk0, st); gpr_dev_free(s->ir_pt0, st);
-    delete s;
+    s->ops = nullptr;
+    hipEvent_t ev;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_dead_mu);
+        g_dead.push_back(dead_set{ev, s});
+    } else {
+        (void)hipStreamSynchronize(st);
+        delete s;
+    }
+    gpr_reap_sets();
     return GPR_OK;
 }
 

@@ -46,7 +46,7 @@ class PackedSet:
     x[nrows, d], dxdr[nrows, d, width] or None, ele[nrows], counts[npts] follow the reference's
     `list_to_tuple` tuple (gpr_calc/utilities.py:340-390)."""
 
-    def __init__(self, role, x, dxdr, ele, counts, col0=0, flags=0):
+    def __init__(self, role, x, dxdr, ele, counts, col0=0, flags=0, x_index=None, dxdr_index=None):
         counts = np.ascontiguousarray(np.asarray(counts, dtype=np.int32))
         self.role, self.flags, self.col0 = role, flags, col0
         self.npts = int(len(counts))
@@ -54,20 +54,26 @@ class PackedSet:
         self.x = to_dev(x)
         if self.x.dim() != 2:
             raise ValueError("x must be [nrows, d]")
-        self.nrows, self.d = int(self.x.shape[0]), int(self.x.shape[1])
+        self.d = int(self.x.shape[1])
         self.ele = to_dev(ele, torch.int32).reshape(-1)
         if dxdr is not None:
             self.dxdr = to_dev(dxdr)
             self.width = int(self.dxdr.shape[-1])
         else:
             self.dxdr, self.width = None, 0
-        if int(counts.sum()) != self.nrows:
-            raise ValueError(f"counts sum to {int(counts.sum())} but there are {self.nrows} rows")
+        # optional gather (gpr_set_create_gather): packed row r reads x[x_index[r]], dxdr[dxdr_index[r]]
+        self.x_index = None if x_index is None else to_dev(x_index, torch.int32).reshape(-1)
+        self.dxdr_index = None if dxdr_index is None else to_dev(dxdr_index, torch.int32).reshape(-1)
+        idx = self.x_index if self.x_index is not None else self.dxdr_index
+        self.nrows = int(self.x.shape[0]) if idx is None else int(idx.shape[0])
+        nsum = int(counts.sum())
+        if nsum != self.nrows:
+            raise ValueError(f"counts sum to {nsum} but there are {self.nrows} rows")
         self._h = C.c_void_p()
-        check(_lib.lib().gpr_set_create(
+        check(_lib.lib().gpr_set_create_gather(
             C.byref(self._h), stream_ptr(), role, self.d, self.width, col0, self.nrows, self.npts,
-            counts.ctypes.data_as(_lib.c_int_p), ptr(self.x), ptr(self.dxdr), ptr(self.ele), flags),
-            "gpr_set_create")
+            counts.ctypes.data_as(_lib.c_int_p), ptr(self.x), ptr(self.dxdr), ptr(self.ele),
+            ptr(self.x_index), ptr(self.dxdr_index), flags), "gpr_set_create_gather")
 
     @property
     def handle(self):
@@ -91,18 +97,65 @@ class PackedSet:
 
 
 class SetPair:
-    """The same points packed in both roles (needed when a set appears on both sides of a block)."""
+    """The same points packed in both roles (a set that appears on both sides of a block needs both); each
+    role is packed on first use.  With x_index / dxdr_index the rows are gathered inside the pack kernel
+    (force points regrouped from the descriptor kernel's output, gpr_set_create_gather)."""
 
-    def __init__(self, x, dxdr, ele, counts, flags=0):
-        self.stream = PackedSet(_lib.ROLE_STREAM, x, dxdr, ele, counts, flags=flags)
-        # share the uploaded tensors
-        self.resident = PackedSet(_lib.ROLE_RESIDENT, self.stream.x, self.stream.dxdr, self.stream.ele, counts,
-                                  flags=flags)
-        self.npts, self.nrows, self.counts = self.stream.npts, self.stream.nrows, self.stream.counts
+    def __init__(self, x, dxdr, ele, counts, flags=0, x_index=None, dxdr_index=None):
+        self.flags = flags
+        self.counts = np.ascontiguousarray(np.asarray(counts, dtype=np.int32))
+        self.x = to_dev(x)
+        self.dxdr = None if dxdr is None else to_dev(dxdr)
+        self.ele = to_dev(ele, torch.int32).reshape(-1)
+        self.x_index = None if x_index is None else to_dev(x_index, torch.int32).reshape(-1)
+        self.dxdr_index = None if dxdr_index is None else to_dev(dxdr_index, torch.int32).reshape(-1)
+        idx = self.x_index if self.x_index is not None else self.dxdr_index
+        self.npts = int(len(self.counts))
+        self.nrows = int(self.x.shape[0]) if idx is None else int(idx.shape[0])
+        self._sets = {}
+        self._variants = {}
+
+    def _role(self, role):
+        s = self._sets.get(role)
+        if s is None:
+            s = self._sets[role] = PackedSet(role, self.x, self.dxdr, self.ele, self.counts, flags=self.flags,
+                                             x_index=self.x_index, dxdr_index=self.dxdr_index)
+        return s
+
+    @property
+    def stream(self):
+        return self._role(_lib.ROLE_STREAM)
+
+    @property
+    def resident(self):
+        return self._role(_lib.ROLE_RESIDENT)
+
+    def variant(self, flags):
+        """the same points under other packing flags (sharing the device tensors)"""
+        if flags == self.flags:
+            return self
+        v = self._variants.get(flags)
+        if v is None:
+            v = self._variants[flags] = SetPair(self.x, self.dxdr, self.ele, self.counts, flags=flags,
+                                                x_index=self.x_index, dxdr_index=self.dxdr_index)
+        return v
+
+    def raw_rows(self):
+        """(x, dxdr, ele) row tensors with the gather applied (materialised; fallback paths only)"""
+        x, dxdr, ele = self.x, self.dxdr, self.ele
+        if self.x_index is not None:
+            x, ele = x.index_select(0, self.x_index.long()), ele.index_select(0, self.x_index.long())
+        if dxdr is not None and self.dxdr_index is not None:
+            dxdr = dxdr.index_select(0, self.dxdr_index.long())
+        return x, dxdr, ele
 
     def close(self):
-        self.stream.close()
-        self.resident.close()
+        for s in self._sets.values():
+            s.close()
+        self._sets = {}
+        for v in self._variants.values():
+            v.close()
+        self._variants = {}
 
 
 def _view(out, nrows, ncols):

@@ -613,22 +613,33 @@ class GP():
         if mine:
             X, frees = self._batch_data_dev([strucs[k] for k in mine])
             mean, var = self._predict_dev(X, self.get_train_x(), f_tol, return_std)
-            mean = mean.cpu().numpy()
-            std = np.sqrt(var.cpu().numpy()) if return_std else None
+            if return_std:                                          # one download for both
+                both = torch.stack((mean, var)).cpu().numpy()
+                mean, std = both[0], np.sqrt(both[1])
+            else:
+                mean, std = mean.cpu().numpy(), None
+            if "force" in X and getattr(X["force"], "_nbr", None) is not None:
+                X["force"]._nbr.check()
             nS = len(mine)
             off = nS
             for s, k in enumerate(mine):
                 n, free_ids = len(strucs[k]), frees[s]
-                nf = 3 * len(free_ids)
+                nf = 3 * (n if free_ids is None else len(free_ids))
                 E = mean[s] * n
-                F = np.zeros((n, 3))
-                F[free_ids] = mean[off:off + nf].reshape(-1, 3)
+                if free_ids is None:
+                    F = mean[off:off + nf].reshape(n, 3).copy()
+                else:
+                    F = np.zeros((n, 3))
+                    F[free_ids] = mean[off:off + nf].reshape(-1, 3)
                 if self.base_potential is not None:
                     e_off, f_off, _ = self.compute_base_potential(strucs[k])
                     E, F = E + e_off, F + f_off
                 if return_std:
-                    F_std = np.zeros((n, 3))
-                    F_std[free_ids] = std[off:off + nf].reshape(-1, 3)
+                    if free_ids is None:
+                        F_std = std[off:off + nf].reshape(n, 3).copy()
+                    else:
+                        F_std = np.zeros((n, 3))
+                        F_std[free_ids] = std[off:off + nf].reshape(-1, 3)
                     results[k] = (E, F, std[s], F_std)
                 else:
                     results[k] = (E, F, None, None)
@@ -659,12 +670,9 @@ class GP():
             return {"energy": _concat_energy([dt["energy"] for dt in datas]),
                     "force": _concat_force([dt["force"] for dt in datas])}, frees
         desc = self.descriptor.calculate_batch_dev(strucs)
-        ele_atoms = desc["numbers_all"].astype(np.int32)
-        atom0, row0, seq = desc["atom0"], desc["row0"], desc["seq_all"]
+        nbr, atom0 = desc["nbr"], desc["atom0"]
         natoms = int(atom0[-1])
         nper = np.diff(atom0)
-        row_off = np.repeat(atom0[:-1], np.diff(row0))            # atom offset of the structure of every seq row
-        gi, gj = seq[:, 0] + row_off, seq[:, 1] + row_off          # global centre / moving-atom ids
         keep = np.ones(natoms, dtype=bool)
         frees = []
         for k, s in enumerate(strucs):
@@ -674,17 +682,14 @@ class GP():
                 fixset = set(int(i) for i in fix)
                 frees.append([i for i in range(int(nper[k])) if i not in fixset])
             else:
-                frees.append(list(range(int(nper[k]))))
-        order = np.argsort(gj, kind="stable")                      # rows grouped by the atom that moves
-        rows = order[keep[gj[order]]]
-        centre_host = gi[rows]
-        counts_f = np.bincount(gj, minlength=natoms)[keep]
-        row_idx = dev.to_dev(rows, torch.int64)
-        centre_idx = dev.to_dev(centre_host, torch.int64)
-        xf = desc["x"].index_select(0, centre_idx)
-        dxf = desc["dxdr"].index_select(0, row_idx)
-        E = dev.SetPair(desc["x"], None, ele_atoms, nper)
-        F = dev.SetPair(xf, dxf, ele_atoms[centre_host], counts_f)
+                frees.append(None)                                  # all atoms free
+        # force point of atom a = the seq rows (i, a) of every centre i that feels a, regrouped on the device
+        # (gpr_nbr_force_rows) and gathered inside the pack kernel: x / dxdr never leave the descriptor's layout
+        counts_f, row_index, x_index = nbr.force_rows(np.flatnonzero(keep))
+        ele = nbr.numbers_dev()
+        E = dev.SetPair(desc["x"], None, ele, nper)
+        F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index)
+        F._nbr = nbr                                                # keeps the index owner alive with the set
         return {"energy": E, "force": F}, frees
 
     def add_structure(self, data, N_max=20, tol_e_var=1.2, tol_f_var=1.2, add_force=True):

@@ -51,7 +51,7 @@ class Dot_mb(DeviceKernel):
             for key in ("energy", "force"):
                 if key in data and n_points(data[key]) > 0:
                     ent = data[key]
-                    ele = ent.stream.ele if isinstance(ent, dev.SetPair) else \
+                    ele = ent.ele if isinstance(ent, dev.SetPair) else \
                         (as_energy_tuple(ent)[1] if key == "energy" else as_force_tuple(ent)[2])
                     if isinstance(ele, torch.Tensor):
                         out.update(torch.unique(ele).cpu().tolist())

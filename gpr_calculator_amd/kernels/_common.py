@@ -16,7 +16,8 @@ def as_energy_tuple(e):
     """accept the (X, ELE, counts) tuple or a list of (x, ele) (kee_C: rbf_kernel.py:26-27), or an
     already packed device SetPair (its raw device tensors are returned)"""
     if isinstance(e, dev.SetPair):
-        return (e.stream.x, e.stream.ele, e.counts)
+        x, _, ele = e.raw_rows()
+        return (x, ele, e.counts)
     if isinstance(e, tuple) and len(e) == 3 and not isinstance(e[0], tuple):
         return e
     return list_to_tuple(list(e), mode="energy")
@@ -25,7 +26,8 @@ def as_energy_tuple(e):
 def as_force_tuple(f, stress=False):
     """accept (X, dXdR, ELE, counts) or a list / object array of (x, dxdr, ele) (kef_C: rbf_kernel.py:112-113)"""
     if isinstance(f, dev.SetPair):
-        return (f.stream.x, f.stream.dxdr, f.stream.ele, f.counts)
+        x, dxdr, ele = f.raw_rows()
+        return (x, dxdr, ele, f.counts)
     if isinstance(f, tuple) and len(f) == 4 and not isinstance(f[0], tuple):
         return f
     return list_to_tuple(list(f), stress=stress)
@@ -77,16 +79,16 @@ class DeviceKernel:
 
     # ---- packing
     def pack_energy(self, e, flags=0):
-        if isinstance(e, dev.SetPair) and e.stream.flags == flags:
-            return e
+        if isinstance(e, dev.SetPair):
+            return e.variant(flags)
         X, ELE, counts = as_energy_tuple(e)
         if isinstance(X, torch.Tensor):
             return dev.SetPair(X, None, ELE, counts, flags=flags)
         return self._cache.get(X, ("E", flags), lambda: dev.SetPair(X, None, ELE, counts, flags=flags))
 
     def pack_force(self, f, flags=0):
-        if isinstance(f, dev.SetPair) and f.stream.flags == flags:
-            return f
+        if isinstance(f, dev.SetPair):
+            return f.variant(flags)
         X, dXdR, ELE, counts = as_force_tuple(f)
         if isinstance(X, torch.Tensor):
             return dev.SetPair(X, dXdR[:, :, :3].contiguous(), ELE, counts, flags=flags)

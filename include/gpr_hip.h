@@ -80,6 +80,15 @@ enum gpr_set_flags {
 int gpr_set_create(gpr_set **out, void *stream, int role, int d, int width, int col0, int nrows,
                    int npts, const int *counts_host, const double *x_dev, const double *dxdr_dev,
                    const int *ele_dev, int flags);
+/* Same, reading the rows through index arrays (device, int32, may be NULL = identity): packed row r takes
+ * x[x_index[r]], ele[x_index[r]] and dxdr[dxdr_index[r]].  This is the force-point regrouping of
+ * gaussianprocess.py:852-870 (rows of every centre that feels atom a) done inside the pack kernel on the
+ * descriptor kernel's own output, with the index arrays of gpr_nbr_force_rows; rows whose index is
+ * negative are dropped like zero-norm rows. */
+int gpr_set_create_gather(gpr_set **out, void *stream, int role, int d, int width, int col0, int nrows,
+                          int npts, const int *counts_host, const double *x_dev, const double *dxdr_dev,
+                          const int *ele_dev, const int *x_index_dev, const int *dxdr_index_dev, int flags);
+/* Never blocks: device memory is released in stream order, host bookkeeping once the stream has passed. */
 int gpr_set_destroy(gpr_set *set, void *stream);
 /* introspection (tests, DESIGN.md numbers): padded rows and bytes held on the device */
 int gpr_set_info(const gpr_set *set, int *npts, int *nrows, int *rows_padded, long long *bytes);
@@ -160,6 +169,27 @@ int gpr_nbr_sizes(const gpr_nbr *nb, int *npairs, int *nrows);
 int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *centre_pair0, int *centre_row0,
                    int *row_pair0, int *self_row, int *seq, int *struct_row0);
 int gpr_nbr_destroy(gpr_nbr *nb);
+/* Device builder: same inputs (host arrays) and the same pairs / rows in the same order, but the search
+ * runs on the GPU (one wavefront per centre atom) and the results stay in HBM.  Synchronises the stream
+ * once (the pair / row totals size every later allocation).  gpr_nbr_sizes works on the handle;
+ * gpr_nbr_export downloads (debug / single-structure path; centre_row0 and struct_row0 are always on the
+ * host); gpr_nbr_destroy releases the device arrays in stream order. */
+int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                         const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on);
+/* device pointers of a device-built handle, in the layouts of gpr_nbr_export (any pointer may be NULL) */
+int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
+                          const int **centre_row0, const int **row_pair0, const int **self_row,
+                          const int **seq, const int **numbers);
+/* Force points on the device (gaussianprocess.py:852-870): point p is moving atom atoms[p] (global id);
+ * its rows are the seq rows (i, a) of every centre i that has a as a neighbour, ascending in i.  By the
+ * symmetry of the neighbour relation their number equals the row count of centre a, so the caller knows
+ * pt_row0[npts+1] (exclusive prefix of those counts, device) from the host copy of centre_row0.
+ * Outputs (device, int32, nrows = pt_row0[npts]): row_index = seq row of (i, a) (index into dxdr),
+ * x_index = global id of i (index into x / numbers). */
+int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const int *pt_row0_dev, int nrows,
+                       int *row_index_dev, int *x_index_dev);
+/* number of (i, a) rows gpr_nbr_force_rows could not find (0 unless the symmetry above is broken); synchronises */
+int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
 
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
 /* x[ncentres, d] and dxdr[nrows, d, 3] (d = nmax(nmax+1)/2 (lmax+1)) from neighbour pairs grouped by
