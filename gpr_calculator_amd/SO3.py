@@ -336,8 +336,8 @@ class NeighborBatch:
         self.ptrs = dict(zip(names, raw))
 
     def force_rows(self, atoms):
-        """(counts, row_index, x_index) of the force points of the moving atoms `atoms` (global ids):
-        device int32 index arrays into dxdr rows / x rows (gpr_nbr_force_rows)"""
+        """(counts, row_index, x_index, pt_row0) of the force points of the moving atoms `atoms` (global ids):
+        device int32 index arrays into dxdr rows / x rows and the point row offsets (gpr_nbr_force_rows)"""
         atoms = np.ascontiguousarray(atoms, dtype=np.int32)
         counts = (self.centre_row0[1:] - self.centre_row0[:-1])[atoms]
         meta = np.empty(2 * len(atoms) + 1, dtype=np.int32)        # [atoms | pt_row0] in one upload
@@ -350,7 +350,7 @@ class NeighborBatch:
         dev.check(_lib.lib().gpr_nbr_force_rows(self._h, len(atoms), dev.ptr(d_meta),
                                                 C.c_void_p(d_meta.data_ptr() + 4 * len(atoms)), nrows,
                                                 dev.ptr(idx[0]), dev.ptr(idx[1])), "gpr_nbr_force_rows")
-        return counts, idx[0, :nrows], idx[1, :nrows]
+        return counts, idx[0, :nrows], idx[1, :nrows], d_meta[len(atoms):]
 
     def numbers_dev(self):
         """int32 device view of the atomic numbers is not exposed as a tensor; upload the host copy"""

@@ -10,6 +10,7 @@
 // i.e. K = sigma^2 Psi Psi'^T with rows  Psi_E = [Phi, sigma0 f],  Psi_F = [-S, 0]:  the N x N assembly becomes
 // one FP64 MFMA GEMM with inner dimension 466 * n_species instead of a sum over all row pairs.  (Identities:
 // d^2 = vech(a~a~^T).vech(b~b~^T);  2 d (a~.B'_q) = vech(a~a~^T).S[q];  d G_pq + w_p z_q = (1/2) S[p].S[q].)
+#include <algorithm>
 #include "gpr_internal.h"
 
 namespace {
@@ -88,6 +89,203 @@ __global__ void __launch_bounds__(576) dot2_features_kernel(feat_args A) {
     }
 }
 
+
+// ---------------------------------------------------------------- direct variant (prediction path)
+// Same Psi rows, computed straight from the descriptor kernel's x / dxdr (rows addressed through the index
+// arrays of gpr_nbr_force_rows) without a packed set, plus the prior variance k(x*, x*) of every predicted
+// quantity in the convention of the reference's numpy helpers (Dot_mb.py:45-85, 177-258: norm + 1e-8, rows
+// never skipped):  force point  diag[3p+q] = sigma^2 |Psi_eps[p, q]|^2  (the identity of the header applied to
+// the eps-normalised rows; a~_eps = s a~, A'_eps = s (D/n - s^2 a~ proj), s = n / (n + 1e-8));  energy points
+// go through dot2_diag_ee_direct_kernel (their cosine carries a second eps and is not an inner product).
+struct dfeat_args {
+    const double *x, *dxdr; const int *ele;
+    const int *pt_row0, *x_index, *d_index;
+    int npts, nc, d, npair, ns;
+    int species[FEAT_MAX_SPECIES];
+    double sigma0, sigma2;
+    double *out; long long ld;
+    double *diag;
+};
+
+constexpr int DF_ROWS = 32;      // rows staged per pass (16 lanes per row: the first 512 threads stage)
+constexpr int DF_LD = 33;        // padded row stride of the staged operands (doubles)
+
+__global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A) {
+    __shared__ double sA[DF_ROWS * DF_LD];            // a~ (native norm)
+    __shared__ double sD[3][DF_ROWS * DF_LD];         // D / n per component
+    __shared__ double sP[DF_ROWS][4];                 // proj[3], s
+    __shared__ int sE[DF_ROWS];                       // species code, INT_MIN for rows that do not exist
+    __shared__ int sLive[DF_ROWS];                    // native convention: norm > 1e-8
+    __shared__ double sRed[9][3];
+    const int p = blockIdx.x, tid = threadIdx.x, e = tid;
+    const bool act = e < A.npair;
+    int k = 0, m = 0;
+    if (act) { while ((k + 1) * (k + 2) / 2 <= e) k++; m = e - k * (k + 1) / 2; }
+    const double wgt = (k == m) ? 1.0 : 1.4142135623730951;
+    double acc[FEAT_MAX_SPECIES][3], ace[FEAT_MAX_SPECIES][3], cnt[FEAT_MAX_SPECIES];
+#pragma unroll
+    for (int s = 0; s < FEAT_MAX_SPECIES; s++) {
+        cnt[s] = 0.0;
+        acc[s][0] = acc[s][1] = acc[s][2] = 0.0; ace[s][0] = ace[s][1] = ace[s][2] = 0.0;
+    }
+    const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
+    const int slot = tid >> 4, g = tid & 15;          // staging: 16 lanes per row
+    for (int rb = r0; rb < r1; rb += DF_ROWS) {
+        __syncthreads();
+        {
+            const int r = rb + slot;
+            const bool stager = slot < DF_ROWS;
+            const bool have = stager && r < r1;
+            int xs = -1, ds = -1;
+            if (have) {
+                xs = A.x_index ? A.x_index[r] : r;
+                ds = A.d_index ? A.d_index[r] : r;
+            }
+            const bool ok = have && xs >= 0 && (A.nc == 1 || ds >= 0);
+            double x0 = 0.0, x1 = 0.0;
+            if (ok) {
+                const double *xr = A.x + (size_t)xs * A.d;
+                if (g < A.d) x0 = xr[g];
+                if (g + 16 < A.d) x1 = xr[g + 16];
+            }
+            double ss = x0 * x0 + x1 * x1;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 16);
+            const double n = sqrt(ss);
+            const bool live = ok && n > 1e-8;          // rbf_kernel.cpp:26,37 / dot_kernel.cpp skip
+            const double inv = n > 0.0 ? 1.0 / n : 0.0;
+            if (stager) {
+                sA[slot * DF_LD + g] = x0 * inv;
+                sA[slot * DF_LD + g + 16] = x1 * inv;
+            }
+            if (A.nc == 4) {
+                double pr[3] = {0.0, 0.0, 0.0};
+                double dv[6];
+                const double *D = ok ? A.dxdr + (size_t)ds * A.d * 3 : nullptr;
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int el = g + 16 * u;
+                    dv[u] = (ok && el < 3 * A.d) ? D[el] * inv : 0.0;
+                }
+                // a~_k of the element's k: lanes hold k = g and g + 16; fetch through the group
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                    const double alo = __shfl(x0 * inv, kk & 15, 16), ahi = __shfl(x1 * inv, kk & 15, 16);
+                    const double ak = (kk < 16) ? alo : ahi;
+                    const double t = (el < 3 * A.d) ? ak * dv[u] : 0.0;
+                    pr[0] += (c == 0) ? t : 0.0; pr[1] += (c == 1) ? t : 0.0; pr[2] += (c == 2) ? t : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+#pragma unroll
+                    for (int o = 8; o >= 1; o >>= 1) pr[c] += __shfl_xor(pr[c], o, 16);
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                    if (stager && kk < 32) sD[c][slot * DF_LD + kk] = dv[u];
+                }
+                if (stager && g < 3) sP[slot][g] = pr[g];
+            }
+            if (stager && g == 0) {
+                sP[slot][3] = n / (n + 1e-8);
+                sE[slot] = ok ? A.ele[xs] : INT_MIN;
+                sLive[slot] = live ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (!act) continue;
+        const int nr = min(DF_ROWS, r1 - rb);
+        for (int r = 0; r < nr; r++) {
+            const int el = sE[r];
+            if (el == INT_MIN) continue;
+            const double ak = sA[r * DF_LD + k], am = sA[r * DF_LD + m], sc = sP[r][3], s2 = sc * sc;
+            const double live = sLive[r] ? 1.0 : 0.0;
+            double v[3] = {0.0, 0.0, 0.0}, ve[3] = {0.0, 0.0, 0.0};
+            if (A.nc == 4) {
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const double dk = sD[q][r * DF_LD + k], dm = sD[q][r * DF_LD + m], pq = sP[r][q];
+                    v[q] = live * wgt * (ak * (dm - am * pq) + am * (dk - ak * pq));
+                    ve[q] = wgt * s2 * (ak * (dm - s2 * am * pq) + am * (dk - s2 * ak * pq));
+                }
+            } else {
+                v[0] = live * wgt * ak * am;
+            }
+#pragma unroll
+            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
+                if (s < A.ns && el == A.species[s]) {
+                    acc[s][0] += v[0]; acc[s][1] += v[1]; acc[s][2] += v[2];
+                    ace[s][0] += ve[0]; ace[s][1] += ve[1]; ace[s][2] += ve[2];
+                    cnt[s] += live;
+                }
+        }
+    }
+    const int nq = (A.nc == 4) ? 3 : 1;
+    const int npt_rows = r1 - r0;
+    const double inv_cnt = npt_rows > 0 ? 1.0 / npt_rows : 0.0;
+    if (act) {
+        const double scale = (A.nc == 4) ? -1.0 : inv_cnt;
+        for (int q = 0; q < nq; q++) {
+            double *o = A.out + (long long)(p * nq + q) * A.ld;
+#pragma unroll
+            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
+                if (s < A.ns) {
+                    o[s * A.npair + e] = scale * acc[s][q];
+                    if (e == 0) o[A.ns * A.npair + s] = (A.nc == 4) ? 0.0 : A.sigma0 * cnt[s] * inv_cnt;
+                }
+        }
+    }
+    if (A.nc == 4 && A.diag) {                       // sigma^2 |Psi_eps|^2, fixed-order block reduction
+        double dq[3] = {0.0, 0.0, 0.0};
+        if (act)
+#pragma unroll
+            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
+                if (s < A.ns)
+#pragma unroll
+                    for (int q = 0; q < 3; q++) dq[q] += ace[s][q] * ace[s][q];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) dq[q] += __shfl_xor(dq[q], o);
+        __syncthreads();
+        if ((tid & 63) == 0) { sRed[tid >> 6][0] = dq[0]; sRed[tid >> 6][1] = dq[1]; sRed[tid >> 6][2] = dq[2]; }
+        __syncthreads();
+        if (tid < 3) {
+            double t = 0.0;
+            for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sRed[w][tid];
+            A.diag[3 * (size_t)p + tid] = A.sigma2 * t;
+        }
+    }
+}
+
+// prior variance of energy points, numpy-helper convention (Dot_mb.py:177-202): rows of one point against each
+// other, same species only, cosine = x.x' / (1e-8 + (|x| + 1e-8)(|x'| + 1e-8)), mean of sigma^2 (cos^2 + sigma0^2)
+__global__ void __launch_bounds__(256) dot2_diag_ee_direct_kernel(dfeat_args A) {
+    __shared__ double sRed[4];
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1], n = r1 - r0;
+    double part = 0.0;
+    for (long long t = tid; t < (long long)n * n; t += blockDim.x) {
+        const int i = (int)(t / n), j = (int)(t - (long long)i * n);
+        const int xi = A.x_index ? A.x_index[r0 + i] : r0 + i, xj = A.x_index ? A.x_index[r0 + j] : r0 + j;
+        if (A.ele[xi] != A.ele[xj]) continue;
+        const double *a = A.x + (size_t)xi * A.d, *b = A.x + (size_t)xj * A.d;
+        double s = 0.0, na = 0.0, nb = 0.0;
+        for (int q = 0; q < A.d; q++) { s += a[q] * b[q]; na += a[q] * a[q]; nb += b[q] * b[q]; }
+        const double c = s / (1e-8 + (sqrt(na) + 1e-8) * (sqrt(nb) + 1e-8));
+        part += c * c + A.sigma0 * A.sigma0;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if ((tid & 63) == 0) sRed[tid >> 6] = part;
+    __syncthreads();
+    if (tid == 0) {
+        const double tot = sRed[0] + sRed[1] + sRed[2] + sRed[3];
+        A.diag[p] = n > 0 ? A.sigma2 * tot / ((double)n * (double)n) : 0.0;
+    }
+}
+
 }  // namespace
 
 // Psi rows of the points of a STREAM-packed set: energy set -> out[npts, F]; force set -> out[3*npts, F]
@@ -115,5 +313,36 @@ extern "C" int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("dot2_features launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}
+
+// Direct variant for prediction: Psi rows and prior variances of points given as row ranges pt_row0[npts+1]
+// (device) over index arrays into the descriptor kernel's outputs.  width = 0: energy points (rows r read
+// x[x_index[r]]; psi[npts, F], diag[npts]); width = 3: force points (rows read x[x_index[r]], dxdr[dxdr_index[r]];
+// psi[3 npts, F], diag[3 npts]).  Index arrays may be NULL (identity); diag may be NULL.  d <= 32.
+extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int *pt_row0_dev,
+                                        const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev,
+                                        const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
+                                        double sigma, double sigma0, double *psi, long long ld, double *diag) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(width == 0 || width == 3, "gpr_dot2_features_direct: width must be 0 or 3 (got %d)", width);
+    GPR_REQUIRE(d >= 1 && d <= GPR_KPAD, "gpr_dot2_features_direct: d=%d unsupported (1..%d)", d, GPR_KPAD);
+    GPR_REQUIRE(ns >= 1 && ns <= FEAT_MAX_SPECIES, "gpr_dot2_features_direct: 1..%d species supported (got %d)", FEAT_MAX_SPECIES, ns);
+    const int npair = d * (d + 1) / 2, F = ns * (npair + 1);
+    GPR_REQUIRE(psi && ld >= F, "gpr_dot2_features_direct: output leading dimension %lld < %d", ld, F);
+    if (npts <= 0) return GPR_OK;
+    GPR_REQUIRE(pt_row0_dev && x_dev && ele_dev && (width == 0 || dxdr_dev), "gpr_dot2_features_direct: null device pointer");
+    dfeat_args A;
+    A.x = x_dev; A.dxdr = dxdr_dev; A.ele = ele_dev; A.pt_row0 = pt_row0_dev; A.x_index = x_index_dev; A.d_index = dxdr_index_dev;
+    A.npts = npts; A.nc = width ? 4 : 1; A.d = d; A.npair = npair; A.ns = ns;
+    for (int s = 0; s < FEAT_MAX_SPECIES; s++) A.species[s] = s < ns ? species_host[s] : 0;
+    A.sigma0 = sigma0; A.sigma2 = sigma * sigma; A.out = psi; A.ld = ld; A.diag = diag;
+    const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
+    const int threads = std::max(512, ((npair + 63) / 64) * 64);
+    hipLaunchKernelGGL(dot2_features_direct_kernel, dim3(npts), dim3(threads), 0, st, A);
+    if (width == 0 && diag) hipLaunchKernelGGL(dot2_diag_ee_direct_kernel, dim3(npts), dim3(256), 0, st, A);
+    gpr_prof_end(st, pid);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("dot2_features_direct launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
     return GPR_OK;
 }

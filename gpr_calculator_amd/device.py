@@ -11,9 +11,18 @@ from ._lib import KernelParams, check
 F64 = torch.float64
 
 
+_DEVICES = {}
+
+
 def device():
-    _lib.require_gpu()
-    return torch.device("cuda", torch.cuda.current_device())
+    """current HIP device (raises when there is none: the package computes on the GPU only)"""
+    if not _DEVICES:
+        _lib.require_gpu()
+    idx = torch.cuda.current_device()
+    d = _DEVICES.get(idx)
+    if d is None:
+        d = _DEVICES[idx] = torch.device("cuda", idx)
+    return d
 
 
 def stream_ptr():
@@ -23,6 +32,8 @@ def stream_ptr():
 def to_dev(a, dtype=F64):
     """numpy / tensor -> contiguous device tensor of dtype"""
     if isinstance(a, torch.Tensor):
+        if a.is_cuda and a.dtype == dtype and a.is_contiguous():
+            return a
         return a.to(device=device(), dtype=dtype).contiguous()
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device())
 
@@ -129,6 +140,14 @@ class SetPair:
     @property
     def resident(self):
         return self._role(_lib.ROLE_RESIDENT)
+
+    def row0_dev(self):
+        """exclusive prefix of the per-point row counts, int32 [npts + 1] on the device"""
+        if getattr(self, "_row0_dev", None) is None:
+            r0 = np.zeros(self.npts + 1, dtype=np.int32)
+            np.cumsum(self.counts, out=r0[1:])
+            self._row0_dev = to_dev(r0, torch.int32)
+        return self._row0_dev
 
     def variant(self, flags):
         """the same points under other packing flags (sharing the device tensors)"""
@@ -320,6 +339,26 @@ def dot2_features(pset, species, sigma0, out=None):
     check(_lib.lib().gpr_dot2_features(stream_ptr(), pset.handle, ns, species.ctypes.data_as(_lib.c_int_p),
                                        float(sigma0), ptr(out), max(int(out.stride(0)), F)), "gpr_dot2_features")
     return out
+
+
+def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True):
+    """(Psi rows, prior variances) of the points of an unpacked SetPair straight from its row tensors and
+    index arrays (gpr_dot2_features_direct): [npts, F] / [npts] for energies, [3 npts, F] / [3 npts] for forces"""
+    species = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
+    ns = len(species)
+    d = int(pair.x.shape[1])
+    width = 0 if pair.dxdr is None else 3
+    if width and int(pair.dxdr.shape[-1]) != 3:
+        raise ValueError("direct features take dxdr[rows, d, 3]")
+    F = ns * (d * (d + 1) // 2 + 1)
+    rows = pair.npts * (3 if width else 1)
+    psi = torch.empty((rows, F), dtype=F64, device=device())
+    diag = torch.empty(rows, dtype=F64, device=device()) if want_diag else None
+    check(_lib.lib().gpr_dot2_features_direct(
+        stream_ptr(), d, width, pair.npts, ptr(pair.row0_dev()), ptr(pair.x_index), ptr(pair.dxdr_index),
+        ptr(pair.x), ptr(pair.dxdr), ptr(pair.ele), ns, species.ctypes.data_as(_lib.c_int_p), float(sigma),
+        float(sigma0), ptr(psi), F, ptr(diag)), "gpr_dot2_features_direct")
+    return psi, diag
 
 
 def rowdot(a, b):

@@ -277,6 +277,17 @@ class GP():
         K(train, X) = K_trans^T is built directly (structures streamed, training set resident)."""
         ws = self._weight_space()
         Kt = None
+        if ws is not None and self.weight_space_mean and hasattr(self.kernel, "psi_diag_dev"):
+            # Dot kernel at zeta = 2, batch form: features and prior variances straight from the descriptor
+            # output; mean = Psi* w, var = diag - rowsum((Psi* M) o Psi*)
+            pd = self.kernel.psi_diag_dev(X, ws[0], want_diag=return_std)
+            if pd is not None:
+                P, diag = pd
+                mean = dev.gemm(P, ws[2]).reshape(-1)
+                if not return_std:
+                    return mean, None
+                var = diag - dev.rowdot(dev.gemm(P, ws[1]), P)
+                return mean, torch.clamp_min(var, 0.0)
         if ws is not None and self.weight_space_mean:
             # Dot kernel at zeta = 2: K_trans alpha = Psi* (sigma^2 Psi^T alpha) = Psi* w, w built once per fit
             mean = dev.gemm(self.kernel._psi(X, ws[0]), ws[2]).reshape(-1)
@@ -685,10 +696,11 @@ class GP():
                 frees.append(None)                                  # all atoms free
         # force point of atom a = the seq rows (i, a) of every centre i that feels a, regrouped on the device
         # (gpr_nbr_force_rows) and gathered inside the pack kernel: x / dxdr never leave the descriptor's layout
-        counts_f, row_index, x_index = nbr.force_rows(np.flatnonzero(keep))
+        counts_f, row_index, x_index, f_row0 = nbr.force_rows(np.flatnonzero(keep))
         ele = nbr.numbers_dev()
         E = dev.SetPair(desc["x"], None, ele, nper)
         F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index)
+        F._row0_dev = f_row0
         F._nbr = nbr                                                # keeps the index owner alive with the set
         return {"energy": E, "force": F}, frees
 

@@ -76,6 +76,28 @@ class Dot_mb(DeviceKernel):
             parts.append(pair._psi)
         return parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
 
+    def psi_diag_dev(self, data, species, want_diag=True):
+        """(Psi, diag) of a data dictionary whose entries are unpacked device SetPairs (the batch-prediction
+        form): features and prior variances in one pass over the descriptor output, no packed sets
+        (csrc/features.hip, gpr_dot2_features_direct).  None when an entry is not in that form."""
+        parts, diags = [], []
+        for key in ("energy", "force"):
+            if key in data and n_points(data[key]) > 0:
+                ent = data[key]
+                if not isinstance(ent, dev.SetPair) or ent.flags != 0:
+                    return None
+                if ent.dxdr is not None and int(ent.dxdr.shape[-1]) != 3:
+                    return None
+                psi, dg = dev.dot2_features_direct(ent, species, self.sigma, self.sigma0 if key == "energy" else 0.0,
+                                                   want_diag)
+                parts.append(psi); diags.append(dg)
+        if not parts:
+            return None
+        P = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
+        if not want_diag:
+            return P, None
+        return P, (diags[0] if len(diags) == 1 else torch.cat(diags))
+
     def _feature_path(self, data1, data2, zeta_ee):
         if not self.use_feature_map or float(zeta_ee) != 2.0:
             return None

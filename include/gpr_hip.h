@@ -135,6 +135,16 @@ int gpr_diag_ee(void *stream, const gpr_kernel_params *kp, const gpr_set *set1,
  * atomic numbers that receive a feature block. */
 int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const int *species_host, double sigma0,
                       double *out, long long ld);
+/* Direct variant for the prediction path: the same Psi rows computed straight from the descriptor kernel's
+ * x / dxdr, rows addressed through point ranges pt_row0[npts+1] (device) and the optional index arrays of
+ * gpr_nbr_force_rows (NULL = identity), with no packed set; plus (diag != NULL) the prior variance
+ * k(x*, x*) of every predicted quantity in the numpy-helper convention of Dot_mb.diag (Dot_mb.py:45-85,
+ * 177-258).  width = 0: energy points, psi[npts, F], diag[npts]; width = 3: force points, psi[3 npts, F],
+ * diag[3 npts]. */
+int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int *pt_row0_dev,
+                             const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev,
+                             const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
+                             double sigma, double sigma0, double *psi, long long ld, double *diag);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;

@@ -106,6 +106,7 @@ def test_fit_predict_structure_matches_oracle(kind, port_natives):
 
     # batched predict of several structures equals the one-by-one path
     batch = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(3)]
+    batch[1].fixed = np.array([0, 3])
     Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True, f_tol=1e-8)
     for k, s in enumerate(batch):
         e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True, f_tol=1e-8)
@@ -162,3 +163,26 @@ def test_add_structure_queue_semantics():
     assert np.isfinite(E) and np.isfinite(F).all()
     gp.fit(show=False, opt=False)
     assert gp.alpha_.shape[0] > n_before
+
+
+def test_dot_direct_features_match_packed_features_and_diag():
+    """gpr_dot2_features_direct (prediction path: no packed sets) against gpr_dot2_features on packed sets and
+    the pair-sum diag kernels, on a two-species batch with fixed atoms"""
+    import torch
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell
+    kern = Dot_mb(para=[1.7, 0.9], zeta=2.0)
+    gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0), log_file="/tmp/gpr_test.log")
+    batch = [fcc_cell(seed=s, species=(46, 78) if s % 2 else (46,)) for s in range(4)]
+    batch[2].fixed = np.array([1, 5, 6])
+    X, frees = gp._batch_data_dev(batch)
+    species = (46, 78)
+    P_direct, diag_direct = kern.psi_diag_dev(X, species, want_diag=True)
+    P_packed = kern._psi(X, species)
+    diag_packed = kern.diag_dev(X)
+    scale = float(P_packed.abs().max())
+    assert float((P_direct - P_packed).abs().max()) < 1e-13 * scale
+    assert float((diag_direct - diag_packed).abs().max()) < 1e-12 * float(diag_packed.abs().max())
+    assert frees[0] is None and len(frees[2]) == len(batch[2]) - 3

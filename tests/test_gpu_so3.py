@@ -75,7 +75,7 @@ def test_device_neighbour_build_is_identical_to_host_build():
     row_off = np.repeat(atom0[:-1], np.diff(row0))
     gi, gj = seq[:, 0] + row_off, seq[:, 1] + row_off
     atoms = np.array([a for a in range(int(atom0[-1])) if a % 3 != 1])
-    counts, row_index, x_index = nbr.force_rows(atoms)
+    counts, row_index, x_index, _ = nbr.force_rows(atoms)
     nbr.check()
     row_index, x_index = row_index.cpu().numpy(), x_index.cpu().numpy()
     off = 0
