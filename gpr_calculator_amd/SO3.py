@@ -242,7 +242,7 @@ class SO3:
         """device-resident neighbour pairs / seq rows of a batch (gpr_nbr_build_device); NeighborBatch"""
         return NeighborBatch(strucs, float(self.rcut), bool(self.weight_on))
 
-    def calculate_batch_dev(self, strucs, host_index=False):
+    def calculate_batch_dev(self, strucs, host_index=False, nbr=None):
         """Descriptors of several structures in one launch.  Returns a dict of device tensors
         x [sum n, d], dxdr [sum S, d, 3] plus `nbr` (the NeighborBatch the rows refer to) and the host
         offsets atom0 / row0 / numbers_all.  With host_index=True the neighbour search runs on the host
@@ -263,7 +263,8 @@ class SO3:
             ptrs = [dev.ptr(a) for a in keep]
             nbr = None
         else:
-            nbr = self.neighbor_batch_dev(strucs)
+            if nbr is None:
+                nbr = self.neighbor_batch_dev(strucs)
             atom0, row0, numbers = nbr.atom0, nbr.row0, nbr.numbers
             nc, P, S = nbr.natoms, nbr.P, nbr.S
             ptrs = [nbr.ptrs[k] for k in ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row")]

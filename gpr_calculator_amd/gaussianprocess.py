@@ -680,8 +680,10 @@ class GP():
                 datas.append(data); frees.append(free_ids)
             return {"energy": _concat_energy([dt["energy"] for dt in datas]),
                     "force": _concat_force([dt["force"] for dt in datas])}, frees
-        desc = self.descriptor.calculate_batch_dev(strucs)
-        nbr, atom0 = desc["nbr"], desc["atom0"]
+        # order matters for the host: every upload happens before the descriptor kernel is queued (a pageable
+        # upload waits for the work already on the stream)
+        nbr = self.descriptor.neighbor_batch_dev(strucs)
+        atom0 = nbr.atom0
         natoms = int(atom0[-1])
         nper = np.diff(atom0)
         keep = np.ones(natoms, dtype=bool)
@@ -695,10 +697,14 @@ class GP():
             else:
                 frees.append(None)                                  # all atoms free
         # force point of atom a = the seq rows (i, a) of every centre i that feels a, regrouped on the device
-        # (gpr_nbr_force_rows) and gathered inside the pack kernel: x / dxdr never leave the descriptor's layout
+        # (gpr_nbr_force_rows) and gathered inside the consumer kernels: x / dxdr never leave the descriptor's layout
         counts_f, row_index, x_index, f_row0 = nbr.force_rows(np.flatnonzero(keep))
-        ele = nbr.numbers_dev()
+        meta = np.concatenate((atom0, nbr.numbers)).astype(np.int32)
+        d_meta = dev.to_dev(meta, torch.int32)
+        e_row0, ele = d_meta[:len(atom0)], d_meta[len(atom0):]
+        desc = self.descriptor.calculate_batch_dev(strucs, nbr=nbr)
         E = dev.SetPair(desc["x"], None, ele, nper)
+        E._row0_dev = e_row0
         F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index)
         F._row0_dev = f_row0
         F._nbr = nbr                                                # keeps the index owner alive with the set
