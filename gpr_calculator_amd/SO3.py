@@ -174,11 +174,34 @@ class SO3:
         return self.nmax * (self.nmax + 1) // 2 * (self.lmax + 1)
 
     # ------------------------------------------------------------------ host bookkeeping
+    NCHEB = 16      # Chebyshev coefficients per segment of the radial table
+
     def _device_tables(self):
+        """(table, nseg, ncheb): radial Chebyshev table + angular constants on the device (gpr_so3_tables), built
+        once per (nmax, lmax, rcut, alpha) from the reference's quadrature table G, rq"""
         if self._tables is None:
             rq, G = radial_table(self.nmax, self.lmax, float(self.rcut), float(self.alpha))
-            self._tables = (dev.to_dev(rq), dev.to_dev(G), len(rq))
+            nseg = max(8, int(np.ceil(1.2 * float(self.rcut) * np.sqrt(float(self.alpha)))))
+            L = _lib.lib()
+            size = int(L.gpr_so3_table_size(self.nmax, self.lmax, nseg, self.NCHEB))
+            table = torch.empty(size, dtype=dev.F64, device=dev.device())
+            d_rq, d_G = dev.to_dev(rq), dev.to_dev(G)
+            dev.check(L.gpr_so3_tables(dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha),
+                                       len(rq), dev.ptr(d_G), dev.ptr(d_rq), nseg, self.NCHEB, dev.ptr(table)),
+                      "gpr_so3_tables")
+            self._tables = (table, nseg, self.NCHEB, d_G, d_rq)
         return self._tables
+
+    def radial_functions(self, r, mode="table"):
+        """F0_nl(r), F1_nl(r) [len(r), nmax, lmax+1, 2] from the device table or the direct quadrature"""
+        table, nseg, ncheb, d_G, d_rq = self._device_tables()
+        rs = dev.to_dev(np.asarray(r, dtype=np.float64))
+        out = torch.empty((len(rs), self.nmax, self.lmax + 1, 2), dtype=dev.F64, device=dev.device())
+        dev.check(_lib.lib().gpr_so3_radial(dev.stream_ptr(), 1 if mode == "table" else 0, self.nmax, self.lmax,
+                                            float(self.rcut), float(self.alpha), int(d_rq.shape[0]), dev.ptr(d_G),
+                                            dev.ptr(d_rq), nseg, ncheb, dev.ptr(table), len(rs), dev.ptr(rs),
+                                            dev.ptr(out)), "gpr_so3_radial")
+        return out.cpu().numpy()
 
     def neighbor_index(self, atoms, atom_ids=None):
         """pairs, `seq` and the pair/row maps of one structure (the bookkeeping of
@@ -249,10 +272,9 @@ class SO3:
         (gpr_nbr_build) and the per-structure `seq` lists are returned as numpy arrays as well."""
         if not self.derivative:
             raise NotImplementedError("derivative=False is not used on the GPR hot path")
-        rq, G, nq = self._device_tables()
+        table, nseg, ncheb = self._device_tables()[:3]
         D = dev.device()
         d = self.ncoefs
-        nlm = self.nmax * (self.lmax + 1) * (2 * self.lmax + 1)
         if host_index:
             nb = self.neighbor_index_batch(strucs)
             atom0, row0, numbers = nb["atom0"], nb["row0"], nb["numbers"]
@@ -270,10 +292,9 @@ class SO3:
             ptrs = [nbr.ptrs[k] for k in ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row")]
         x = torch.empty((nc, d), dtype=dev.F64, device=D)
         dxdr = torch.empty((S, d, 3), dtype=dev.F64, device=D)
-        scratch = torch.empty((max(P, 1) * nlm * 3, 2), dtype=dev.F64, device=D)
         dev.check(_lib.lib().gpr_so3_power_spectrum(
-            dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nq, dev.ptr(G), dev.ptr(rq),
-            nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr), dev.ptr(scratch)), "gpr_so3_power_spectrum")
+            dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nseg, ncheb, dev.ptr(table),
+            nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr)), "gpr_so3_power_spectrum")
         out = dict(x=x, dxdr=dxdr, atom0=atom0, row0=row0, numbers_all=numbers, nbr=nbr,
                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))])
         if host_index:

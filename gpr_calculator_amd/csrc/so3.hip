@@ -5,12 +5,24 @@
 // the per-centre assembly loop of SO3.calculate (:243-273: c_tot, power spectrum P, dP per neighbour
 // pair, scatter into the (i, j) rows of `seq`, self row = -sum of the others).
 //
-// One 256-thread workgroup per centre atom.  Phase 1: each wavefront takes neighbour pairs of the
-// centre in turn -- lanes over quadrature nodes for the radial integrals, over m for the Legendre
-// recurrences, over (n, l, m) for the expansion coefficients -- stores dC of the pair in a global
-// scratch and accumulates c_tot in wavefront-private LDS.  Phase 2: the four partial c_tot are summed
-// in a fixed order, lanes over coefficients emit x_i, and one wavefront per seq row contracts the
-// stored dC with conj(c_tot).  No atomics; the summation order is fixed.
+// Radial part.  For a neighbour at distance r the reference integrates, per (n, l),
+//     I_nl(r) = sum_q G[n][q] i_l(2 alpha r r_q)          (80-node quadrature, SO3.py:623-655)
+// and only ever uses F0_nl(r) = 4 pi exp(-alpha r^2) I_nl(r) and its derivative F1_nl = dF0_nl/dr.  Both are
+// smooth functions of the single scalar r, so gpr_so3_tables evaluates that same quadrature once, at
+// Chebyshev nodes of `nseg` equal segments of [0, rcut] (Bessel functions by Miller's recurrence, below), and
+// stores piecewise Chebyshev coefficients; the descriptor kernel then evaluates 2 nmax (lmax+1) short Clenshaw
+// sums per pair instead of 80 Bessel tables.  The interpolation error (8 segments x 16 coefficients at
+// alpha = 2, rcut = 5) is 5e-15 of each function's scale -- below the rounding of the quadrature itself; it is
+// measured against the direct quadrature in tests/test_gpu_so3.py.
+//
+// Angular part and assembly.  With A_nl = norm_l w (fc F1 + fc' F0), B_nl = norm_l w fc F0 the pair's
+// coefficients are c_nlm = B_nl Y_lm and dc_nlm/dr_k = A_nl Y_lm u_k + B_nl (grad Y_lm)_k, so the derivative of
+// the power spectrum row needs only the 15 + 45 real numbers
+//     R_nl = sum_m Re[Y_lm conj(ctot_nlm)],   S_nlk = sum_m Re[(grad Y_lm)_k conj(ctot_nlm)]:
+//     dP[(n1,n2,l), k] = u_k (A_n1l R_n2l + A_n2l R_n1l) + B_n1l S_n2lk + B_n2l S_n1lk
+// and dC itself is never formed.  One 256-thread workgroup per centre atom: pass 1 accumulates c_tot over the
+// centre's pairs (one pair per wavefront at a time), pass 2 walks the seq rows (one row per wavefront),
+// re-evaluates the cheap per-pair tables and contracts.  No atomics; the summation order is fixed.
 #include "gpr_internal.h"
 
 namespace {
@@ -18,22 +30,7 @@ namespace {
 constexpr int SO3_LCAP = 7;      // lmax <= 6  (tables hold l = 0 .. lmax+1)
 constexpr int SO3_NQCAP = 128;   // quadrature nodes: 10*(nmax+lmax+1) <= 128
 constexpr int SO3_WAVES = 4;
-
-struct so3_args {
-    int nmax, lmax, nq, d;
-    double rcut, alpha;
-    const double *G;            // [nmax][nq] radial weights (SO3.py:623-655)
-    const double *rq;           // [nq] quadrature radii
-    const double *vec;          // [P][3] neighbour displacement
-    const double *wj;           // [P] neighbour weight (Z_j, SO3.py:385)
-    const int *centre_pair0;    // [nc+1]
-    const int *centre_row0;     // [nc+1] seq-row range of each centre
-    const int *row_pair0;       // [S+1]  pair range of each seq row
-    const int *self_row;        // [nc]   seq row (i, i)
-    double *x;                  // [nc][d]
-    double *dxdr;               // [S][d][3]
-    double2 *dc;                // scratch [P][nmax*L*M][3]
-};
+constexpr int SO3_NCHEB = 16;    // Chebyshev coefficients per segment (compile-time: the Clenshaw sum is fully unrolled)
 
 struct cplx { double re, im; };
 __device__ __forceinline__ cplx cmul(cplx a, cplx b) { return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; }
@@ -75,73 +72,99 @@ __device__ void sph_in_table(double x, int lt, double *b) {
     }
 }
 
-// dynamic LDS layout (doubles), sized for the actual (nmax, lmax, nq):
-//   sG [nmax][nq] | srq [nq] | per wave: sB [L][nq], sD [L][nq] | sI, sdI [4][32] | sY [4][LT+1][LT+1] cplx |
-//   sGY [4][L][M][3] cplx | sCw [4][NLM] cplx | sSelf [4][96];   phase 2 re-uses the sB/sD area per wave as
-//   the staging buffer of one pair's dC (NLM*3 complex), which the host checks to fit.
-struct so3_lds {
-    int oG, orq, oB, oD, oI, odI, oY, oGY, oC, oSelf, oNY, oCG, oNL, total, bstride, ystride, gystride, cstride;
-};
-__host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, int nq) {
-    const int L = lmax + 1, M = 2 * lmax + 1, LT = lmax + 2, NLM = nmax * L * M;
-    so3_lds o;
-    int off = 0;
-    o.oG = off; off += nmax * nq;
-    o.orq = off; off += nq;
-    // per-wave Bessel tables sB | sD (contiguous areas of SO3_WAVES * bs doubles each); in phase 2 the two areas
-    // together are re-cut into SO3_WAVES staging buffers of NLM*6 doubles (one pair's dC as complex triples)
-    int bs = L * nq;
-    const int need = (NLM * 6 * SO3_WAVES + 2 * SO3_WAVES - 1) / (2 * SO3_WAVES);
-    if (bs < need) bs = need;
-    o.bstride = bs;
-    o.oB = off; off += SO3_WAVES * bs;
-    o.oD = off; off += SO3_WAVES * bs;
-    o.oI = off; off += SO3_WAVES * 32;
-    o.odI = off; off += SO3_WAVES * 32;
-    o.ystride = LT * LT * 2;
-    o.oY = off; off += SO3_WAVES * o.ystride;
-    o.gystride = L * M * 3 * 2;
-    o.oGY = off; off += SO3_WAVES * o.gystride;
-    o.cstride = NLM * 2;
-    o.oC = off; off += SO3_WAVES * o.cstride;
-    o.oSelf = off; off += SO3_WAVES * 96;
-    o.oNY = off; off += LT * LT;            // Y_l^m normalisation, l <= lmax+1, m >= 0
-    o.oCG = off; off += L * M * 6;          // the six coefficients of grad Y_l^m (SO3.py:682-707)
-    o.oNL = off; off += L;                  // norm_l = sqrt(2 sqrt2 pi / sqrt(2l+1)) (SO3.py:206)
-    o.total = off;
-    return o;
+// ---------------------------------------------------------------- table layout (doubles, device global)
+//   cheb [nseg][ncheb][NF]   NF = 2 nmax (lmax+1): function f = 2 (n L + l) + {0: F0, 1: F1}
+//   NY   [(lmax+3)^2]        Y_l^m normalisation, l <= lmax+1, m >= 0 (row width lmax+3)
+//   CG   [L][M][6]           the six coefficients of grad Y_l^m (SO3.py:682-707)
+//   NL   [L]                 norm_l = sqrt(2 sqrt2 pi / sqrt(2l+1)) (SO3.py:206)
+//   RI   [(lmax+3)^2]        1 / (l - m) for l > m (Legendre recurrence without divisions)
+struct so3_tab { int NF, oNY, oCG, oNL, oRI, total; };
+__host__ __device__ inline so3_tab so3_table_layout(int nmax, int lmax, int nseg, int ncheb) {
+    const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3;
+    so3_tab t;
+    t.NF = 2 * nmax * L;
+    int off = nseg * ncheb * t.NF;
+    t.oNY = off; off += YW * YW;
+    t.oCG = off; off += L * M * 6;
+    t.oNL = off; off += L;
+    t.oRI = off; off += YW * YW;
+    t.total = off;
+    return t;
 }
 
-__global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int L = A.lmax + 1, M = 2 * A.lmax + 1, NLM = A.nmax * L * M;
-    const int LT = A.lmax + 1;                  // highest l in the Y table (gradients need l+1)
-    const int YW = LT + 1;                      // row width of the Y table
-    const so3_lds lay = so3_layout(A.nmax, A.lmax, A.nq);
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double *sG = smem + lay.oG, *srq = smem + lay.orq;
-    double *sB = smem + lay.oB + wave * lay.bstride, *sD = smem + lay.oD + wave * lay.bstride;
-    double *sI = smem + lay.oI + wave * 32, *sdI = smem + lay.odI + wave * 32;
-    cplx *sY = (cplx *)(smem + lay.oY + wave * lay.ystride);
-    cplx *sGY = (cplx *)(smem + lay.oGY + wave * lay.gystride);
-    cplx *sCw = (cplx *)(smem + lay.oC + wave * lay.cstride);
-    double *sSelf = smem + lay.oSelf;
-    const int ic = blockIdx.x;
-    const int p0 = A.centre_pair0[ic], p1 = A.centre_pair0[ic + 1];
-    double *sNY = smem + lay.oNY, *sCG = smem + lay.oCG, *sNL = smem + lay.oNL;
-    // constant tables (square roots and factorial ratios) evaluated once per workgroup
-    for (int e = tid; e < (LT + 1) * (LT + 1); e += 256) {
-        const int l = e / (LT + 1), m = e % (LT + 1);
+// direct quadrature of F0_nl(r), F1_nl(r) (SO3.py:608-727 restricted to the radial factors): one wavefront per
+// radius, lanes over quadrature nodes.  out[nr][NF].
+__global__ void __launch_bounds__(64) so3_radial_direct_kernel(int nmax, int lmax, double alpha, int nq, const double *G,
+                                                              const double *rq, int nr, const double *rs, double *out) {
+    const int ir = blockIdx.x, lane = threadIdx.x, L = lmax + 1;
+    if (ir >= nr) return;
+    const double r = rs[ir];
+    const int lt = lmax > 1 ? lmax : 1;
+    double s0[SO3_LCAP * 4], s1[SO3_LCAP * 4];          // [n][l], nmax <= 4 here (checked on the host)
+#pragma unroll
+    for (int e = 0; e < SO3_LCAP * 4; e++) { s0[e] = 0.0; s1[e] = 0.0; }
+    for (int q = lane; q < nq; q += 64) {
+        double b[SO3_LCAP + 1];
+        const double rqq = rq[q], xarg = 2.0 * alpha * r * rqq, chain = 2.0 * alpha * rqq, ixarg = 1.0 / xarg;
+        sph_in_table(xarg, lt, b);
+#pragma unroll
+        for (int l = 0; l < SO3_LCAP; l++)
+            if (l <= lmax) {
+                const double db = ((l == 0) ? b[1] : b[l - 1] - (l + 1) * ixarg * b[l]) * chain;   // scipy _spherical_in_d
+#pragma unroll
+                for (int n = 0; n < 4; n++)
+                    if (n < nmax) { const double g = G[n * nq + q]; s0[n * SO3_LCAP + l] += g * b[l]; s1[n * SO3_LCAP + l] += g * db; }
+            }
+    }
+    const double E = 4.0 * M_PI * exp(-alpha * r * r);
+#pragma unroll
+    for (int n = 0; n < 4; n++)
+#pragma unroll
+        for (int l = 0; l < SO3_LCAP; l++)
+            if (n < nmax && l <= lmax) {
+                double a = s0[n * SO3_LCAP + l], d = s1[n * SO3_LCAP + l];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); d += __shfl_xor(d, o); }
+                if (lane == 0) {
+                    out[(size_t)ir * 2 * nmax * L + 2 * (n * L + l)] = E * a;
+                    out[(size_t)ir * 2 * nmax * L + 2 * (n * L + l) + 1] = E * (d - 2.0 * alpha * r * a);
+                }
+            }
+}
+
+__global__ void so3_cheb_nodes_kernel(int nseg, int ncheb, double rcut, double *rs) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseg * ncheb) return;
+    const int seg = t / ncheb, j = t % ncheb;
+    const double half = 0.5 * rcut / nseg, mid = (seg + 0.5) * rcut / nseg;
+    rs[t] = mid + half * cos(M_PI * (j + 0.5) / ncheb);
+}
+
+// vals[seg][j][f] at the Chebyshev nodes -> coef[seg][k][f], f(t) = sum_k coef_k T_k(t) (coef_0 already halved)
+__global__ void so3_cheb_coef_kernel(int nseg, int ncheb, int NF, const double *vals, double *coef) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nseg * ncheb * NF) return;
+    const int f = t % NF, k = (t / NF) % ncheb, seg = t / (NF * ncheb);
+    double s = 0.0;
+    for (int j = 0; j < ncheb; j++) s += vals[((size_t)seg * ncheb + j) * NF + f] * cos(M_PI * k * (j + 0.5) / ncheb);
+    coef[t] = s * (k == 0 ? 1.0 : 2.0) / ncheb;
+}
+
+__global__ void so3_const_tables_kernel(int lmax, double *NY, double *CG, double *NL, double *RI) {
+    const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, tid = threadIdx.x;
+    for (int e = tid; e < YW * YW; e += blockDim.x) {
+        const int l = e / YW, m = e % YW;
         double v = 0.0;
-        if (m <= l) {
+        if (m <= l && l <= lmax + 1) {
             double ratio = 1.0;                          // (l-m)! / (l+m)!
             for (int k = l - m + 1; k <= l + m; k++) ratio /= k;
             v = sqrt((2 * l + 1) / (4.0 * M_PI) * ratio);
         }
-        sNY[e] = v;
+        NY[e] = v;
+        RI[e] = l > m ? 1.0 / (l - m) : 0.0;
     }
-    for (int e = tid; e < L * M; e += 256) {
-        const int l = e / M, m = e % M - A.lmax;
+    for (int e = tid; e < L * M; e += blockDim.x) {
+        const int l = e / M, m = e % M - lmax;
         double c[6] = {0, 0, 0, 0, 0, 0};
         if (l >= 1 && m >= -l && m <= l) {
             const double dl = l;
@@ -152,12 +175,97 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
             c[4] = -sqrt((dl - m + 1) * (dl - m + 2) / 2 / (2 * dl + 1) / (2 * dl + 3)) * dl;
             if (abs(m - 1) <= l - 1) c[5] = -sqrt((dl + m - 1) * (dl + m) / 2 / (2 * dl - 1) / (2 * dl + 1)) * (dl + 1);
         }
-        for (int k = 0; k < 6; k++) sCG[e * 6 + k] = c[k];
+        for (int k = 0; k < 6; k++) CG[e * 6 + k] = c[k];
     }
-    for (int e = tid; e < L; e += 256) sNL[e] = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * e + 1.0));
-    for (int e = tid; e < A.nmax * A.nq; e += 256) sG[e] = A.G[e];
-    for (int e = tid; e < A.nq; e += 256) srq[e] = A.rq[e];
-    for (int e = lane; e < NLM; e += 64) sCw[e] = {0.0, 0.0};
+    for (int e = tid; e < L; e += blockDim.x) NL[e] = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * e + 1.0));
+}
+
+// Clenshaw evaluation of function f of the piecewise Chebyshev table at radius r
+__device__ __forceinline__ double cheb_eval(const double *cheb, int nseg, int NF, double rcut, double r, int f) {
+    int seg = (int)(r * nseg / rcut);
+    seg = seg < 0 ? 0 : (seg > nseg - 1 ? nseg - 1 : seg);
+    const double inv_half = 2.0 * nseg / rcut, mid = (seg + 0.5) * rcut / nseg;
+    const double t = (r - mid) * inv_half, t2 = 2.0 * t;
+    const double *c = cheb + (size_t)seg * SO3_NCHEB * NF + f;
+    double cf[SO3_NCHEB];
+#pragma unroll
+    for (int k = 0; k < SO3_NCHEB; k++) cf[k] = c[k * NF];          // all loads in flight before the recurrence
+    double b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int k = SO3_NCHEB - 1; k >= 1; k--) { const double b0 = cf[k] + t2 * b1 - b2; b2 = b1; b1 = b0; }
+    return cf[0] + t * b1 - b2;
+}
+
+__global__ void so3_radial_eval_kernel(const double *cheb, int nseg, int ncheb, int NF, double rcut, int nr, const double *rs,
+                                       double *out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nr * NF) return;
+    out[t] = cheb_eval(cheb, nseg, NF, rcut, rs[t / NF], t % NF);
+}
+
+// ---------------------------------------------------------------- descriptor kernel
+struct so3_args {
+    int nmax, lmax, d, nseg, ncheb;
+    double rcut, alpha;
+    const double *table;        // so3_table_layout
+    const double *vec;          // [P][3] neighbour displacement
+    const double *wj;           // [P] neighbour weight (Z_j, SO3.py:385)
+    const int *centre_pair0;    // [nc+1]
+    const int *centre_row0;     // [nc+1] seq-row range of each centre
+    const int *row_pair0;       // [S+1]  pair range of each seq row
+    const int *self_row;        // [nc]   seq row (i, i)
+    double *x;                  // [nc][d]
+    double *dxdr;               // [S][d][3]
+};
+
+// dynamic LDS layout (doubles): constant tables NY | CG | NL, c_tot [NLM] cplx, self sums [4][96], and per
+// wavefront: A [32] | B [32] | Y [(lmax+3)^2] cplx | GY [L][M][3] cplx | R [32] | S [96] | Cw [NLM] cplx
+struct so3_lds { int oNY, oCG, oNL, oRI, oCtot, oSelf, oWave, wstride, oA, oB, oY, oGY, oR, oS, oCw, total; };
+__host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
+    const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, NLM = nmax * L * M;
+    so3_lds o;
+    int off = 0;
+    o.oNY = off; off += YW * YW;
+    o.oCG = off; off += L * M * 6;
+    o.oNL = off; off += L;
+    o.oRI = off; off += YW * YW;
+    off = (off + 1) & ~1;
+    o.oCtot = off; off += NLM * 2;
+    o.oSelf = off; off += SO3_WAVES * 96;
+    o.oWave = off;
+    int w = 0;
+    o.oA = w; w += 32;
+    o.oB = w; w += 32;
+    o.oY = w; w += YW * YW * 2;
+    o.oGY = w; w += L * M * 3 * 2;
+    o.oR = w; w += 32;
+    o.oS = w; w += 96;
+    o.oCw = w; w += NLM * 2;
+    o.wstride = (w + 1) & ~1;
+    o.total = off + SO3_WAVES * o.wstride;
+    return o;
+}
+
+__global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
+    const int YW = P.lmax + 3;                  // row width of the Y table (l, m <= lmax+1, one spare column)
+    const so3_lds lay = so3_layout(P.nmax, P.lmax);
+    const so3_tab tab = so3_table_layout(P.nmax, P.lmax, P.nseg, P.ncheb);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double *sNY = smem + lay.oNY, *sCG = smem + lay.oCG, *sNL = smem + lay.oNL, *sRI = smem + lay.oRI;
+    cplx *ctot = (cplx *)(smem + lay.oCtot);
+    double *sSelf = smem + lay.oSelf;
+    double *wbase = smem + lay.oWave + wave * lay.wstride;
+    double *sA = wbase + lay.oA, *sB = wbase + lay.oB, *sR = wbase + lay.oR, *sS = wbase + lay.oS;
+    cplx *sY = (cplx *)(wbase + lay.oY), *sGY = (cplx *)(wbase + lay.oGY), *sCw = (cplx *)(wbase + lay.oCw);
+    const int ic = blockIdx.x;
+    const int p0 = P.centre_pair0[ic], p1 = P.centre_pair0[ic + 1];
+    {
+        const double *src = P.table + tab.oNY;          // NY | CG | NL | RI are contiguous in the table and in LDS
+        const int ncst = 2 * YW * YW + L * M * 6 + L;
+        for (int e = tid; e < ncst; e += 256) smem[lay.oNY + e] = src[e];
+    }
     __syncthreads();
 
     auto Ylm = [&](int l, int m) -> cplx {     // any m; zero outside |m| <= l
@@ -167,9 +275,26 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
         const double sgn = ((-m) & 1) ? -1.0 : 1.0;
         return {sgn * v.re, -sgn * v.im};
     };
-    // Y_l^m (m = lane >= 0, l = m .. lmax+1) and grad Y_l^m of the unit vector (ux, uy, uz), |r| = r
-    auto angular_tables = [&](double ux, double uy, double uz, double r) {
-        if (lane <= LT) {
+    // per-pair tables of one wavefront: A_nl, B_nl (lanes over the 2 nmax L radial functions), Y_l^m for
+    // l <= ltop (lanes over m >= 0), and, when GRAD, grad Y_l^m (lanes over (l, m))
+    auto pair_tables = [&](int p, bool grad, double &ux, double &uy, double &uz) {
+        const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+        const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
+        ux = vx * inv_r; uy = vy * inv_r; uz = vz * inv_r;
+        const double w = P.wj[p];
+        double sarg, carg;
+        sincos(M_PI * r / P.rcut, &sarg, &carg);
+        const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI / P.rcut * sarg;
+        if (lane < 2 * NL) {
+            const double v = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, lane);
+            const double other = __shfl_xor(v, 1);                  // F0 <-> F1 of the same (n, l)
+            const int nl = lane >> 1, l = nl % L;
+            const double norm = sNL[l] * w;                          // SO3.py:206, 221
+            if (lane & 1) sA[nl] = norm * (fc * v + dfc * other);    // v = F1, other = F0
+            else sB[nl] = norm * fc * v;                             // v = F0
+        }
+        const int ltop = grad ? P.lmax + 1 : P.lmax;
+        if (lane <= ltop) {
             const int m = lane;
             const double ct = uz, rho = sqrt(ux * ux + uy * uy), st = rho;
             const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
@@ -178,11 +303,11 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
             double pmm = 1.0;                                // P_m^m with the Condon-Shortley phase
             for (int k = 1; k <= m; k++) pmm *= -(2 * k - 1) * st;
             double plm2 = 0.0, plm1 = pmm;
-            for (int l = m; l <= LT; l++) {
+            for (int l = m; l <= ltop; l++) {
                 double plm;
                 if (l == m) plm = pmm;
                 else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
-                else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) / (l - m);
+                else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) * sRI[l * YW + m];
                 if (l > m) { plm2 = plm1; plm1 = plm; }
                 const double nrm = sNY[l * YW + m];
                 sY[l * YW + m] = {nrm * plm * cm, nrm * plm * sm};
@@ -190,119 +315,60 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
         }
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
-        // gradient of Y_l^m from its covariant spherical components (SO3.py:682-707)
-        const double inv_r = 1.0 / r;
-        for (int e = lane; e < L * M; e += 64) {
-            const int l = e / M, m = e % M - A.lmax;
-            cplx g0 = {0, 0}, gp = {0, 0}, gm = {0, 0};
-            if (l >= 1 && m >= -l && m <= l) {
-                const double *cg = sCG + e * 6;
-                g0 = cadd(cscale(Ylm(l + 1, m), cg[0] * inv_r), cscale(Ylm(l - 1, m), cg[1] * inv_r));
-                gp = cadd(cscale(Ylm(l + 1, m + 1), cg[2] * inv_r), cscale(Ylm(l - 1, m + 1), cg[3] * inv_r));
-                gm = cadd(cscale(Ylm(l + 1, m - 1), cg[4] * inv_r), cscale(Ylm(l - 1, m - 1), cg[5] * inv_r));
+        if (grad) {
+            // gradient of Y_l^m from its covariant spherical components (SO3.py:682-707)
+            for (int e = lane; e < L * M; e += 64) {
+                const int l = e / M, m = e % M - P.lmax;
+                cplx g0 = {0, 0}, gp = {0, 0}, gm = {0, 0};
+                if (l >= 1 && m >= -l && m <= l) {
+                    const double *cg = sCG + e * 6;
+                    g0 = cadd(cscale(Ylm(l + 1, m), cg[0] * inv_r), cscale(Ylm(l - 1, m), cg[1] * inv_r));
+                    gp = cadd(cscale(Ylm(l + 1, m + 1), cg[2] * inv_r), cscale(Ylm(l - 1, m + 1), cg[3] * inv_r));
+                    gm = cadd(cscale(Ylm(l + 1, m - 1), cg[4] * inv_r), cscale(Ylm(l - 1, m - 1), cg[5] * inv_r));
+                }
+                const double is2 = 0.70710678118654752440;
+                cplx dmp = {gm.re - gp.re, gm.im - gp.im}, smp = {gm.re + gp.re, gm.im + gp.im};
+                sGY[e * 3 + 0] = cscale(dmp, is2);
+                sGY[e * 3 + 1] = {-is2 * smp.im, is2 * smp.re};          // i/sqrt(2) * (gm + gp)
+                sGY[e * 3 + 2] = g0;
             }
-            const double is2 = 0.70710678118654752440;
-            cplx dmp = {gm.re - gp.re, gm.im - gp.im}, smp = {gm.re + gp.re, gm.im + gp.im};
-            sGY[e * 3 + 0] = cscale(dmp, is2);
-            sGY[e * 3 + 1] = {-is2 * smp.im, is2 * smp.re};          // i/sqrt(2) * (gm + gp)
-            sGY[e * 3 + 2] = g0;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
     };
 
-    // ---- phase 1: every wavefront walks its share of the centre's neighbour pairs (no block barriers inside:
-    //      all tables are wavefront private, ordered by wave_barrier + LDS fences)
-    for (int p = p0 + wave; p < p1; p += SO3_WAVES) {
-        const double vx = A.vec[3 * p], vy = A.vec[3 * p + 1], vz = A.vec[3 * p + 2];
-        const double r = sqrt(vx * vx + vy * vy + vz * vz);
-        const double ux = vx / r, uy = vy / r, uz = vz / r;
-        // A1: Bessel values at the quadrature nodes (lanes over nodes)
-        const int lt = A.lmax > 1 ? A.lmax : 1;
-        for (int q = lane; q < A.nq; q += 64) {
-            double b[SO3_LCAP + 1];
-            const double rqq = srq[q];
-            const double xarg = 2.0 * A.alpha * r * rqq;
-            sph_in_table(xarg, lt, b);
-            const double chain = 2.0 * A.alpha * rqq;           // d/dr of the argument
-            const double ixarg = 1.0 / xarg;
+    // ---- pass 1: c_tot.  Each wavefront walks its share of the centre's pairs; lane e accumulates the
+    //      coefficients e, e + 64, e + 128 (< NLM) in registers.  No block barriers inside the loop: all tables
+    //      are wavefront private, ordered by wave_barrier + LDS fences.
+    {
+        cplx acc[3] = {{0, 0}, {0, 0}, {0, 0}};
+        for (int p = p0 + wave; p < p1; p += SO3_WAVES) {
+            double ux, uy, uz;
+            pair_tables(p, false, ux, uy, uz);
 #pragma unroll
-            for (int l = 0; l <= SO3_LCAP - 1; l++)
-                if (l <= A.lmax) {
-                    sB[l * A.nq + q] = b[l];
-                    const double db = (l == 0) ? b[1] : b[l - 1] - (l + 1) * ixarg * b[l];   // scipy _spherical_in_d
-                    sD[l * A.nq + q] = db * chain;
+            for (int rnd = 0; rnd < 3; rnd++) {
+                const int e = lane + 64 * rnd;
+                if (e < NLM) {
+                    const int nl = e / M, l = nl % L, m = e % M - P.lmax;
+                    if (m >= -l && m <= l) acc[rnd] = cadd(acc[rnd], cscale(Ylm(l, m), sB[nl]));
                 }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        // A2: radial integrals I[n][l], dI/dr: lanes = (n, l) x 4 node quarters, then a 4-lane reduction
-        {
-            const int e = lane >> 2, part = lane & 3, nl = A.nmax * L;
-            for (int e0 = 0; e0 < nl; e0 += 16) {
-                const int ee = e0 + e;
-                double s0 = 0.0, s1 = 0.0;
-                if (ee < nl) {
-                    const int n = ee / L, l = ee % L;
-                    for (int q = part; q < A.nq; q += 4) {
-                        const double g = sG[n * A.nq + q];
-                        s0 += g * sB[l * A.nq + q];
-                        s1 += g * sD[l * A.nq + q];
-                    }
-                }
-                s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
-                s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
-                if (ee < nl && part == 0) { sI[ee] = s0; sdI[ee] = s1; }
             }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
-        angular_tables(ux, uy, uz, r);
-        // C: expansion coefficients and gradients of this pair (lanes over (n, l, m))
-        {
-            const double w = A.wj[p];
-            const double E = 4.0 * M_PI * exp(-A.alpha * r * r);
-            const double gE = -2.0 * A.alpha * r * E;                            // d/dr
-            const double fc = 0.5 * (cos(M_PI * r / A.rcut) + 1.0);
-            const double dfc = -0.5 * M_PI / A.rcut * sin(M_PI * r / A.rcut);
-            const double u[3] = {ux, uy, uz};
-            for (int e = lane; e < NLM; e += 64) {
-                const int n = e / (L * M), l = (e / M) % L, mi = e % M, m = mi - A.lmax;
-                cplx cval = {0, 0}, dcv[3] = {{0, 0}, {0, 0}, {0, 0}};
-                if (m >= -l && m <= l) {
-                    const double norm = sNL[l] * w;                                               // SO3.py:206, 221
-                    const double In = sI[n * L + l], dIn = sdI[n * L + l];
-                    const cplx Y = Ylm(l, m);
-                    const cplx yin = cscale(Y, In);
-                    cval = cscale(yin, E);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        cplx t = cscale(yin, gE * u[k]);
-                        cplx h = cadd(cscale(sGY[(l * M + mi) * 3 + k], In), cscale(Y, dIn * u[k]));
-                        t = cadd(t, cscale(h, E));
-                        t = cadd(cscale(t, fc), cscale(cval, dfc * u[k]));
-                        dcv[k] = cscale(t, norm);
-                    }
-                    cval = cscale(cval, fc * norm);
-                }
-                double2 *o = A.dc + ((size_t)p * NLM + e) * 3;
-#pragma unroll
-                for (int k = 0; k < 3; k++) o[k] = make_double2(dcv[k].re, dcv[k].im);
-                sCw[e] = cadd(sCw[e], cval);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
+        for (int rnd = 0; rnd < 3; rnd++) { const int e = lane + 64 * rnd; if (e < NLM) sCw[e] = acc[rnd]; }
+        for (int e = lane + 192; e < NLM; e += 64) sCw[e] = {0.0, 0.0};      // NLM > 192 is refused by the host
+    }
+    __syncthreads();
+    for (int e = tid; e < NLM; e += 256) {
+        cplx s = {0.0, 0.0};
+        for (int w2 = 0; w2 < SO3_WAVES; w2++) s = cadd(s, ((cplx *)(smem + lay.oWave + w2 * lay.wstride + lay.oCw))[e]);
+        ctot[e] = s;
     }
     __syncthreads();
 
-    // ---- phase 2: c_tot, x_i, dP rows
-    cplx *sC0 = (cplx *)(smem + lay.oC);
-    for (int e = tid; e < NLM; e += 256) {
-        cplx s = sC0[e];
-        for (int w2 = 1; w2 < SO3_WAVES; w2++) s = cadd(s, ((cplx *)(smem + lay.oC + w2 * lay.cstride))[e]);
-        sC0[e] = s;
-    }
-    __syncthreads();
-    const cplx *ctot = sC0;
+    // ---- power spectrum x_i
     auto decode = [&](int c, int &n1, int &n2, int &l) {
         const int pi = c / L;
         l = c % L;
@@ -310,7 +376,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
         while ((n1 + 1) * (n1 + 2) / 2 <= pi) n1++;
         n2 = pi - n1 * (n1 + 1) / 2;
     };
-    for (int c = tid; c < A.d; c += 256) {
+    for (int c = tid; c < P.d; c += 256) {
         int n1, n2, l;
         decode(c, n1, n2, l);
         double s = 0.0;
@@ -318,58 +384,60 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
             const cplx a = ctot[(n1 * L + l) * M + mi], b = ctot[(n2 * L + l) * M + mi];
             s += a.re * b.re + a.im * b.im;
         }
-        A.x[(size_t)ic * A.d + c] = s;
+        P.x[(size_t)ic * P.d + c] = s;
     }
-    const int r0 = A.centre_row0[ic], r1 = A.centre_row0[ic + 1], rself = A.self_row[ic];
-    const int ne = A.d * 3;
-    double self0 = 0.0, self1 = 0.0;
-    // per lane: the two (coefficient, component) outputs it owns and their c_tot index pairs
-    int e_idx[2], i1b[2], i2b[2];
+
+    // ---- pass 2: dP rows.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk; both keep their c_tot row
+    //      (n, l, .) in LDS reach.  Lanes e < 3 d then combine into the row's outputs.
+    const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1], rself = P.self_row[ic];
+    const int ne = P.d * 3;
+    int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
+    if (lane < NL) t_nl = lane;
+    else if (lane < 4 * NL) { t_nl = (lane - NL) / 3; t_k = (lane - NL) % 3; }
+    const bool has_task = lane < 4 * NL;
+    const int t_l = t_nl % L;
+    int e_k[2], iA1[2], iA2[2];
 #pragma unroll
     for (int rnd = 0; rnd < 2; rnd++) {
         const int e = lane + 64 * rnd;
-        e_idx[rnd] = e;
         int n1 = 0, n2 = 0, l = 0;
         if (e < ne) decode(e / 3, n1, n2, l);
-        i1b[rnd] = (n1 * L + l) * M; i2b[rnd] = (n2 * L + l) * M;
+        e_k[rnd] = e % 3; iA1[rnd] = n1 * L + l; iA2[rnd] = n2 * L + l;
     }
-    double2 *stage = (double2 *)(smem + lay.oB + wave * NLM * 6);   // wave-private staging of one pair's dC
+    double self0 = 0.0, self1 = 0.0;
     for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
         if (row == rself) continue;
-        const int q0 = A.row_pair0[row], q1 = A.row_pair0[row + 1];
+        const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
         double s[2] = {0.0, 0.0};
         for (int p = q0; p < q1; p++) {
-            const double2 *dp = A.dc + (size_t)p * NLM * 3;
-            __builtin_amdgcn_wave_barrier();
-            {   // coalesced copy of the pair's dC: all loads in flight before the first LDS store
-                double2 tmp[8];
-                const int nt = NLM * 3;
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int t = lane + 64 * u; if (t < nt) tmp[u] = dp[t]; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) { const int t = lane + 64 * u; if (t < nt) stage[t] = tmp[u]; }
-                for (int t = lane + 512; t < nt; t += 64) stage[t] = dp[t];
+            double ux, uy, uz;
+            pair_tables(p, true, ux, uy, uz);
+            if (has_task) {
+                double acc = 0.0;
+                for (int m = -t_l; m <= t_l; m++) {
+                    const int mi = m + P.lmax;
+                    const cplx y = (t_k < 0) ? Ylm(t_l, m) : sGY[((t_l * M) + mi) * 3 + t_k];
+                    const cplx c = ctot[t_nl * M + mi];
+                    acc += y.re * c.re + y.im * c.im;
+                }
+                if (t_k < 0) sR[t_nl] = acc; else sS[t_nl * 3 + t_k] = acc;
             }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
 #pragma unroll
             for (int rnd = 0; rnd < 2; rnd++) {
-                const int e = e_idx[rnd];
-                if (e < ne) {
-                    const int k = e % 3;
-                    double acc = 0.0;
-                    for (int mi = 0; mi < M; mi++) {
-                        const int i1 = i1b[rnd] + mi, i2 = i2b[rnd] + mi;
-                        const double2 d1 = stage[i1 * 3 + k], d2 = stage[i2 * 3 + k];
-                        acc += d1.x * ctot[i2].re + d1.y * ctot[i2].im + d2.x * ctot[i1].re + d2.y * ctot[i1].im;
-                    }
-                    s[rnd] += acc;
+                if (lane + 64 * rnd < ne) {
+                    const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
+                    const double uk = (k == 0) ? ux : (k == 1 ? uy : uz);
+                    s[rnd] += uk * (sA[a1] * sR[a2] + sA[a2] * sR[a1]) + sB[a1] * sS[a2 * 3 + k] + sB[a2] * sS[a1 * 3 + k];
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
         }
 #pragma unroll
         for (int rnd = 0; rnd < 2; rnd++)
-            if (e_idx[rnd] < ne) A.dxdr[(size_t)row * ne + e_idx[rnd]] = s[rnd];
+            if (lane + 64 * rnd < ne) P.dxdr[(size_t)row * ne + lane + 64 * rnd] = s[rnd];
         self0 += s[0]; self1 += s[1];
     }
     sSelf[wave * 96 + lane] = self0;
@@ -378,46 +446,98 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args A) {
     for (int e = tid; e < ne; e += 256) {
         double s = 0.0;
         for (int w2 = 0; w2 < SO3_WAVES; w2++) s += sSelf[w2 * 96 + e];
-        A.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
+        P.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
     }
+}
+
+int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char *who) {
+    const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1, M = 2 * lmax + 1;
+    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > 4 || nq > SO3_NQCAP || nmax * L > 16 || d * 3 > 96 ||
+        nmax * L * M > 192 || nseg < 1 || ncheb != SO3_NCHEB) {
+        gpr_set_error("%s: (nmax=%d, lmax=%d, nq=%d, nseg=%d, ncheb=%d) outside this build's limits "
+                      "(nmax <= 4, lmax <= %d, nq <= %d, nmax (lmax+1) <= 16, ncoef <= 32, ncheb == %d)",
+                      who, nmax, lmax, nq, nseg, ncheb, SO3_LCAP - 1, SO3_NQCAP, SO3_NCHEB);
+        return GPR_ERR_UNSUPPORTED;
+    }
+    return GPR_OK;
 }
 
 }  // namespace
 
+extern "C" long long gpr_so3_table_size(int nmax, int lmax, int nseg, int ncheb) {
+    return so3_table_layout(nmax, lmax, nseg, ncheb).total;
+}
+
+// Builds the radial Chebyshev table and the angular constant tables on the device (once per descriptor
+// configuration).  G[nmax, nq], rq[nq]: the reference's quadrature (SO3.py:446-453, 623-655), device.
+extern "C" int gpr_so3_tables(void *stream, int nmax, int lmax, double rcut, double alpha, int nq, const double *G,
+                              const double *rq, int nseg, int ncheb, double *table) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = so3_check_limits(nmax, lmax, nq, nseg, ncheb, "gpr_so3_tables");
+    if (rc) return rc;
+    GPR_REQUIRE(G && rq && table && nq >= 1 && rcut > 0.0, "gpr_so3_tables: null pointer or bad sizes");
+    const so3_tab tab = so3_table_layout(nmax, lmax, nseg, ncheb);
+    const int nr = nseg * ncheb;
+    void *p;
+    if ((rc = gpr_dev_alloc(&p, (size_t)nr * (1 + tab.NF) * sizeof(double), st))) return rc;
+    double *rs = (double *)p, *vals = rs + nr;
+    hipLaunchKernelGGL(so3_cheb_nodes_kernel, dim3((nr + 255) / 256), dim3(256), 0, st, nseg, ncheb, rcut, rs);
+    hipLaunchKernelGGL(so3_radial_direct_kernel, dim3(nr), dim3(64), 0, st, nmax, lmax, alpha, nq, G, rq, nr, rs, vals);
+    hipLaunchKernelGGL(so3_cheb_coef_kernel, dim3((nr * tab.NF + 255) / 256), dim3(256), 0, st, nseg, ncheb, tab.NF, vals, table);
+    hipLaunchKernelGGL(so3_const_tables_kernel, dim3(1), dim3(256), 0, st, lmax, table + tab.oNY, table + tab.oCG, table + tab.oNL, table + tab.oRI);
+    hipError_t e = hipGetLastError();
+    gpr_dev_free(p, st);
+    if (e != hipSuccess) { gpr_set_error("gpr_so3_tables: launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}
+
+// F0_nl(r), F1_nl(r) at arbitrary radii rs[nr] (device): mode 0 = direct quadrature, 1 = Chebyshev table.
+// out[nr, 2 nmax (lmax+1)].  Test / validation entry point.
+extern "C" int gpr_so3_radial(void *stream, int mode, int nmax, int lmax, double rcut, double alpha, int nq, const double *G,
+                              const double *rq, int nseg, int ncheb, const double *table, int nr, const double *rs,
+                              double *out) {
+    hipStream_t st = (hipStream_t)stream;
+    int rc = so3_check_limits(nmax, lmax, nq, nseg, ncheb, "gpr_so3_radial");
+    if (rc) return rc;
+    if (nr <= 0) return GPR_OK;
+    GPR_REQUIRE(rs && out, "gpr_so3_radial: null pointer");
+    const int NF = 2 * nmax * (lmax + 1);
+    if (mode == 0) {
+        GPR_REQUIRE(G && rq, "gpr_so3_radial: direct mode needs G and rq");
+        hipLaunchKernelGGL(so3_radial_direct_kernel, dim3(nr), dim3(64), 0, st, nmax, lmax, alpha, nq, G, rq, nr, rs, out);
+    } else {
+        GPR_REQUIRE(table, "gpr_so3_radial: table mode needs the table");
+        hipLaunchKernelGGL(so3_radial_eval_kernel, dim3((nr * NF + 255) / 256), dim3(256), 0, st, table, nseg, ncheb, NF, rcut, nr, rs, out);
+    }
+    GPR_HIP_TRY(hipGetLastError());
+    return GPR_OK;
+}
+
 // x[nc, d], dxdr[S, d, 3] from neighbour pairs grouped by centre and, inside a centre, by seq row.
-// All pointers are device pointers; scratch must hold P * nmax*(lmax+1)*(2*lmax+1) * 3 complex doubles.
-extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nq,
-                                      const double *G, const double *rq, int ncentres, int npairs, int nrows,
+// All pointers are device pointers; `table` comes from gpr_so3_tables with the same (nmax, lmax, rcut, alpha).
+extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                                      const double *table, int ncentres, int npairs, int nrows,
                                       const double *vec, const double *wj, const int *centre_pair0,
                                       const int *centre_row0, const int *row_pair0, const int *self_row,
-                                      double *x, double *dxdr, void *scratch) {
+                                      double *x, double *dxdr) {
     hipStream_t st = (hipStream_t)stream;
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1);
-    GPR_REQUIRE(nmax >= 1 && lmax >= 0, "gpr_so3_power_spectrum: bad nmax/lmax");
-    if (lmax > SO3_LCAP - 1 || nq > SO3_NQCAP || nmax * (lmax + 1) > 32 || d * 3 > 96 || nq < 1) {
-        gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d, nq=%d) outside this build's limits "
-                      "(lmax <= %d, nq <= %d, ncoef <= 32)", nmax, lmax, nq, SO3_LCAP - 1, SO3_NQCAP);
-        return GPR_ERR_UNSUPPORTED;
-    }
+    int rc = so3_check_limits(nmax, lmax, 1, nseg, ncheb, "gpr_so3_power_spectrum");
+    if (rc) return rc;
     if (ncentres <= 0) return GPR_OK;
-    GPR_REQUIRE(G && rq && centre_pair0 && centre_row0 && row_pair0 && self_row && x && dxdr,
+    GPR_REQUIRE(table && centre_pair0 && centre_row0 && row_pair0 && self_row && x && dxdr,
                 "gpr_so3_power_spectrum: null pointer");
-    GPR_REQUIRE(npairs == 0 || (vec && wj && scratch), "gpr_so3_power_spectrum: null pair arrays");
+    GPR_REQUIRE(npairs == 0 || (vec && wj), "gpr_so3_power_spectrum: null pair arrays");
     (void)nrows;
     so3_args A;
-    A.nmax = nmax; A.lmax = lmax; A.nq = nq; A.d = d; A.rcut = rcut; A.alpha = alpha;
-    A.G = G; A.rq = rq; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
-    A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr; A.dc = (double2 *)scratch;
-    const so3_lds lay = so3_layout(nmax, lmax, nq);
+    A.nmax = nmax; A.lmax = lmax; A.d = d; A.nseg = nseg; A.ncheb = ncheb; A.rcut = rcut; A.alpha = alpha;
+    A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
+    A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
+    const so3_lds lay = so3_layout(nmax, lmax);
     const size_t lds_bytes = (size_t)lay.total * sizeof(double);
-    if (lds_bytes > 150 * 1024) {
-        gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d, nq=%d) needs %zu bytes of LDS", nmax, lmax, nq, lds_bytes);
+    if (lds_bytes > 64 * 1024) {
+        gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d) needs %zu bytes of LDS", nmax, lmax, lds_bytes);
         return GPR_ERR_UNSUPPORTED;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        attr_set = true;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
     hipLaunchKernelGGL(so3_centre_kernel, dim3(ncentres), dim3(256), lds_bytes, st, A);

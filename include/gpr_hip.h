@@ -202,20 +202,33 @@ int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const 
 int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
 
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
+/* Tables of one descriptor configuration, built on the device once: piecewise Chebyshev coefficients (nseg
+ * equal segments of [0, rcut], ncheb coefficients each) of the radial functions
+ *   F0_nl(r) = 4 pi exp(-alpha r^2) sum_q G[n][q] i_l(2 alpha r rq[q]),   F1_nl = dF0_nl/dr
+ * -- the reference's 10(nmax+lmax+1)-node Gauss-Chebyshev quadrature against modified spherical Bessel functions
+ * (SO3.py:446-453, 563-565, 623-655), evaluated at the Chebyshev nodes -- plus the Y_lm normalisation and
+ * gradient coefficient tables (SO3.py:682-707).  G[nmax, nq], rq[nq] and table[gpr_so3_table_size()] are device
+ * arrays. */
+long long gpr_so3_table_size(int nmax, int lmax, int nseg, int ncheb);
+int gpr_so3_tables(void *stream, int nmax, int lmax, double rcut, double alpha, int nq, const double *G,
+                   const double *rq, int nseg, int ncheb, double *table);
+/* F0_nl, F1_nl at radii rs[nr] (device) into out[nr, 2 nmax (lmax+1)] (index 2 (n (lmax+1) + l) + {0, 1}):
+ * mode 0 = the direct quadrature, mode 1 = the table.  Validation entry point (tests compare the two). */
+int gpr_so3_radial(void *stream, int mode, int nmax, int lmax, double rcut, double alpha, int nq, const double *G,
+                   const double *rq, int nseg, int ncheb, const double *table, int nr, const double *rs, double *out);
 /* x[ncentres, d] and dxdr[nrows, d, 3] (d = nmax(nmax+1)/2 (lmax+1)) from neighbour pairs grouped by
  * centre atom and, inside a centre, by `seq` row (gpr_calc/SO3.py:186-323, 608-727).
- *   G[nmax, nq], rq[nq]     radial quadrature table (SO3.py:446-453, 623-655), device
+ *   table                        from gpr_so3_tables for the same (nmax, lmax, rcut, alpha, nseg, ncheb), device
  *   vec[npairs, 3], wj[npairs]   displacement and weight (Z_j) of every neighbour pair, device
  *   centre_pair0[ncentres+1]     pair range of each centre
  *   centre_row0[ncentres+1]      seq-row range of each centre
  *   row_pair0[nrows+1]           pair range of each seq row (i, j)
- *   self_row[ncentres]           seq row (i, i), which receives minus the sum of the other rows
- *   scratch                      npairs * nmax*(lmax+1)*(2 lmax+1) * 3 * 16 bytes, device          */
-int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nq,
-                           const double *G, const double *rq, int ncentres, int npairs, int nrows,
+ *   self_row[ncentres]           seq row (i, i), which receives minus the sum of the other rows           */
+int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                           const double *table, int ncentres, int npairs, int nrows,
                            const double *vec, const double *wj, const int *centre_pair0,
                            const int *centre_row0, const int *row_pair0, const int *self_row,
-                           double *x, double *dxdr, void *scratch);
+                           double *x, double *dxdr);
 
 /* ------------------------------------------------------------------ dense FP64 linear algebra */
 /* Row-major device matrices.  Lower Cholesky in place: on return the lower triangle of a holds

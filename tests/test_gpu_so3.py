@@ -96,3 +96,28 @@ def test_batch_descriptor_device_index_matches_host_index():
     a = des.calculate_batch_dev(strucs, host_index=True)
     b = des.calculate_batch_dev(strucs)
     assert torch.equal(a["x"], b["x"]) and torch.equal(a["dxdr"], b["dxdr"])
+
+
+@pytest.mark.parametrize("cfg", [(3, 4, 5.0, 2.0), (3, 3, 3.5, 1.0), (2, 6, 6.0, 3.0)], ids=["n3l4", "n3l3", "n2l6"])
+def test_radial_chebyshev_table_matches_direct_quadrature(cfg):
+    """the piecewise Chebyshev table of F0_nl, F1_nl against the direct 10(nmax+lmax+1)-node quadrature on the
+    device, and the direct quadrature against scipy's Bessel functions (oracle formula, SO3.py:608-727)"""
+    from scipy.special import spherical_in
+    from gpr_calculator_amd.SO3 import SO3, radial_table
+    nmax, lmax, rcut, alpha = cfg
+    des = SO3(nmax=nmax, lmax=lmax, rcut=rcut, alpha=alpha)
+    r = np.random.default_rng(5).uniform(0.02, rcut * (1 - 1e-9), 3000)
+    tab = des.radial_functions(r, mode="table")
+    direct = des.radial_functions(r, mode="direct")
+    scale = np.abs(direct).max(axis=0, keepdims=True)
+    assert (np.abs(tab - direct) / scale).max() < 2e-13
+    rq, G = radial_table(nmax, lmax, rcut, alpha)
+    arg = 2 * alpha * np.outer(r, rq)
+    E = 4 * np.pi * np.exp(-alpha * r ** 2)
+    for l in range(lmax + 1):
+        I = spherical_in(l, arg) @ G.T                                            # [P, n]
+        dI = (spherical_in(l, arg, derivative=True) * (2 * alpha * rq)[None, :]) @ G.T
+        F0 = E[:, None] * I
+        F1 = E[:, None] * (dI - 2 * alpha * r[:, None] * I)
+        assert (np.abs(direct[:, :, l, 0] - F0) / scale[0, :, l, 0]).max() < 1e-12
+        assert (np.abs(direct[:, :, l, 1] - F1) / scale[0, :, l, 1]).max() < 1e-11
