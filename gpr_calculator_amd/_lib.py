@@ -69,6 +69,7 @@ _L1_SIGNATURES = {
     "gpr_so3_tables": ([_vp, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp], _i),
     "gpr_so3_radial": ([_vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp], _i),
     "gpr_gemv_t": ([_vp, _i, _i, _vp, _ll, _vp, _vp], _i),
+    "gpr_ws_finish": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _vp, _vp], _i),
     "gpr_rowdot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
     "gpr_frob_dot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
 }

@@ -421,6 +421,25 @@ __global__ void __launch_bounds__(256) rowdot_kernel(int m, int n, const double 
     if (lane == 0) out[row] = acc;
 }
 
+// weight-space prediction tail: mean[i] = P[i,:] . w and var[i] = max(diag[i] - Q[i,:] . P[i,:], 0) in one pass over
+// the rows (Q = P M); one wavefront per row, fixed summation order.  out = [mean (m) | var (m)]
+__global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const double *P, long long ldp, const double *Q,
+                                                         long long ldq, const double *w, const double *diag, double *out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= m) return;
+    double a1 = 0.0, a2 = 0.0;
+    for (int j = lane; j < n; j += 64) {
+        const double pv = P[(long long)row * ldp + j];
+        a1 += pv * w[j];
+        if (Q) a2 += pv * Q[(long long)row * ldq + j];
+    }
+    for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
+    if (lane == 0) {
+        out[row] = a1;
+        if (Q) out[m + row] = fmax(diag[row] - a2, 0.0);
+    }
+}
+
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
 __global__ void gemv_t_partial_kernel(int n, int ncols, const double *a, long long lda, const double *x, double *part,
                                       int rows_per) {
@@ -645,6 +664,15 @@ extern "C" int gpr_rowdot(void *stream, int m, int n, const double *a, long long
     GPR_REQUIRE(out && (n == 0 || (a && b && lda >= n && ldb >= n)), "gpr_rowdot: bad arguments");
     hipLaunchKernelGGL(rowdot_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, a, lda, b, ldb, out);
     LAUNCH_CHECK("rowdot");
+    return GPR_OK;
+}
+
+extern "C" int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, const double *Q, long long ldq,
+                             const double *w, const double *diag, double *out) {
+    if (m <= 0) return GPR_OK;
+    GPR_REQUIRE(out && P && w && ldp >= n && (!Q || (diag && ldq >= n)), "gpr_ws_finish: bad arguments");
+    hipLaunchKernelGGL(ws_finish_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, P, ldp, Q, ldq, w, diag, out);
+    LAUNCH_CHECK("ws_finish");
     return GPR_OK;
 }
 

@@ -110,7 +110,8 @@ struct dfeat_args {
 constexpr int DF_ROWS = 32;      // rows staged per pass (16 lanes per row: the first 512 threads stage)
 constexpr int DF_LD = 33;        // padded row stride of the staged operands (doubles)
 
-__global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A) {
+template <int NS, int THREADS>
+__global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_args A) {
     __shared__ double sA[DF_ROWS * DF_LD];            // a~ (native norm)
     __shared__ double sD[3][DF_ROWS * DF_LD];         // D / n per component
     __shared__ double sP[DF_ROWS][4];                 // proj[3], s
@@ -122,9 +123,9 @@ __global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A)
     int k = 0, m = 0;
     if (act) { while ((k + 1) * (k + 2) / 2 <= e) k++; m = e - k * (k + 1) / 2; }
     const double wgt = (k == m) ? 1.0 : 1.4142135623730951;
-    double acc[FEAT_MAX_SPECIES][3], ace[FEAT_MAX_SPECIES][3], cnt[FEAT_MAX_SPECIES];
+    double acc[NS][3], ace[NS][3], cnt[NS];
 #pragma unroll
-    for (int s = 0; s < FEAT_MAX_SPECIES; s++) {
+    for (int s = 0; s < NS; s++) {
         cnt[s] = 0.0;
         acc[s][0] = acc[s][1] = acc[s][2] = 0.0; ace[s][0] = ace[s][1] = ace[s][2] = 0.0;
     }
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A)
                     const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
                     if (stager && kk < 32) sD[c][slot * DF_LD + kk] = dv[u];
                 }
-                if (stager && g < 3) sP[slot][g] = pr[g];
+                if (stager && g < 3) sP[slot][g] = (g == 0) ? pr[0] : (g == 1 ? pr[1] : pr[2]);
             }
             if (stager && g == 0) {
                 sP[slot][3] = n / (n + 1e-8);
@@ -213,8 +214,8 @@ __global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A)
                 v[0] = live * wgt * ak * am;
             }
 #pragma unroll
-            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
-                if (s < A.ns && el == A.species[s]) {
+            for (int s = 0; s < NS; s++)
+                if (el == A.species[s]) {
                     acc[s][0] += v[0]; acc[s][1] += v[1]; acc[s][2] += v[2];
                     ace[s][0] += ve[0]; ace[s][1] += ve[1]; ace[s][2] += ve[2];
                     cnt[s] += live;
@@ -229,8 +230,7 @@ __global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A)
         for (int q = 0; q < nq; q++) {
             double *o = A.out + (long long)(p * nq + q) * A.ld;
 #pragma unroll
-            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
-                if (s < A.ns) {
+            for (int s = 0; s < NS; s++) {
                     o[s * A.npair + e] = scale * acc[s][q];
                     if (e == 0) o[A.ns * A.npair + s] = (A.nc == 4) ? 0.0 : A.sigma0 * cnt[s] * inv_cnt;
                 }
@@ -240,10 +240,9 @@ __global__ void __launch_bounds__(576) dot2_features_direct_kernel(dfeat_args A)
         double dq[3] = {0.0, 0.0, 0.0};
         if (act)
 #pragma unroll
-            for (int s = 0; s < FEAT_MAX_SPECIES; s++)
-                if (s < A.ns)
+            for (int s = 0; s < NS; s++)
 #pragma unroll
-                    for (int q = 0; q < 3; q++) dq[q] += ace[s][q] * ace[s][q];
+                for (int q = 0; q < 3; q++) dq[q] += ace[s][q] * ace[s][q];
 #pragma unroll
         for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -338,8 +337,19 @@ extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts
     for (int s = 0; s < FEAT_MAX_SPECIES; s++) A.species[s] = s < ns ? species_host[s] : 0;
     A.sigma0 = sigma0; A.sigma2 = sigma * sigma; A.out = psi; A.ld = ld; A.diag = diag;
     const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
-    const int threads = std::max(512, ((npair + 63) / 64) * 64);
-    hipLaunchKernelGGL(dot2_features_direct_kernel, dim3(npts), dim3(threads), 0, st, A);
+    const bool wide = npair > 512;
+#define GPR_DF_LAUNCH(NSV)                                                                                         \
+    do {                                                                                                           \
+        if (wide) hipLaunchKernelGGL((dot2_features_direct_kernel<NSV, 576>), dim3(npts), dim3(576), 0, st, A);   \
+        else hipLaunchKernelGGL((dot2_features_direct_kernel<NSV, 512>), dim3(npts), dim3(512), 0, st, A);        \
+    } while (0)
+    switch (ns) {
+        case 1: GPR_DF_LAUNCH(1); break;
+        case 2: GPR_DF_LAUNCH(2); break;
+        case 3: GPR_DF_LAUNCH(3); break;
+        default: GPR_DF_LAUNCH(4); break;
+    }
+#undef GPR_DF_LAUNCH
     if (width == 0 && diag) hipLaunchKernelGGL(dot2_diag_ee_direct_kernel, dim3(npts), dim3(256), 0, st, A);
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();

@@ -341,9 +341,19 @@ def dot2_features(pset, species, sigma0, out=None):
     return out
 
 
-def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True):
+def ws_finish(P, w, Q=None, diag=None):
+    """[mean | var] = [P w | max(diag - rowsum(Q o P), 0)] as one [2, m] (or [1, m]) device tensor (gpr_ws_finish)"""
+    m, n = P.shape
+    out = torch.empty((2 if Q is not None else 1, m), dtype=F64, device=P.device)
+    check(_lib.lib().gpr_ws_finish(stream_ptr(), m, n, ptr(P), int(P.stride(0)), ptr(Q),
+                                   int(Q.stride(0)) if Q is not None else 0, ptr(w), ptr(diag), ptr(out)), "gpr_ws_finish")
+    return out
+
+
+def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True, psi_out=None, diag_out=None):
     """(Psi rows, prior variances) of the points of an unpacked SetPair straight from its row tensors and
-    index arrays (gpr_dot2_features_direct): [npts, F] / [npts] for energies, [3 npts, F] / [3 npts] for forces"""
+    index arrays (gpr_dot2_features_direct): [npts, F] / [npts] for energies, [3 npts, F] / [3 npts] for forces;
+    psi_out / diag_out: preallocated row windows to write into"""
     species = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
     ns = len(species)
     d = int(pair.x.shape[1])
@@ -352,12 +362,13 @@ def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True):
         raise ValueError("direct features take dxdr[rows, d, 3]")
     F = ns * (d * (d + 1) // 2 + 1)
     rows = pair.npts * (3 if width else 1)
-    psi = torch.empty((rows, F), dtype=F64, device=device())
-    diag = torch.empty(rows, dtype=F64, device=device()) if want_diag else None
+    psi = psi_out if psi_out is not None else torch.empty((rows, F), dtype=F64, device=device())
+    diag = (diag_out if diag_out is not None else torch.empty(rows, dtype=F64, device=device())) if want_diag else None
+    assert tuple(psi.shape) == (rows, F) and psi.stride(1) == 1 and (diag is None or diag.shape[0] == rows)
     check(_lib.lib().gpr_dot2_features_direct(
         stream_ptr(), d, width, pair.npts, ptr(pair.row0_dev()), ptr(pair.x_index), ptr(pair.dxdr_index),
         ptr(pair.x), ptr(pair.dxdr), ptr(pair.ele), ns, species.ctypes.data_as(_lib.c_int_p), float(sigma),
-        float(sigma0), ptr(psi), F, ptr(diag)), "gpr_dot2_features_direct")
+        float(sigma0), ptr(psi), int(psi.stride(0)), ptr(diag)), "gpr_dot2_features_direct")
     return psi, diag
 
 

@@ -283,11 +283,8 @@ class GP():
             pd = self.kernel.psi_diag_dev(X, ws[0], want_diag=return_std)
             if pd is not None:
                 P, diag = pd
-                mean = dev.gemm(P, ws[2]).reshape(-1)
-                if not return_std:
-                    return mean, None
-                var = diag - dev.rowdot(dev.gemm(P, ws[1]), P)
-                return mean, torch.clamp_min(var, 0.0)
+                out = dev.ws_finish(P, ws[2], dev.gemm(P, ws[1]) if return_std else None, diag)
+                return out[0], (out[1] if return_std else None)
         if ws is not None and self.weight_space_mean:
             # Dot kernel at zeta = 2: K_trans alpha = Psi* (sigma^2 Psi^T alpha) = Psi* w, w built once per fit
             mean = dev.gemm(self.kernel._psi(X, ws[0]), ws[2]).reshape(-1)
@@ -625,7 +622,11 @@ class GP():
             X, frees = self._batch_data_dev([strucs[k] for k in mine])
             mean, var = self._predict_dev(X, self.get_train_x(), f_tol, return_std)
             if return_std:                                          # one download for both
-                both = torch.stack((mean, var)).cpu().numpy()
+                base = mean._base
+                if base is not None and base is var._base and tuple(base.shape) == (2, mean.numel()):
+                    both = base.cpu().numpy()                       # [mean | var] already share one buffer
+                else:
+                    both = torch.stack((mean, var)).cpu().numpy()
                 mean, std = both[0], np.sqrt(both[1])
             else:
                 mean, std = mean.cpu().numpy(), None

@@ -80,7 +80,7 @@ class Dot_mb(DeviceKernel):
         """(Psi, diag) of a data dictionary whose entries are unpacked device SetPairs (the batch-prediction
         form): features and prior variances in one pass over the descriptor output, no packed sets
         (csrc/features.hip, gpr_dot2_features_direct).  None when an entry is not in that form."""
-        parts, diags = [], []
+        ents = []
         for key in ("energy", "force"):
             if key in data and n_points(data[key]) > 0:
                 ent = data[key]
@@ -88,15 +88,20 @@ class Dot_mb(DeviceKernel):
                     return None
                 if ent.dxdr is not None and int(ent.dxdr.shape[-1]) != 3:
                     return None
-                psi, dg = dev.dot2_features_direct(ent, species, self.sigma, self.sigma0 if key == "energy" else 0.0,
-                                                   want_diag)
-                parts.append(psi); diags.append(dg)
-        if not parts:
+                ents.append((ent, ent.npts * (1 if ent.dxdr is None else 3), self.sigma0 if key == "energy" else 0.0))
+        if not ents:
             return None
-        P = parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)
-        if not want_diag:
-            return P, None
-        return P, (diags[0] if len(diags) == 1 else torch.cat(diags))
+        d = int(ents[0][0].x.shape[1])
+        F = len(species) * (d * (d + 1) // 2 + 1)
+        rows = sum(e[1] for e in ents)
+        P = torch.empty((rows, F), dtype=dev.F64, device=dev.device())      # both parts write into one buffer
+        diag = torch.empty(rows, dtype=dev.F64, device=dev.device()) if want_diag else None
+        r0 = 0
+        for ent, n, s0 in ents:
+            dev.dot2_features_direct(ent, species, self.sigma, s0, want_diag, psi_out=P[r0:r0 + n],
+                                     diag_out=None if diag is None else diag[r0:r0 + n])
+            r0 += n
+        return P, diag
 
     def _feature_path(self, data1, data2, zeta_ee):
         if not self.use_feature_map or float(zeta_ee) != 2.0:

@@ -264,6 +264,10 @@ int gpr_colsumsq(void *stream, int n, int ncols, const double *v, long long ldv,
  * kernel: psi^T M psi for every predicted quantity) */
 int gpr_rowdot(void *stream, int m, int n, const double *a, long long lda, const double *b, long long ldb,
                double *out);
+/* Tail of the weight-space prediction (Dot kernel, zeta = 2): out[i] = P[i,:] . w (mean) and, when Q = P M is
+ * given, out[m+i] = max(diag[i] - Q[i,:] . P[i,:], 0) (variance, gaussianprocess.py:903-907), one pass */
+int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, const double *Q, long long ldq,
+                  const double *w, const double *diag, double *out);
 /* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
  * gaussianprocess.py:196-198), deterministic reduction order */
 int gpr_frob_dot(void *stream, int m, int n, const double *a, long long lda, const double *b,
