@@ -455,6 +455,7 @@ extern "C" int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *ce
         return GPR_OK;
     }
     // device-built: download what was asked for (a synchronising debug / single-structure path)
+    if (!vec && !w && !centre_pair0 && !row_pair0 && !self_row && !seq) return GPR_OK;
     const int n = nb->natoms, P = nb->P, S = nb->S;
     hipStream_t st = nb->st;
     auto dl = [&](void *dst, const void *src, size_t bytes) -> hipError_t {

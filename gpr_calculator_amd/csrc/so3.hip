@@ -20,9 +20,10 @@
 // the power spectrum row needs only the 15 + 45 real numbers
 //     R_nl = sum_m Re[Y_lm conj(ctot_nlm)],   S_nlk = sum_m Re[(grad Y_lm)_k conj(ctot_nlm)]:
 //     dP[(n1,n2,l), k] = u_k (A_n1l R_n2l + A_n2l R_n1l) + B_n1l S_n2lk + B_n2l S_n1lk
-// and dC itself is never formed.  One 256-thread workgroup per centre atom: pass 1 accumulates c_tot over the
-// centre's pairs (one pair per wavefront at a time), pass 2 walks the seq rows (one row per wavefront),
-// re-evaluates the cheap per-pair tables and contracts.  No atomics; the summation order is fixed.
+// and dC itself is never formed; S is evaluated without grad Y either, from Y_{l+-1} and per-centre tables that
+// contract the gradient coefficients (SO3.py:682-707) with c_tot once.  One 256-thread workgroup per centre atom:
+// the per-pair tables (geometry, A, B, Y) are built with lanes over pairs into LDS records, pass 1 sums c_tot
+// from them, pass 2 walks the seq rows (one row per wavefront).  No atomics; the summation order is fixed.
 #include "gpr_internal.h"
 
 namespace {
@@ -218,153 +219,136 @@ struct so3_args {
     double *dxdr;               // [S][d][3]
 };
 
-// dynamic LDS layout (doubles): constant tables NY | CG | NL, c_tot [NLM] cplx, self sums [4][96], and per
-// wavefront: A [32] | B [32] | Y [(lmax+3)^2] cplx | GY [L][M][3] cplx | R [32] | S [96] | Cw [NLM] cplx
-struct so3_lds { int oNY, oCG, oNL, oRI, oCtot, oSelf, oWave, wstride, oA, oB, oY, oGY, oR, oS, oCw, total; };
+constexpr int SO3_PC = 48;       // pairs whose tables are resident in LDS at a time
+constexpr int SO3_NLP = 16;      // padded nmax (lmax+1)
+
+// dynamic LDS layout (doubles).  Per-centre tables: NY | RI | NL constants, c_tot [NLM] cplx, Rf [NL][L] cplx
+// (c_tot folded onto m >= 0), Tf [NL][3][2][LT+1] cplx (gradient coefficients contracted with c_tot, folded onto
+// m' >= 0), self sums [4][96], per wavefront R [16] | S [48]; then SO3_PC pair records of `rec` doubles:
+//   ux uy uz 1/r r fc fc' w | A [16] | B [16] | Y_l^m, 0 <= m <= l <= lmax+1, triangular, cplx
+struct so3_lds { int oNY, oRI, oNL, oCtot, oRf, oTf, oSelf, oRS, oRec, rec, tri, total; };
 __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
-    const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, NLM = nmax * L * M;
+    const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, LT = lmax + 1, NLM = nmax * L * M, NL = nmax * L;
     so3_lds o;
     int off = 0;
     o.oNY = off; off += YW * YW;
-    o.oCG = off; off += L * M * 6;
-    o.oNL = off; off += L;
     o.oRI = off; off += YW * YW;
+    o.oNL = off; off += L;
     off = (off + 1) & ~1;
     o.oCtot = off; off += NLM * 2;
+    o.oRf = off; off += NL * L * 2;
+    o.oTf = off; off += NL * 3 * 2 * (LT + 1) * 2;
     o.oSelf = off; off += SO3_WAVES * 96;
-    o.oWave = off;
-    int w = 0;
-    o.oA = w; w += 32;
-    o.oB = w; w += 32;
-    o.oY = w; w += YW * YW * 2;
-    o.oGY = w; w += L * M * 3 * 2;
-    o.oR = w; w += 32;
-    o.oS = w; w += 96;
-    o.oCw = w; w += NLM * 2;
-    o.wstride = (w + 1) & ~1;
-    o.total = off + SO3_WAVES * o.wstride;
+    o.oRS = off; off += SO3_WAVES * 64;
+    o.tri = (LT + 1) * (LT + 2) / 2;
+    o.rec = 8 + 2 * SO3_NLP + 2 * o.tri;
+    o.oRec = off; off += SO3_PC * o.rec;
+    o.total = off;
     return o;
 }
 
 __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
-    const int YW = P.lmax + 3;                  // row width of the Y table (l, m <= lmax+1, one spare column)
+    const int YW = P.lmax + 3, LT = P.lmax + 1;
     const so3_lds lay = so3_layout(P.nmax, P.lmax);
     const so3_tab tab = so3_table_layout(P.nmax, P.lmax, P.nseg, P.ncheb);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double *sNY = smem + lay.oNY, *sCG = smem + lay.oCG, *sNL = smem + lay.oNL, *sRI = smem + lay.oRI;
-    cplx *ctot = (cplx *)(smem + lay.oCtot);
+    const double *sNY = smem + lay.oNY, *sRI = smem + lay.oRI, *sNL = smem + lay.oNL;
+    cplx *ctot = (cplx *)(smem + lay.oCtot), *sRf = (cplx *)(smem + lay.oRf), *sTf = (cplx *)(smem + lay.oTf);
     double *sSelf = smem + lay.oSelf;
-    double *wbase = smem + lay.oWave + wave * lay.wstride;
-    double *sA = wbase + lay.oA, *sB = wbase + lay.oB, *sR = wbase + lay.oR, *sS = wbase + lay.oS;
-    cplx *sY = (cplx *)(wbase + lay.oY), *sGY = (cplx *)(wbase + lay.oGY), *sCw = (cplx *)(wbase + lay.oCw);
+    double *sR = smem + lay.oRS + wave * 64, *sS = sR + 16;
+    double *recs = smem + lay.oRec;
+    const int REC = lay.rec;
     const int ic = blockIdx.x;
     const int p0 = P.centre_pair0[ic], p1 = P.centre_pair0[ic + 1];
-    {
-        const double *src = P.table + tab.oNY;          // NY | CG | NL | RI are contiguous in the table and in LDS
-        const int ncst = 2 * YW * YW + L * M * 6 + L;
-        for (int e = tid; e < ncst; e += 256) smem[lay.oNY + e] = src[e];
-    }
+    const double *gCG = P.table + tab.oCG;
+    for (int e = tid; e < YW * YW; e += 256) { smem[lay.oNY + e] = P.table[tab.oNY + e]; smem[lay.oRI + e] = P.table[tab.oRI + e]; }
+    for (int e = tid; e < L; e += 256) smem[lay.oNL + e] = P.table[tab.oNL + e];
     __syncthreads();
 
-    auto Ylm = [&](int l, int m) -> cplx {     // any m; zero outside |m| <= l
-        if (m > l || -m > l) return {0.0, 0.0};
-        if (m >= 0) return sY[l * YW + m];
-        cplx v = sY[l * YW - m];
-        const double sgn = ((-m) & 1) ? -1.0 : 1.0;
-        return {sgn * v.re, -sgn * v.im};
-    };
-    // per-pair tables of one wavefront: A_nl, B_nl (lanes over the 2 nmax L radial functions), Y_l^m for
-    // l <= ltop (lanes over m >= 0), and, when GRAD, grad Y_l^m (lanes over (l, m))
-    auto pair_tables = [&](int p, bool grad, double &ux, double &uy, double &uz) {
-        const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
-        const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
-        ux = vx * inv_r; uy = vy * inv_r; uz = vz * inv_r;
-        const double w = P.wj[p];
-        double sarg, carg;
-        sincos(M_PI * r / P.rcut, &sarg, &carg);
-        const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI / P.rcut * sarg;
-        if (lane < 2 * NL) {
-            const double v = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, lane);
-            const double other = __shfl_xor(v, 1);                  // F0 <-> F1 of the same (n, l)
-            const int nl = lane >> 1, l = nl % L;
-            const double norm = sNL[l] * w;                          // SO3.py:206, 221
-            if (lane & 1) sA[nl] = norm * (fc * v + dfc * other);    // v = F1, other = F0
-            else sB[nl] = norm * fc * v;                             // v = F0
+    // Tables of the pairs [c0, c0 + npc): lanes over pairs.  Stage 0: one thread per pair -- geometry and cutoff.
+    // Stage 1: four threads per pair -- three evaluate the radial Chebyshev sums (A_nl, B_nl), one runs the
+    // Legendre / azimuth recurrences (Y_l^m, l <= lmax+1).  Ends with a block barrier.
+    auto build_records = [&](int c0, int npc) {
+        if (tid < npc) {
+            const int p = c0 + tid;
+            double *rec = recs + tid * REC;
+            const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+            const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
+            double sarg, carg;
+            sincos(M_PI * r / P.rcut, &sarg, &carg);
+            rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
+            rec[5] = 0.5 * (carg + 1.0); rec[6] = -0.5 * M_PI / P.rcut * sarg; rec[7] = P.wj[p];
         }
-        const int ltop = grad ? P.lmax + 1 : P.lmax;
-        if (lane <= ltop) {
-            const int m = lane;
-            const double ct = uz, rho = sqrt(ux * ux + uy * uy), st = rho;
-            const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
-            double cm = 1.0, sm = 0.0;                       // cos(m phi), sin(m phi)
-            for (int k = 0; k < m; k++) { const double c2 = cm * cphi - sm * sphi; sm = sm * cphi + cm * sphi; cm = c2; }
-            double pmm = 1.0;                                // P_m^m with the Condon-Shortley phase
-            for (int k = 1; k <= m; k++) pmm *= -(2 * k - 1) * st;
-            double plm2 = 0.0, plm1 = pmm;
-            for (int l = m; l <= ltop; l++) {
-                double plm;
-                if (l == m) plm = pmm;
-                else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
-                else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) * sRI[l * YW + m];
-                if (l > m) { plm2 = plm1; plm1 = plm; }
-                const double nrm = sNY[l * YW + m];
-                sY[l * YW + m] = {nrm * plm * cm, nrm * plm * sm};
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        if (grad) {
-            // gradient of Y_l^m from its covariant spherical components (SO3.py:682-707)
-            for (int e = lane; e < L * M; e += 64) {
-                const int l = e / M, m = e % M - P.lmax;
-                cplx g0 = {0, 0}, gp = {0, 0}, gm = {0, 0};
-                if (l >= 1 && m >= -l && m <= l) {
-                    const double *cg = sCG + e * 6;
-                    g0 = cadd(cscale(Ylm(l + 1, m), cg[0] * inv_r), cscale(Ylm(l - 1, m), cg[1] * inv_r));
-                    gp = cadd(cscale(Ylm(l + 1, m + 1), cg[2] * inv_r), cscale(Ylm(l - 1, m + 1), cg[3] * inv_r));
-                    gm = cadd(cscale(Ylm(l + 1, m - 1), cg[4] * inv_r), cscale(Ylm(l - 1, m - 1), cg[5] * inv_r));
+        __syncthreads();
+        {
+            const int pr = tid >> 2, part = tid & 3;
+            if (pr < npc) {
+                double *rec = recs + pr * REC;
+                if (part < 3) {
+                    const double r = rec[4], fc = rec[5], dfc = rec[6], w = rec[7];
+                    for (int nl = part; nl < NL; nl += 3) {
+                        const double F0 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl);
+                        const double F1 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl + 1);
+                        const double norm = sNL[nl % L] * w;                 // SO3.py:206, 221
+                        rec[8 + nl] = norm * (fc * F1 + dfc * F0);
+                        rec[8 + SO3_NLP + nl] = norm * fc * F0;
+                    }
+                } else {
+                    const double ux = rec[0], uy = rec[1], ct = rec[2];
+                    const double rho = sqrt(ux * ux + uy * uy);
+                    const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
+                    cplx *Y = (cplx *)(rec + 8 + 2 * SO3_NLP);
+                    double cm = 1.0, sm = 0.0, pmm = 1.0;            // cos(m phi), sin(m phi), P_m^m (Condon-Shortley)
+                    for (int m = 0; m <= LT; m++) {
+                        if (m > 0) {
+                            const double c2 = cm * cphi - sm * sphi;
+                            sm = sm * cphi + cm * sphi; cm = c2;
+                            pmm *= -(2 * m - 1) * rho;
+                        }
+                        double plm2 = 0.0, plm1 = pmm;
+                        for (int l = m; l <= LT; l++) {
+                            double plm;
+                            if (l == m) plm = pmm;
+                            else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
+                            else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) * sRI[l * YW + m];
+                            if (l > m) { plm2 = plm1; plm1 = plm; }
+                            const double nrm = sNY[l * YW + m] * plm;
+                            Y[l * (l + 1) / 2 + m] = {nrm * cm, nrm * sm};
+                        }
+                    }
                 }
-                const double is2 = 0.70710678118654752440;
-                cplx dmp = {gm.re - gp.re, gm.im - gp.im}, smp = {gm.re + gp.re, gm.im + gp.im};
-                sGY[e * 3 + 0] = cscale(dmp, is2);
-                sGY[e * 3 + 1] = {-is2 * smp.im, is2 * smp.re};          // i/sqrt(2) * (gm + gp)
-                sGY[e * 3 + 2] = g0;
             }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
         }
+        __syncthreads();
     };
 
-    // ---- pass 1: c_tot.  Each wavefront walks its share of the centre's pairs; lane e accumulates the
-    //      coefficients e, e + 64, e + 128 (< NLM) in registers.  No block barriers inside the loop: all tables
-    //      are wavefront private, ordered by wave_barrier + LDS fences.
+    // ---- pass 1: c_tot[nl][m >= 0] = sum over pairs of B_nl Y_l^m; thread e = (nl, m)
+    const int nchunks = (p1 - p0 + SO3_PC - 1) / SO3_PC;
     {
-        cplx acc[3] = {{0, 0}, {0, 0}, {0, 0}};
-        for (int p = p0 + wave; p < p1; p += SO3_WAVES) {
-            double ux, uy, uz;
-            pair_tables(p, false, ux, uy, uz);
-#pragma unroll
-            for (int rnd = 0; rnd < 3; rnd++) {
-                const int e = lane + 64 * rnd;
-                if (e < NLM) {
-                    const int nl = e / M, l = nl % L, m = e % M - P.lmax;
-                    if (m >= -l && m <= l) acc[rnd] = cadd(acc[rnd], cscale(Ylm(l, m), sB[nl]));
+        const int nl = tid / L, m = tid % L, l = nl % L;
+        const bool mine = tid < NL * L && m <= l;
+        cplx acc = {0.0, 0.0};
+        for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
+            const int npc = min(SO3_PC, p1 - c0);
+            build_records(c0, npc);
+            if (mine)
+                for (int q = 0; q < npc; q++) {
+                    const double *rec = recs + q * REC;
+                    const cplx y = ((const cplx *)(rec + 8 + 2 * SO3_NLP))[l * (l + 1) / 2 + m];
+                    const double b = rec[8 + SO3_NLP + nl];
+                    acc.re += b * y.re; acc.im += b * y.im;
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            if (nchunks > 1) __syncthreads();            // records are rebuilt by the next chunk
         }
-#pragma unroll
-        for (int rnd = 0; rnd < 3; rnd++) { const int e = lane + 64 * rnd; if (e < NLM) sCw[e] = acc[rnd]; }
-        for (int e = lane + 192; e < NLM; e += 64) sCw[e] = {0.0, 0.0};      // NLM > 192 is refused by the host
-    }
-    __syncthreads();
-    for (int e = tid; e < NLM; e += 256) {
-        cplx s = {0.0, 0.0};
-        for (int w2 = 0; w2 < SO3_WAVES; w2++) s = cadd(s, ((cplx *)(smem + lay.oWave + w2 * lay.wstride + lay.oCw))[e]);
-        ctot[e] = s;
+        for (int e = tid; e < NLM; e += 256) ctot[e] = {0.0, 0.0};
+        __syncthreads();
+        if (mine) {
+            ctot[nl * M + P.lmax + m] = acc;
+            if (m > 0) { const double sg = (m & 1) ? -1.0 : 1.0; ctot[nl * M + P.lmax - m] = {sg * acc.re, -sg * acc.im}; }
+            sRf[nl * L + m] = (m == 0) ? acc : cplx{2.0 * acc.re, 2.0 * acc.im};
+        }
     }
     __syncthreads();
 
@@ -387,8 +371,42 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         P.x[(size_t)ic * P.d + c] = s;
     }
 
-    // ---- pass 2: dP rows.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk; both keep their c_tot row
-    //      (n, l, .) in LDS reach.  Lanes e < 3 d then combine into the row's outputs.
+    // ---- gradient coefficients contracted with c_tot (SO3.py:682-707 folded into per-centre tables):
+    //      S_nlk(pair) = (1/r) sum_{side} sum_{m' >= 0} Re[Y_{l', m'} conj(Tf[nl][k][side][m'])], l' = l -/+ 1
+    {
+        const int W = LT + 1, ntf = NL * 3 * 2 * W;
+        for (int e = tid; e < ntf; e += 256) {
+            const int mp = e % W, side = (e / W) % 2, k = (e / (2 * W)) % 3, nl = e / (6 * W), l = nl % L;
+            const int lp = side ? l + 1 : l - 1;
+            cplx out = {0.0, 0.0};
+            if (lp >= 0 && mp <= lp && l >= 1) {
+                auto ctv = [&](int m) -> cplx { return (m >= -l && m <= l) ? ctot[nl * M + P.lmax + m] : cplx{0.0, 0.0}; };
+                auto cgv = [&](int m, int which) -> double {
+                    return (m >= -l && m <= l) ? gCG[((size_t)l * M + (m + P.lmax)) * 6 + which] : 0.0;
+                };
+                auto Tval = [&](int m1) -> cplx {                      // coefficient of Y_{lp, m1}, any sign of m1
+                    const double is2 = 0.70710678118654752440;
+                    if (k == 2) return cscale(ctv(m1), cgv(m1, side ? 0 : 1));
+                    const cplx up = cscale(ctv(m1 + 1), cgv(m1 + 1, side ? 4 : 5) * is2);      // from gm of (l, m1+1)
+                    const cplx dn = cscale(ctv(m1 - 1), cgv(m1 - 1, side ? 2 : 3) * is2);      // from gp of (l, m1-1)
+                    if (k == 0) return {up.re - dn.re, up.im - dn.im};
+                    const cplx sm = {up.re + dn.re, up.im + dn.im};
+                    return {sm.im, -sm.re};                                // -i (up + dn)
+                };
+                out = Tval(mp);
+                if (mp > 0) {
+                    const cplx t2 = Tval(-mp);
+                    const double sg = (mp & 1) ? -1.0 : 1.0;
+                    out.re += sg * t2.re; out.im -= sg * t2.im;
+                }
+            }
+            sTf[e] = out;
+        }
+    }
+    __syncthreads();
+
+    // ---- pass 2: dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
+    //      lanes e < 3 d then combine into the row's outputs.
     const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1], rself = P.self_row[ic];
     const int ne = P.d * 3;
     int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
@@ -405,40 +423,59 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         e_k[rnd] = e % 3; iA1[rnd] = n1 * L + l; iA2[rnd] = n2 * L + l;
     }
     double self0 = 0.0, self1 = 0.0;
-    for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
-        if (row == rself) continue;
-        const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
-        double s[2] = {0.0, 0.0};
-        for (int p = q0; p < q1; p++) {
-            double ux, uy, uz;
-            pair_tables(p, true, ux, uy, uz);
-            if (has_task) {
-                double acc = 0.0;
-                for (int m = -t_l; m <= t_l; m++) {
-                    const int mi = m + P.lmax;
-                    const cplx y = (t_k < 0) ? Ylm(t_l, m) : sGY[((t_l * M) + mi) * 3 + t_k];
-                    const cplx c = ctot[t_nl * M + mi];
-                    acc += y.re * c.re + y.im * c.im;
+    for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
+        const int npc = min(SO3_PC, p1 - c0), c1 = c0 + npc;
+        if (nchunks > 1) build_records(c0, npc);        // a single chunk is still resident from pass 1
+        for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
+            if (row == rself) continue;
+            const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
+            const int a = max(q0, c0), b = min(q1, c1);
+            if (a >= b) continue;
+            double s[2] = {0.0, 0.0};
+            for (int p = a; p < b; p++) {
+                const double *rec = recs + (p - c0) * REC;
+                const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
+                if (has_task) {
+                    double acc = 0.0;
+                    if (t_k < 0) {
+                        const cplx *rf = sRf + t_nl * L;
+                        for (int m = 0; m <= t_l; m++) { const cplx y = Y[t_l * (t_l + 1) / 2 + m]; acc += y.re * rf[m].re + y.im * rf[m].im; }
+                        sR[t_nl] = acc;
+                    } else {
+                        const int W = LT + 1;
+                        const cplx *tf = sTf + ((t_nl * 3 + t_k) * 2) * W;
+                        if (t_l >= 1) {
+                            const int lp = t_l - 1;
+                            for (int m = 0; m <= lp; m++) { const cplx y = Y[lp * (lp + 1) / 2 + m]; acc += y.re * tf[m].re + y.im * tf[m].im; }
+                            const int lq = t_l + 1;
+                            for (int m = 0; m <= lq; m++) { const cplx y = Y[lq * (lq + 1) / 2 + m]; acc += y.re * tf[W + m].re + y.im * tf[W + m].im; }
+                        }
+                        sS[t_nl * 3 + t_k] = acc * rec[3];
+                    }
                 }
-                if (t_k < 0) sR[t_nl] = acc; else sS[t_nl * 3 + t_k] = acc;
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
 #pragma unroll
-            for (int rnd = 0; rnd < 2; rnd++) {
+                for (int rnd = 0; rnd < 2; rnd++) {
+                    if (lane + 64 * rnd < ne) {
+                        const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
+                        const double *A = rec + 8, *B = rec + 8 + SO3_NLP;
+                        s[rnd] += rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+            }
+#pragma unroll
+            for (int rnd = 0; rnd < 2; rnd++)
                 if (lane + 64 * rnd < ne) {
-                    const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
-                    const double uk = (k == 0) ? ux : (k == 1 ? uy : uz);
-                    s[rnd] += uk * (sA[a1] * sR[a2] + sA[a2] * sR[a1]) + sB[a1] * sS[a2 * 3 + k] + sB[a2] * sS[a1 * 3 + k];
+                    double *o = P.dxdr + (size_t)row * ne + lane + 64 * rnd;
+                    // a row whose pairs straddle a chunk boundary: this lane wrote the earlier part itself
+                    *o = (q0 < c0) ? *o + s[rnd] : s[rnd];
                 }
-            }
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
+            self0 += s[0]; self1 += s[1];
         }
-#pragma unroll
-        for (int rnd = 0; rnd < 2; rnd++)
-            if (lane + 64 * rnd < ne) P.dxdr[(size_t)row * ne + lane + 64 * rnd] = s[rnd];
-        self0 += s[0]; self1 += s[1];
+        if (nchunks > 1) __syncthreads();
     }
     sSelf[wave * 96 + lane] = self0;
     if (lane < 32) sSelf[wave * 96 + 64 + lane] = self1;
@@ -535,9 +572,14 @@ extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double r
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
     const so3_lds lay = so3_layout(nmax, lmax);
     const size_t lds_bytes = (size_t)lay.total * sizeof(double);
-    if (lds_bytes > 64 * 1024) {
+    if (lds_bytes > 96 * 1024) {
         gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d) needs %zu bytes of LDS", nmax, lmax, lds_bytes);
         return GPR_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        attr_set = true;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
     hipLaunchKernelGGL(so3_centre_kernel, dim3(ncentres), dim3(256), lds_bytes, st, A);

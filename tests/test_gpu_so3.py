@@ -121,3 +121,21 @@ def test_radial_chebyshev_table_matches_direct_quadrature(cfg):
         F1 = E[:, None] * (dI - 2 * alpha * r[:, None] * I)
         assert (np.abs(direct[:, :, l, 0] - F0) / scale[0, :, l, 0]).max() < 1e-12
         assert (np.abs(direct[:, :, l, 1] - F1) / scale[0, :, l, 1]).max() < 1e-11
+
+
+@pytest.mark.parametrize("scale", [1.0, 0.78], ids=["2chunks", "3chunks"])
+def test_so3_dense_small_cell_matches_oracle(scale):
+    """a 2-atom skewed cell at rcut = 5: 56 / ~120 neighbour pairs per centre and ~30 / ~60 periodic images per seq
+    row, so the kernel's pair tables are rebuilt in several chunks of 48 and rows straddle chunk boundaries"""
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    from oracle.so3_numpy import so3_calculate
+    s = SimpleAtoms(numbers=[46, 78], positions=np.array([[0.1, 0.2, 0.3], [1.2, 1.1, 1.4]]) * scale,
+                    cell=np.array([[2.6, 0, 0], [0.9, 2.5, 0], [0.3, 0.4, 2.7]]) * scale, pbc=[True, True, True])
+    des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
+    nb = des.neighbor_index_batch([s])
+    assert np.diff(nb["centre_pair0"]).min() > (48 if scale == 1.0 else 96) and np.diff(nb["row_pair0"]).max() > 20
+    out = des.calculate(s)
+    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, 3, 4, 5.0, 2.0)
+    assert np.array_equal(out["seq"], ref["seq"])
+    assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL

@@ -42,3 +42,33 @@ torch.cuda.synchronize(); tot = (time.perf_counter() - t0) / N * 1e3
 print(f"step {tot:.3f} ms")
 for k, v in sorted(acc.items(), key=lambda kv: -kv[1]):
     print(f"{k:32s} {v / N * 1e3:8.3f} ms  x{cnt[k] / N:.0f}")
+
+# ---- finer split of the descriptor front end (host view)
+import ctypes as C
+from gpr_calculator_amd import _lib
+from gpr_calculator_amd.neighbors import atoms_arrays
+def split(n=20):
+    t = collections.defaultdict(float)
+    for _ in range(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); arrs = [atoms_arrays(s) for s in batch]; t1 = time.perf_counter()
+        atom0 = np.zeros(len(arrs) + 1, dtype=np.int64); np.cumsum([len(a[0]) for a in arrs], out=atom0[1:])
+        a0 = atom0.astype(np.int32)
+        numbers = np.ascontiguousarray(np.concatenate([a[0] for a in arrs]), dtype=np.int32)
+        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
+        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
+        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32)
+        t2 = time.perf_counter()
+        L = _lib.lib(); h = C.c_void_p()
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p); dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        L.gpr_nbr_build_device(C.byref(h), dev.stream_ptr(), len(arrs), ip(a0), dp(pos), dp(cells), ip(pbc), ip(numbers), 5.0, 0)
+        t3 = time.perf_counter()
+        L.gpr_nbr_destroy(h)
+        t4 = time.perf_counter()
+        nb = gp.descriptor.neighbor_batch_dev(batch); t5 = time.perf_counter()
+        fr = nb.force_rows(np.arange(nb.natoms)); t6 = time.perf_counter()
+        desc = gp.descriptor.calculate_batch_dev(batch, nbr=nb); t7 = time.perf_counter()
+        t["atoms_arrays x64"] += t1 - t0; t["concat"] += t2 - t1; t["gpr_nbr_build_device"] += t3 - t2
+        t["destroy"] += t4 - t3; t["NeighborBatch total"] += t5 - t4; t["force_rows"] += t6 - t5; t["so3 launch"] += t7 - t6
+    for k, v in t.items(): print(f"  {k:28s} {v / n * 1e3:7.3f} ms")
+split()
