@@ -182,7 +182,7 @@ __global__ void so3_const_tables_kernel(int lmax, double *NY, double *CG, double
 }
 
 // Clenshaw evaluation of function f of the piecewise Chebyshev table at radius r
-__device__ __forceinline__ double cheb_eval(const double *cheb, int nseg, int NF, double rcut, double r, int f) {
+__device__ __noinline__ double cheb_eval(const double *cheb, int nseg, int NF, double rcut, double r, int f) {
     int seg = (int)(r * nseg / rcut);
     seg = seg < 0 ? 0 : (seg > nseg - 1 ? nseg - 1 : seg);
     const double inv_half = 2.0 * nseg / rcut, mid = (seg + 0.5) * rcut / nseg;
@@ -205,8 +205,17 @@ __global__ void so3_radial_eval_kernel(const double *cheb, int nseg, int ncheb, 
 }
 
 // ---------------------------------------------------------------- descriptor kernel
+// Ordering of wavefront-private LDS traffic between lanes of one wavefront: the LDS queue is in order, so draining
+// it (and stopping the compiler from moving memory operations across) is enough.  A workgroup fence would also
+// wait for the outstanding global stores of the previous row (vmcnt), i.e. put HBM write latency into the loop.
+__device__ __forceinline__ void so3_wave_lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
 struct so3_args {
-    int nmax, lmax, d, nseg, ncheb;
+    int nmax, lmax, d, nseg, ncheb, dbg;
     double rcut, alpha;
     const double *table;        // so3_table_layout
     const double *vec;          // [P][3] neighbour displacement
@@ -277,7 +286,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
             const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
             const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
             double sarg, carg;
-            sincos(M_PI * r / P.rcut, &sarg, &carg);
+            sincospi(r / P.rcut, &sarg, &carg);             // cutoff 0.5 (cos(pi r / rcut) + 1) and its derivative
             rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
             rec[5] = 0.5 * (carg + 1.0); rec[6] = -0.5 * M_PI / P.rcut * sarg; rec[7] = P.wj[p];
         }
@@ -333,6 +342,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
             const int npc = min(SO3_PC, p1 - c0);
             build_records(c0, npc);
+            if (P.dbg == 1) return;
             if (mine)
                 for (int q = 0; q < npc; q++) {
                     const double *rec = recs + q * REC;
@@ -405,6 +415,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
     }
     __syncthreads();
 
+    if (P.dbg == 2) return;
     // ---- pass 2: dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
     //      lanes e < 3 d then combine into the row's outputs.
     const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1], rself = P.self_row[ic];
@@ -436,25 +447,29 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                 const double *rec = recs + (p - c0) * REC;
                 const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
                 if (has_task) {
+                    // fixed-length, predicated sums: every LDS load of the task is issued before the first add
                     double acc = 0.0;
                     if (t_k < 0) {
-                        const cplx *rf = sRf + t_nl * L;
-                        for (int m = 0; m <= t_l; m++) { const cplx y = Y[t_l * (t_l + 1) / 2 + m]; acc += y.re * rf[m].re + y.im * rf[m].im; }
+                        const cplx *rf = sRf + t_nl * L, *yl = Y + t_l * (t_l + 1) / 2;
+#pragma unroll
+                        for (int m = 0; m < SO3_LCAP; m++)
+                            if (m <= t_l) { const cplx y = yl[m], c = rf[m]; acc += y.re * c.re + y.im * c.im; }
                         sR[t_nl] = acc;
                     } else {
                         const int W = LT + 1;
                         const cplx *tf = sTf + ((t_nl * 3 + t_k) * 2) * W;
-                        if (t_l >= 1) {
-                            const int lp = t_l - 1;
-                            for (int m = 0; m <= lp; m++) { const cplx y = Y[lp * (lp + 1) / 2 + m]; acc += y.re * tf[m].re + y.im * tf[m].im; }
-                            const int lq = t_l + 1;
-                            for (int m = 0; m <= lq; m++) { const cplx y = Y[lq * (lq + 1) / 2 + m]; acc += y.re * tf[W + m].re + y.im * tf[W + m].im; }
-                        }
+                        const int lp = t_l - 1, lq = t_l + 1;
+                        const cplx *y0 = Y + (lp > 0 ? lp * (lp + 1) / 2 : 0), *y1 = Y + lq * (lq + 1) / 2;
+#pragma unroll
+                        for (int m = 0; m < SO3_LCAP - 1; m++)
+                            if (m <= lp) { const cplx y = y0[m], c = tf[m]; acc += y.re * c.re + y.im * c.im; }
+#pragma unroll
+                        for (int m = 0; m < SO3_LCAP + 1; m++)
+                            if (m <= lq && t_l >= 1) { const cplx y = y1[m], c = tf[W + m]; acc += y.re * c.re + y.im * c.im; }
                         sS[t_nl * 3 + t_k] = acc * rec[3];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
+                so3_wave_lds_sync();
 #pragma unroll
                 for (int rnd = 0; rnd < 2; rnd++) {
                     if (lane + 64 * rnd < ne) {
@@ -463,8 +478,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                         s[rnd] += rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                __threadfence_block();
+                so3_wave_lds_sync();
             }
 #pragma unroll
             for (int rnd = 0; rnd < 2; rnd++)
@@ -568,6 +582,7 @@ extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double r
     (void)nrows;
     so3_args A;
     A.nmax = nmax; A.lmax = lmax; A.d = d; A.nseg = nseg; A.ncheb = ncheb; A.rcut = rcut; A.alpha = alpha;
+    { const char *dbg = getenv("GPR_SO3_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }   // phase ablation for profiling only
     A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
     const so3_lds lay = so3_layout(nmax, lmax);
