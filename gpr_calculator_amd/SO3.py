@@ -378,6 +378,10 @@ class NeighborBatch:
         """int32 device view of the atomic numbers is not exposed as a tensor; upload the host copy"""
         return dev.to_dev(self.numbers, torch.int32)
 
+    def status_into(self, slot):
+        """queue the missing-row count (as a double) into the one-element device tensor `slot`"""
+        dev.check(_lib.lib().gpr_nbr_status_to(self._h, dev.ptr(slot)), "gpr_nbr_status_to")
+
     def check(self):
         n = C.c_int()
         dev.check(_lib.lib().gpr_nbr_check(self._h, C.byref(n)), "gpr_nbr_check")

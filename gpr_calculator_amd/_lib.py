@@ -56,6 +56,7 @@ _L1_SIGNATURES = {
     "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 8, _i),
     "gpr_nbr_force_rows": ([_vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gpr_nbr_check": ([_vp, c_int_p], _i),
+    "gpr_nbr_status_to": ([_vp, _vp], _i),
     "gpr_nbr_build": ([C.POINTER(_vp), _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),
     "gpr_nbr_export": ([_vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p], _i),

@@ -430,6 +430,19 @@ extern "C" int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_
     return GPR_OK;
 }
 
+namespace {
+__global__ void nbr_status_kernel(const int *err, double *dst) { dst[0] = (double)err[0]; }
+}
+
+// device-side variant of gpr_nbr_check: writes the count (as a double) into dst[0] on the handle's stream, so that it
+// can travel with the caller's own result download instead of costing a synchronisation of its own
+extern "C" int gpr_nbr_status_to(const gpr_nbr *nb, double *dst_dev) {
+    GPR_REQUIRE(nb && nb->on_device && dst_dev, "gpr_nbr_status_to: needs a device-built handle and a device pointer");
+    hipLaunchKernelGGL(nbr_status_kernel, dim3(1), dim3(1), 0, nb->st, nb->d_err, dst_dev);
+    GPR_HIP_TRY(hipGetLastError());
+    return GPR_OK;
+}
+
 extern "C" int gpr_nbr_check(const gpr_nbr *nb, int *nmissing) {
     GPR_REQUIRE(nb && nb->on_device && nmissing, "gpr_nbr_check: needs a device-built handle");
     GPR_HIP_TRY(hipMemcpyAsync(nmissing, nb->d_err, sizeof(int), hipMemcpyDeviceToHost, nb->st));

@@ -341,13 +341,17 @@ def dot2_features(pset, species, sigma0, out=None):
     return out
 
 
-def ws_finish(P, w, Q=None, diag=None):
-    """[mean | var] = [P w | max(diag - rowsum(Q o P), 0)] as one [2, m] (or [1, m]) device tensor (gpr_ws_finish)"""
+def ws_finish(P, w, Q=None, diag=None, tail=0):
+    """[mean | var] = [P w | max(diag - rowsum(Q o P), 0)] as one [2, m] (or [1, m]) device tensor (gpr_ws_finish);
+    with tail > 0 returns (out, flat) where flat is the 1-D buffer [mean | var | tail words]: status words that should
+    ride along with the result download go into its last `tail` slots"""
     m, n = P.shape
-    out = torch.empty((2 if Q is not None else 1, m), dtype=F64, device=P.device)
+    k = 2 if Q is not None else 1
+    flat = torch.empty(k * m + tail, dtype=F64, device=P.device)
+    out = flat[:k * m].view(k, m)
     check(_lib.lib().gpr_ws_finish(stream_ptr(), m, n, ptr(P), int(P.stride(0)), ptr(Q),
                                    int(Q.stride(0)) if Q is not None else 0, ptr(w), ptr(diag), ptr(out)), "gpr_ws_finish")
-    return out
+    return (out, flat) if tail else out
 
 
 def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True, psi_out=None, diag_out=None):

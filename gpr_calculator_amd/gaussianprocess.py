@@ -272,7 +272,7 @@ class GP():
         self.fits += 1
 
     # ------------------------------------------------------------------ prediction
-    def _predict_dev(self, X, train_x, f_tol, return_std):
+    def _predict_dev(self, X, train_x, f_tol, return_std, want_flat=False):
         """mean [m] (and variance [m]) of the quantities in X on the device.
         K(train, X) = K_trans^T is built directly (structures streamed, training set resident)."""
         ws = self._weight_space()
@@ -283,8 +283,9 @@ class GP():
             pd = self.kernel.psi_diag_dev(X, ws[0], want_diag=return_std)
             if pd is not None:
                 P, diag = pd
-                out = dev.ws_finish(P, ws[2], dev.gemm(P, ws[1]) if return_std else None, diag)
-                return out[0], (out[1] if return_std else None)
+                out, flat = dev.ws_finish(P, ws[2], dev.gemm(P, ws[1]) if return_std else None, diag, tail=1)
+                res = (out[0], out[1] if return_std else None)
+                return res + (flat,) if want_flat else res
         if ws is not None and self.weight_space_mean:
             # Dot kernel at zeta = 2: K_trans alpha = Psi* (sigma^2 Psi^T alpha) = Psi* w, w built once per fit
             mean = dev.gemm(self.kernel._psi(X, ws[0]), ws[2]).reshape(-1)
@@ -295,7 +296,7 @@ class GP():
                 Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
             mean = dev.gemv_t(Kt, self._alpha_dev)                                # K_trans alpha
         if not return_std:
-            return mean, None
+            return (mean, None, None) if want_flat else (mean, None)
         var = self.kernel.diag_dev(X)
         if ws is not None:
             # Dot kernel at zeta = 2: k = sigma^2 Psi psi, so |L^-1 k|^2 = psi^T M psi with the F x F matrix
@@ -308,7 +309,8 @@ class GP():
                 Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
             V = dev.trmm_lower(self._Linv(), Kt)                                  # V = L^-1 K_trans^T
             var = var - dev.colsumsq(V)
-        return mean, torch.clamp_min(var, 0.0)
+        var = torch.clamp_min(var, 0.0)
+        return (mean, var, None) if want_flat else (mean, var)
 
     # mean of the Dot feature path evaluated in weight space (Psi* w) instead of K_trans alpha: same number,
     # summed over features instead of training points
@@ -620,18 +622,24 @@ class GP():
         results = {}
         if mine:
             X, frees = self._batch_data_dev([strucs[k] for k in mine])
-            mean, var = self._predict_dev(X, self.get_train_x(), f_tol, return_std)
-            if return_std:                                          # one download for both
-                base = mean._base
-                if base is not None and base is var._base and tuple(base.shape) == (2, mean.numel()):
-                    both = base.cpu().numpy()                       # [mean | var] already share one buffer
-                else:
-                    both = torch.stack((mean, var)).cpu().numpy()
-                mean, std = both[0], np.sqrt(both[1])
+            mean, var, flat = self._predict_dev(X, self.get_train_x(), f_tol, return_std, want_flat=True)
+            nbr = getattr(X["force"], "_nbr", None) if "force" in X else None
+            if flat is not None:
+                # [mean | var | status] share one buffer (weight-space path): one download, no extra synchronisation
+                if nbr is not None:
+                    nbr.status_into(flat[-1:])
+                host = flat.cpu().numpy()
+                if nbr is not None and host[-1] != 0.0:
+                    raise RuntimeError(f"neighbour table is not symmetric: {int(host[-1])} force rows missing")
+                m_ = mean.numel()
+                mean, std = host[:m_], (np.sqrt(host[m_:2 * m_]) if return_std else None)
             else:
-                mean, std = mean.cpu().numpy(), None
-            if "force" in X and getattr(X["force"], "_nbr", None) is not None:
-                X["force"]._nbr.check()
+                if return_std:
+                    mean, std = mean.cpu().numpy(), np.sqrt(var.cpu().numpy())
+                else:
+                    mean, std = mean.cpu().numpy(), None
+                if nbr is not None:
+                    nbr.check()
             nS = len(mine)
             off = nS
             for s, k in enumerate(mine):

@@ -200,6 +200,8 @@ int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const 
                        int *row_index_dev, int *x_index_dev);
 /* number of (i, a) rows gpr_nbr_force_rows could not find (0 unless the symmetry above is broken); synchronises */
 int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
+/* same count written as a double to dst_dev[0] in stream order (rides along with the caller's result download) */
+int gpr_nbr_status_to(const gpr_nbr *nb, double *dst_dev);
 
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
 /* Tables of one descriptor configuration, built on the device once: piecewise Chebyshev coefficients (nseg

@@ -72,3 +72,77 @@ def split(n=20):
         t["destroy"] += t4 - t3; t["NeighborBatch total"] += t5 - t4; t["force_rows"] += t6 - t5; t["so3 launch"] += t7 - t6
     for k, v in t.items(): print(f"  {k:28s} {v / n * 1e3:7.3f} ms")
 split()
+
+def split2(n=50):
+    """statement-level timing of NeighborBatch.__init__ (copied body)"""
+    rcut, weight_on = 5.0, False
+    t = collections.defaultdict(float)
+    L = _lib.lib()
+    for _ in range(n):
+        torch.cuda.synchronize()
+        T = [time.perf_counter()]
+        def tick(): T.append(time.perf_counter())
+        arrs = [atoms_arrays(s) for s in batch]; tick()
+        nstruct = len(arrs)
+        atom0_ = np.zeros(nstruct + 1, dtype=np.int64)
+        np.cumsum([len(a[0]) for a in arrs], out=atom0_[1:])
+        atom0 = atom0_.astype(np.int32); tick()
+        numbers_ = np.concatenate([a[0] for a in arrs]).astype(np.int64)
+        numbers = np.ascontiguousarray(numbers_, dtype=np.int32); tick()
+        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
+        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
+        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32); tick()
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        h = C.c_void_p()
+        sp = dev.stream_ptr(); tick()
+        dev.check(L.gpr_nbr_build_device(C.byref(h), sp, nstruct, ip(atom0), dp(pos), dp(cells), ip(pbc), ip(numbers), rcut, int(weight_on)), "x"); tick()
+        P_, S_ = C.c_int(), C.c_int()
+        dev.check(L.gpr_nbr_sizes(h, C.byref(P_), C.byref(S_)), "x")
+        cr0 = np.empty(int(atom0[-1]) + 1, np.int32); row0 = np.empty(nstruct + 1, np.int32)
+        dev.check(L.gpr_nbr_export(h, None, None, None, ip(cr0), None, None, None, ip(row0)), "x"); tick()
+        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers")
+        raw = [C.c_void_p() for _ in names]
+        dev.check(L.gpr_nbr_device_arrays(h, *[C.byref(r) for r in raw]), "x"); tick()
+        L.gpr_nbr_destroy(h); tick()
+        for k, lab in enumerate(("atoms_arrays", "atom0", "numbers", "pos/cells/pbc", "stream_ptr", "build_device", "sizes+export", "device_arrays", "destroy")):
+            t[lab] += T[k + 1] - T[k]
+    for k, v in t.items(): print(f"    {k:20s} {v / n * 1e3:7.3f} ms")
+split2()
+
+def split3(n=50):
+    """statement-level timing of GP._batch_data_dev + predict tail (copied body)"""
+    t = collections.defaultdict(float)
+    self = gp
+    strucs = batch
+    for _ in range(n):
+        torch.cuda.synchronize()
+        T = [time.perf_counter()]
+        def tick(): T.append(time.perf_counter())
+        nbr = self.descriptor.neighbor_batch_dev(strucs); tick()
+        atom0 = nbr.atom0
+        natoms = int(atom0[-1]); nper = np.diff(atom0)
+        keep = np.ones(natoms, dtype=bool); frees = []
+        for k, s in enumerate(strucs):
+            fix = self._get_fixed_atoms(s)
+            if len(fix):
+                keep[atom0[k] + np.asarray(fix, dtype=np.int64)] = False
+                frees.append([i for i in range(int(nper[k])) if i not in set(fix)])
+            else:
+                frees.append(None)
+        tick()
+        counts_f, row_index, x_index, f_row0 = nbr.force_rows(np.flatnonzero(keep)); tick()
+        meta = np.concatenate((atom0, nbr.numbers)).astype(np.int32)
+        d_meta = dev.to_dev(meta, torch.int32)
+        e_row0, ele = d_meta[:len(atom0)], d_meta[len(atom0):]; tick()
+        desc = self.descriptor.calculate_batch_dev(strucs, nbr=nbr); tick()
+        E = dev.SetPair(desc["x"], None, ele, nper); E._row0_dev = e_row0
+        F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index); F._row0_dev = f_row0; F._nbr = nbr
+        X = {"energy": E, "force": F}; tick()
+        mean, var, flat = self._predict_dev(X, self.get_train_x(), 1e-8, True, want_flat=True); tick()
+        nbr.status_into(flat[-1:]); tick()
+        both = flat.cpu().numpy(); tick()
+        for k, lab in enumerate(("neighbor_batch_dev", "keep/frees loop", "force_rows", "meta upload", "so3 launch", "SetPairs", "_predict_dev", "status_into", "download (waits GPU)")):
+            t[lab] += T[k + 1] - T[k]
+    for k, v in t.items(): print(f"      {k:22s} {v / n * 1e3:7.3f} ms")
+split3()
