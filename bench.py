@@ -194,10 +194,13 @@ def main():
             "gemm": ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
                      2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N"),
             "gemv": ("gemv_t_partial_kernel: K_trans alpha", 2.0 * m_rows * N, "2 m N"),
-            "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives", n_nbr * 21.0e3,
-                    "~21 kflop per neighbour pair (80-node radial quadrature x 5 Bessel orders, Y_lm, dP contraction)"),
-            "features": ("dot2_features_kernel: explicit degree-2 feature map", float(len(ele_rows)) * 465 * 12,
-                         "12 flop per row and packed (k,m) index"),
+            "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives (FP64 vector; no matrix shape)", n_nbr * 4.0e3,
+                    "~4 kflop per neighbour pair (30 Clenshaw sums of 16 terms, Y_lm recurrences, c_tot, R/S "
+                    "contraction and 90 outputs per pair); the reference's own formulation (80-node Bessel quadrature "
+                    "per pair) would be ~21 kflop"),
+            "features": ("dot2_features_direct_kernel: degree-2 feature rows + prior variances (FP64 vector; no matrix "
+                         "shape)", float(len(ele_rows)) * 465 * 66,
+                         "66 flop per descriptor row and packed (k,m) index (native and numpy-eps feature of 3 components)"),
         }
         dom = max((k for k in per_step if k in work), key=lambda k: per_step[k][0])
         name, flops, unit_note = work[dom]

@@ -352,31 +352,42 @@ class NeighborBatch:
         dev.check(L.gpr_nbr_export(self._h, None, None, None, ip(self.centre_row0), None, None, None, ip(row0)),
                   "gpr_nbr_export")
         self.row0 = row0.astype(np.int64)
-        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers")
+        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers", "atom0")
         raw = [C.c_void_p() for _ in names]
         dev.check(L.gpr_nbr_device_arrays(self._h, *[C.byref(r) for r in raw]), "gpr_nbr_device_arrays")
         self.ptrs = dict(zip(names, raw))
 
-    def force_rows(self, atoms):
-        """(counts, row_index, x_index, pt_row0) of the force points of the moving atoms `atoms` (global ids):
-        device int32 index arrays into dxdr rows / x rows and the point row offsets (gpr_nbr_force_rows)"""
-        atoms = np.ascontiguousarray(atoms, dtype=np.int32)
-        counts = (self.centre_row0[1:] - self.centre_row0[:-1])[atoms]
-        meta = np.empty(2 * len(atoms) + 1, dtype=np.int32)        # [atoms | pt_row0] in one upload
-        meta[:len(atoms)] = atoms
-        meta[len(atoms)] = 0
-        np.cumsum(counts, out=meta[len(atoms) + 1:])
-        nrows = int(meta[-1])
-        d_meta = dev.to_dev(meta, torch.int32)
+    def force_rows(self, atoms=None):
+        """(counts, row_index, x_index, pt_row0) of the force points of the moving atoms `atoms` (global ids; None =
+        every atom): device int32 index arrays into dxdr rows / x rows and the point row offsets (gpr_nbr_force_rows)"""
+        if atoms is None:                                          # nothing to upload: point a is atom a
+            counts = self.centre_row0[1:] - self.centre_row0[:-1]
+            nrows, npts = self.S, self.natoms
+            p_atoms, p_row0 = C.c_void_p(None), C.c_void_p(None)
+            row0_dev = dev.DevArray(self.ptrs["centre_row0"].value, self.natoms + 1, torch.int32, self)
+        else:
+            atoms = np.ascontiguousarray(atoms, dtype=np.int32)
+            counts = (self.centre_row0[1:] - self.centre_row0[:-1])[atoms]
+            meta = np.empty(2 * len(atoms) + 1, dtype=np.int32)    # [atoms | pt_row0] in one upload
+            meta[:len(atoms)] = atoms
+            meta[len(atoms)] = 0
+            np.cumsum(counts, out=meta[len(atoms) + 1:])
+            nrows, npts = int(meta[-1]), len(atoms)
+            d_meta = dev.to_dev(meta, torch.int32)
+            p_atoms, p_row0 = dev.ptr(d_meta), C.c_void_p(d_meta.data_ptr() + 4 * len(atoms))
+            row0_dev = d_meta[len(atoms):]
         idx = torch.empty((2, max(nrows, 1)), dtype=torch.int32, device=dev.device())
-        dev.check(_lib.lib().gpr_nbr_force_rows(self._h, len(atoms), dev.ptr(d_meta),
-                                                C.c_void_p(d_meta.data_ptr() + 4 * len(atoms)), nrows,
-                                                dev.ptr(idx[0]), dev.ptr(idx[1])), "gpr_nbr_force_rows")
-        return counts, idx[0, :nrows], idx[1, :nrows], d_meta[len(atoms):]
+        dev.check(_lib.lib().gpr_nbr_force_rows(self._h, npts, p_atoms, p_row0, nrows, dev.ptr(idx[0]), dev.ptr(idx[1])),
+                  "gpr_nbr_force_rows")
+        return counts, idx[0, :nrows], idx[1, :nrows], row0_dev
 
     def numbers_dev(self):
-        """int32 device view of the atomic numbers is not exposed as a tensor; upload the host copy"""
-        return dev.to_dev(self.numbers, torch.int32)
+        """atomic numbers of all atoms, int32, on the device (uploaded with the geometry)"""
+        return dev.DevArray(self.ptrs["numbers"].value, self.natoms, torch.int32, self)
+
+    def atom0_dev(self):
+        """atom offsets of the structures, int32 [nstruct + 1], on the device"""
+        return dev.DevArray(self.ptrs["atom0"].value, self.nstruct + 1, torch.int32, self)
 
     def status_into(self, slot):
         """queue the missing-row count (as a double) into the one-element device tensor `slot`"""

@@ -33,6 +33,7 @@ _L1_SIGNATURES = {
     "gpr_last_error": ([], C.c_char_p),
     "gpr_build_info": ([], C.c_char_p),
     "gpr_device_count": ([], _i),
+    "gpr_memcpy_dtod": ([_vp, _vp, _vp, _ll], _i),
     "gpr_set_create": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _i], _i),
     "gpr_set_destroy": ([_vp, _vp], _i),
     "gpr_set_info": ([_vp, c_int_p, c_int_p, c_int_p, C.POINTER(_ll)], _i),
@@ -53,7 +54,7 @@ _L1_SIGNATURES = {
     "gpr_dot2_features_direct": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, c_int_p, _d, _d, _vp, C.c_longlong, _vp], _i),
     "gpr_set_create_gather": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _vp, _vp, _i], _i),
     "gpr_nbr_build_device": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
-    "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 8, _i),
+    "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 9, _i),
     "gpr_nbr_force_rows": ([_vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gpr_nbr_check": ([_vp, c_int_p], _i),
     "gpr_nbr_status_to": ([_vp, _vp], _i),

@@ -26,7 +26,7 @@ struct gpr_nbr {
     int P = 0, S = 0;
     char *d_in = nullptr;                       // uploaded geometry blob
     const double *d_wpos = nullptr, *d_shift = nullptr;
-    const int *d_numbers = nullptr, *d_sid = nullptr;
+    const int *d_numbers = nullptr, *d_sid = nullptr, *d_atom0 = nullptr;
     const nbr_sinfo *d_sinfo = nullptr;
     int *d_off = nullptr;                       // [centre_row0 (natoms+1) | centre_pair0 (natoms+1) | counts | err]
     double *d_vec = nullptr, *d_w = nullptr;
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
         const int mid = (lo + hi) >> 1;
         if (f.pt_row0[mid] <= q) lo = mid; else hi = mid;
     }
-    const int a = f.atoms[lo], k = q - f.pt_row0[lo];
+    const int a = f.atoms ? f.atoms[lo] : lo, k = q - f.pt_row0[lo];
     const int atom0 = f.sinfo[f.sid[a]].atom0, al = a - atom0;
     const int i = atom0 + f.seq[2 * (size_t)(f.cr0[a] + k) + 1];
     int r0 = f.cr0[i], r1 = f.cr0[i + 1], found = -1;
@@ -335,12 +335,14 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
     }
     const size_t b_wpos = wpos.size() * 8, b_shift = shifts.size() * 8, b_sinfo = sinfo.size() * sizeof(nbr_sinfo),
                  b_num = (size_t)natoms * 4;
-    std::vector<char> blob(b_wpos + b_shift + b_sinfo + 2 * b_num);
+    const size_t b_a0 = (size_t)(nstruct + 1) * 4;
+    std::vector<char> blob(b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0);
     char *bp = blob.data();
     if (b_wpos) memcpy(bp, wpos.data(), b_wpos);
     if (b_shift) memcpy(bp + b_wpos, shifts.data(), b_shift);
     if (b_sinfo) memcpy(bp + b_wpos + b_shift, sinfo.data(), b_sinfo);
     if (b_num) { memcpy(bp + b_wpos + b_shift + b_sinfo, numbers, b_num); memcpy(bp + b_wpos + b_shift + b_sinfo + b_num, sid.data(), b_num); }
+    memcpy(bp + b_wpos + b_shift + b_sinfo + 2 * b_num, atom0, b_a0);
 
     gpr_nbr *nb = new gpr_nbr();
     nb->on_device = true; nb->st = st; nb->nstruct = nstruct; nb->natoms = natoms;
@@ -359,6 +361,7 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
     nb->d_sinfo = (const nbr_sinfo *)(nb->d_in + b_wpos + b_shift);
     nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
     nb->d_sid = nb->d_numbers + natoms;
+    nb->d_atom0 = nb->d_sid + natoms;
     if ((rc = gpr_dev_alloc(&p, (size_t)(4 * natoms + 4) * sizeof(int), st))) return fail(rc);
     nb->d_off = (int *)p;                       // [cr0 | cp0 | cnt_rows | cnt_pairs | err]
     int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
@@ -404,8 +407,9 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
 
 extern "C" int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
                                      const int **centre_row0, const int **row_pair0, const int **self_row,
-                                     const int **seq, const int **numbers) {
+                                     const int **seq, const int **numbers, const int **atom0) {
     GPR_REQUIRE(nb && nb->on_device, "gpr_nbr_device_arrays: handle was not built by gpr_nbr_build_device");
+    if (atom0) *atom0 = nb->d_atom0;
     if (vec) *vec = nb->d_vec;
     if (w) *w = nb->d_w;
     if (centre_pair0) *centre_pair0 = nb->d_off + nb->natoms + 1;
@@ -422,7 +426,10 @@ extern "C" int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_
     GPR_REQUIRE(nb && nb->on_device, "gpr_nbr_force_rows: handle was not built by gpr_nbr_build_device");
     GPR_REQUIRE(npts >= 0 && nrows >= 0, "gpr_nbr_force_rows: negative sizes");
     if (nrows == 0 || npts == 0) return GPR_OK;
-    GPR_REQUIRE(atoms_dev && pt_row0_dev && row_index_dev && x_index_dev, "gpr_nbr_force_rows: null device pointer");
+    GPR_REQUIRE(row_index_dev && x_index_dev, "gpr_nbr_force_rows: null device pointer");
+    GPR_REQUIRE((atoms_dev && pt_row0_dev) || (!atoms_dev && !pt_row0_dev && npts == nb->natoms && nrows == nb->S),
+                "gpr_nbr_force_rows: atoms and pt_row0 go together; both NULL means every atom moves (npts = natoms, nrows = S)");
+    if (!pt_row0_dev) pt_row0_dev = nb->d_off;          // all atoms free: point a is atom a, its row range is centre_row0
     frow_args f{atoms_dev, pt_row0_dev, nb->d_off, nb->d_seq, nb->d_sid, nb->d_sinfo, row_index_dev, x_index_dev, nb->d_err,
                 npts, nrows};
     hipLaunchKernelGGL(nbr_force_rows_kernel, dim3((nrows + 255) / 256), dim3(256), 0, nb->st, f);

@@ -50,6 +50,13 @@ int gpr_dev_free(void *p, hipStream_t st) {
     return GPR_OK;
 }
 
+extern "C" int gpr_memcpy_dtod(void *stream, void *dst, const void *src, long long bytes) {
+    if (bytes <= 0) return GPR_OK;
+    GPR_REQUIRE(dst && src, "gpr_memcpy_dtod: null pointer");
+    GPR_HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GPR_OK;
+}
+
 // ---------------------------------------------------------------- pack kernel
 struct pack_args {
     const double *x, *dxdr;

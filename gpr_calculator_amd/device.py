@@ -29,8 +29,34 @@ def stream_ptr():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class DevArray:
+    """A device array owned by a native handle (raw pointer + length + dtype); `owner` keeps the handle alive.
+    Accepted wherever this module takes device tensors that are only passed on to the library."""
+
+    def __init__(self, pointer, n, dtype, owner):
+        self.pointer, self.n, self.dtype, self.owner = int(pointer), int(n), dtype, owner
+        self.shape = (self.n,)
+
+    def reshape(self, *_):
+        return self
+
+    def data_ptr(self):
+        return self.pointer
+
+    def tensor(self):
+        """a torch copy (debug / fallback paths)"""
+        out = torch.empty(self.n, dtype=self.dtype, device=device())
+        check(_lib.lib().gpr_memcpy_dtod(stream_ptr(), C.c_void_p(out.data_ptr()), C.c_void_p(self.pointer),
+                                         self.n * out.element_size()), "gpr_memcpy_dtod")
+        return out
+
+
 def to_dev(a, dtype=F64):
     """numpy / tensor -> contiguous device tensor of dtype"""
+    if isinstance(a, DevArray):
+        if a.dtype != dtype:
+            raise TypeError(f"device array of {a.dtype} where {dtype} is needed")
+        return a
     if isinstance(a, torch.Tensor):
         if a.is_cuda and a.dtype == dtype and a.is_contiguous():
             return a
@@ -161,7 +187,8 @@ class SetPair:
 
     def raw_rows(self):
         """(x, dxdr, ele) row tensors with the gather applied (materialised; fallback paths only)"""
-        x, dxdr, ele = self.x, self.dxdr, self.ele
+        x, dxdr = self.x, self.dxdr
+        ele = self.ele.tensor() if isinstance(self.ele, DevArray) else self.ele
         if self.x_index is not None:
             x, ele = x.index_select(0, self.x_index.long()), ele.index_select(0, self.x_index.long())
         if dxdr is not None and self.dxdr_index is not None:

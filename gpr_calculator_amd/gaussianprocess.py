@@ -695,11 +695,12 @@ class GP():
         atom0 = nbr.atom0
         natoms = int(atom0[-1])
         nper = np.diff(atom0)
-        keep = np.ones(natoms, dtype=bool)
-        frees = []
+        keep, frees = None, []
         for k, s in enumerate(strucs):
             fix = self._get_fixed_atoms(s)
             if len(fix):
+                if keep is None:
+                    keep = np.ones(natoms, dtype=bool)
                 keep[atom0[k] + np.asarray(fix, dtype=np.int64)] = False
                 fixset = set(int(i) for i in fix)
                 frees.append([i for i in range(int(nper[k])) if i not in fixset])
@@ -707,10 +708,8 @@ class GP():
                 frees.append(None)                                  # all atoms free
         # force point of atom a = the seq rows (i, a) of every centre i that feels a, regrouped on the device
         # (gpr_nbr_force_rows) and gathered inside the consumer kernels: x / dxdr never leave the descriptor's layout
-        counts_f, row_index, x_index, f_row0 = nbr.force_rows(np.flatnonzero(keep))
-        meta = np.concatenate((atom0, nbr.numbers)).astype(np.int32)
-        d_meta = dev.to_dev(meta, torch.int32)
-        e_row0, ele = d_meta[:len(atom0)], d_meta[len(atom0):]
+        counts_f, row_index, x_index, f_row0 = nbr.force_rows(None if keep is None else np.flatnonzero(keep))
+        e_row0, ele = nbr.atom0_dev(), nbr.numbers_dev()
         desc = self.descriptor.calculate_batch_dev(strucs, nbr=nbr)
         E = dev.SetPair(desc["x"], None, ele, nper)
         E._row0_dev = e_row0

@@ -53,6 +53,8 @@ class Dot_mb(DeviceKernel):
                     ent = data[key]
                     ele = ent.ele if isinstance(ent, dev.SetPair) else \
                         (as_energy_tuple(ent)[1] if key == "energy" else as_force_tuple(ent)[2])
+                    if isinstance(ele, dev.DevArray):
+                        ele = ele.tensor()
                     if isinstance(ele, torch.Tensor):
                         out.update(torch.unique(ele).cpu().tolist())
                     else:

@@ -42,6 +42,8 @@ const char *gpr_last_error(void);
 const char *gpr_build_info(void);
 /* number of HIP devices visible (0 if none / runtime unavailable); never throws */
 int gpr_device_count(void);
+/* stream-ordered device-to-device copy (host code uses it to turn library-owned arrays into caller tensors) */
+int gpr_memcpy_dtod(void *stream, void *dst, const void *src, long long bytes);
 
 /* ------------------------------------------------------------------ kernel parameters */
 enum gpr_kernel_kind { GPR_KERNEL_RBF = 0, GPR_KERNEL_DOT = 1 };
@@ -186,16 +188,18 @@ int gpr_nbr_destroy(gpr_nbr *nb);
  * host); gpr_nbr_destroy releases the device arrays in stream order. */
 int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                          const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on);
-/* device pointers of a device-built handle, in the layouts of gpr_nbr_export (any pointer may be NULL) */
+/* device pointers of a device-built handle, in the layouts of gpr_nbr_export, plus the uploaded numbers[natoms] and
+ * atom0[nstruct+1] (any pointer may be NULL); they live until gpr_nbr_destroy */
 int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
                           const int **centre_row0, const int **row_pair0, const int **self_row,
-                          const int **seq, const int **numbers);
+                          const int **seq, const int **numbers, const int **atom0);
 /* Force points on the device (gaussianprocess.py:852-870): point p is moving atom atoms[p] (global id);
  * its rows are the seq rows (i, a) of every centre i that has a as a neighbour, ascending in i.  By the
  * symmetry of the neighbour relation their number equals the row count of centre a, so the caller knows
  * pt_row0[npts+1] (exclusive prefix of those counts, device) from the host copy of centre_row0.
  * Outputs (device, int32, nrows = pt_row0[npts]): row_index = seq row of (i, a) (index into dxdr),
- * x_index = global id of i (index into x / numbers). */
+ * x_index = global id of i (index into x / numbers).  atoms_dev = pt_row0_dev = NULL means every atom moves
+ * (npts = natoms, nrows = S): point a is atom a and its row range is centre_row0 -- nothing to upload. */
 int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const int *pt_row0_dev, int nrows,
                        int *row_index_dev, int *x_index_dev);
 /* number of (i, a) rows gpr_nbr_force_rows could not find (0 unless the symmetry above is broken); synchronises */

@@ -61,6 +61,7 @@ def _mixed_batch():
 
 def test_device_neighbour_build_is_identical_to_host_build():
     """gpr_nbr_build_device against gpr_nbr_build: same pairs, rows and index maps, bit for bit"""
+    import torch
     from gpr_calculator_amd.SO3 import SO3
     des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
     strucs = _mixed_batch()
@@ -86,6 +87,10 @@ def test_device_neighbour_build_is_identical_to_host_build():
         assert np.array_equal(x_index[off:off + c], gi[rows])
         off += c
     assert off == len(row_index)
+    # every atom moving: no index upload, same answer as the explicit list
+    c_all, r_all, x_all, _ = nbr.force_rows(None)
+    c_exp, r_exp, x_exp, _ = nbr.force_rows(np.arange(int(atom0[-1])))
+    assert np.array_equal(c_all, c_exp) and torch.equal(r_all, r_exp) and torch.equal(x_all, x_exp)
 
 
 def test_batch_descriptor_device_index_matches_host_index():

@@ -101,7 +101,7 @@ def split2(n=50):
         dev.check(L.gpr_nbr_sizes(h, C.byref(P_), C.byref(S_)), "x")
         cr0 = np.empty(int(atom0[-1]) + 1, np.int32); row0 = np.empty(nstruct + 1, np.int32)
         dev.check(L.gpr_nbr_export(h, None, None, None, ip(cr0), None, None, None, ip(row0)), "x"); tick()
-        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers")
+        names = ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row", "seq", "numbers", "atom0")
         raw = [C.c_void_p() for _ in names]
         dev.check(L.gpr_nbr_device_arrays(h, *[C.byref(r) for r in raw]), "x"); tick()
         L.gpr_nbr_destroy(h); tick()
@@ -122,19 +122,13 @@ def split3(n=50):
         nbr = self.descriptor.neighbor_batch_dev(strucs); tick()
         atom0 = nbr.atom0
         natoms = int(atom0[-1]); nper = np.diff(atom0)
-        keep = np.ones(natoms, dtype=bool); frees = []
+        keep, frees = None, []
         for k, s in enumerate(strucs):
             fix = self._get_fixed_atoms(s)
-            if len(fix):
-                keep[atom0[k] + np.asarray(fix, dtype=np.int64)] = False
-                frees.append([i for i in range(int(nper[k])) if i not in set(fix)])
-            else:
-                frees.append(None)
+            frees.append(None if not len(fix) else list(fix))
         tick()
-        counts_f, row_index, x_index, f_row0 = nbr.force_rows(np.flatnonzero(keep)); tick()
-        meta = np.concatenate((atom0, nbr.numbers)).astype(np.int32)
-        d_meta = dev.to_dev(meta, torch.int32)
-        e_row0, ele = d_meta[:len(atom0)], d_meta[len(atom0):]; tick()
+        counts_f, row_index, x_index, f_row0 = nbr.force_rows(None); tick()
+        e_row0, ele = nbr.atom0_dev(), nbr.numbers_dev(); tick()
         desc = self.descriptor.calculate_batch_dev(strucs, nbr=nbr); tick()
         E = dev.SetPair(desc["x"], None, ele, nper); E._row0_dev = e_row0
         F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index); F._row0_dev = f_row0; F._nbr = nbr
