@@ -13,7 +13,7 @@ import torch
 
 from . import _lib
 from . import device as dev
-from .neighbors import atoms_arrays, neighbor_pairs, symbol_of
+from .neighbors import atoms_arrays, batch_arrays, neighbor_pairs, symbol_of
 
 
 def radial_table(nmax, lmax, rcut, alpha):
@@ -327,16 +327,10 @@ class NeighborBatch:
     (csrc/nbr.hip: gpr_nbr_build_device).  Host side: atom0 / row0 offsets, numbers, centre_row0."""
 
     def __init__(self, strucs, rcut, weight_on):
-        arrs = [atoms_arrays(s) for s in strucs]
-        self.nstruct = len(arrs)
-        self.atom0 = np.zeros(self.nstruct + 1, dtype=np.int64)
-        np.cumsum([len(a[0]) for a in arrs], out=self.atom0[1:])
+        self.atom0, self.numbers, pos, cells, pbc = batch_arrays(strucs)
+        self.nstruct = len(strucs)
         atom0 = self.atom0.astype(np.int32)
-        self.numbers = np.concatenate([a[0] for a in arrs]).astype(np.int64) if arrs else np.zeros(0, np.int64)
-        numbers = np.ascontiguousarray(self.numbers, dtype=np.int32)
-        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
-        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
-        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32)
+        numbers = self.numbers.astype(np.int32)
         L = _lib.lib()
         ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
         dp = lambda a: a.ctypes.data_as(_lib.c_double_p)

@@ -27,7 +27,7 @@ from . import device as dev
 from .kernels.Dot_mb import Dot_mb
 from .kernels.RBF_mb import RBF_mb
 from .kernels._common import n_points
-from .neighbors import fixed_indices
+from .neighbors import fixed_indices, has_fixed_atoms
 from .parallel import Comm
 from .utilities import (convert_train_data, list_to_tuple, metric_values, new_pt, species_numbers,
                         tuple_to_list)
@@ -641,8 +641,22 @@ class GP():
                 if nbr is not None:
                     nbr.check()
             nS = len(mine)
+            ns_atoms = [len(strucs[k]) for k in mine]
+            uniform = all(f is None for f in frees) and len(set(ns_atoms)) == 1 and self.base_potential is None
+            if uniform:
+                # same composition, nothing fixed, no base potential (an NEB band): slice the result block once
+                n = ns_atoms[0]
+                Eb = mean[:nS] * n
+                Fb = mean[nS:].reshape(nS, n, 3)
+                if return_std:
+                    Sb = std[nS:].reshape(nS, n, 3)
+                    for s, k in enumerate(mine):
+                        results[k] = (Eb[s], Fb[s], std[s], Sb[s])
+                else:
+                    for s, k in enumerate(mine):
+                        results[k] = (Eb[s], Fb[s], None, None)
             off = nS
-            for s, k in enumerate(mine):
+            for s, k in enumerate(mine if not uniform else ()):
                 n, free_ids = len(strucs[k]), frees[s]
                 nf = 3 * (n if free_ids is None else len(free_ids))
                 E = mean[s] * n
@@ -697,7 +711,7 @@ class GP():
         nper = np.diff(atom0)
         keep, frees = None, []
         for k, s in enumerate(strucs):
-            fix = self._get_fixed_atoms(s)
+            fix = self._get_fixed_atoms(s) if has_fixed_atoms(s) else ()
             if len(fix):
                 if keep is None:
                     keep = np.ones(natoms, dtype=bool)

@@ -76,6 +76,45 @@ def atoms_arrays(atoms):
     return numbers.astype(np.int64), pos, cell, pbc
 
 
+def batch_arrays(strucs):
+    """(atom0[ns+1] int64, numbers[N] int64, positions[N,3], cells[ns,9], pbc[ns,3] int32) of a list of ase.Atoms /
+    SimpleAtoms: the concatenated form the batched neighbour search takes.  One pass of attribute reads and four
+    numpy calls (the per-structure atoms_arrays conversions cost more than the search itself for small cells)."""
+    ns = len(strucs)
+    atom0 = np.zeros(ns + 1, dtype=np.int64)
+    if ns == 0:
+        return atom0, np.zeros(0, np.int64), np.zeros((0, 3)), np.zeros((0, 9)), np.zeros((0, 3), np.int32)
+    try:
+        nums = [s.numbers for s in strucs]                  # ase.Atoms and SimpleAtoms both expose these as arrays
+        poss = [s.positions for s in strucs]
+        cells = np.array([s.cell for s in strucs], dtype=np.float64).reshape(ns, 9)
+        pbc = np.array([s.pbc for s in strucs]).astype(np.int32)
+        if pbc.shape != (ns, 3):
+            raise ValueError
+        np.cumsum([len(a) for a in nums], out=atom0[1:])
+        numbers = np.concatenate(nums).astype(np.int64)
+        pos = np.ascontiguousarray(np.concatenate(poss, axis=0), dtype=np.float64)
+        if pos.shape != (int(atom0[-1]), 3):
+            raise ValueError
+        return atom0, numbers, pos, np.ascontiguousarray(cells), np.ascontiguousarray(pbc)
+    except (AttributeError, ValueError, TypeError):
+        arrs = [atoms_arrays(s) for s in strucs]
+        np.cumsum([len(a[0]) for a in arrs], out=atom0[1:])
+        numbers = np.concatenate([a[0] for a in arrs]).astype(np.int64)
+        pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs], axis=0), dtype=np.float64)
+        cells = np.ascontiguousarray(np.stack([a[2] for a in arrs]).reshape(-1, 9), dtype=np.float64)
+        pbc = np.ascontiguousarray(np.stack([a[3] for a in arrs]), dtype=np.int32)
+        return atom0, numbers, pos, cells, pbc
+
+
+def has_fixed_atoms(atoms):
+    """cheap test before fixed_indices: does the structure carry any constraint at all"""
+    fx = getattr(atoms, "fixed", None)
+    if fx is not None:
+        return len(fx) > 0
+    return bool(getattr(atoms, "constraints", None))
+
+
 def fixed_indices(atoms):
     """indices held by an ASE FixAtoms constraint (gaussianprocess.py:823-832) or SimpleAtoms.fixed"""
     if hasattr(atoms, "fixed"):
