@@ -575,7 +575,18 @@ class GP():
 
     def predict_structure(self, struc, stress=True, return_std=False, f_tol=1e-8):
         """Energy, forces (, stress) and their standard deviations for one structure
-        (gaussianprocess.py:834-918).  E is the total energy, E_std is per atom."""
+        (gaussianprocess.py:834-918).  E is the total energy, E_std is per atom.
+
+        Without stress (what the calculator asks for when the cell is fixed) a single structure takes the same
+        device-resident route as predict_structures -- neighbour search, descriptor, regrouping and prediction
+        without a host copy of x / dxdr; `device_single = False` selects the tuple route below, which is also the
+        one for stress, for several ranks and for foreign descriptors."""
+        if (not stress and self.device_single and self.comm.size == 1
+                and hasattr(self.descriptor, "calculate_batch_dev")):
+            Es, Fs, Es_std, Fs_std = self.predict_structures([struc], return_std=return_std, f_tol=f_tol)
+            if return_std:
+                return Es[0], Fs[0], None, Es_std[0], Fs_std[0]
+            return Es[0], Fs[0], None
         d = self.descriptor.calculate(struc, use_mpi=True)
         data, free_ids = self._structure_data(struc, d, stress=stress)
         train_x = self.get_train_x()
@@ -611,6 +622,8 @@ class GP():
             F_std[free_ids] = y_std[1:].reshape([len(free_ids), 3])
             return E, F, S, E_std, F_std
         return E, F, S
+
+    device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
         """Batched predict_structure(stress=False): one descriptor pass, one K_trans build, one

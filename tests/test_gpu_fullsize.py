@@ -81,7 +81,9 @@ def test_prediction_properties(model):
     assert gp.predict_structure(far, stress=False, return_std=True)[4].mean() > 2 * F_std.mean()
     # batched path == one-by-one path
     for k in (0, 5):
+        gp.device_single = False            # tuple route (host descriptor, packed sets) as the cross-check
         e1, f1, _, es1, fs1 = gp.predict_structure(batch[k], stress=False, return_std=True)
+        gp.device_single = True
         assert abs(Es[k] - e1) < 1e-8 and np.abs(Fs[k] - f1).max() < 1e-8 and np.abs(Fs_std[k] - fs1).max() < 1e-7
     # linearity of the mean in the labels: doubling y doubles alpha and the prediction
     import torch

@@ -77,10 +77,15 @@ def test_fit_predict_structure_matches_oracle(kind, port_natives):
     assert np.abs(gp.alpha_ - alpha).max() / np.abs(alpha).max() < 1e-7     # cond(K) amplifies rounding
     assert np.abs(gp._K_inv - K_inv).max() / np.abs(K_inv).max() < 1e-7
 
-    # predict a new structure with one fixed atom, E/F/sigma
+    # predict a new structure with one fixed atom, E/F/sigma: tuple route (host descriptor, packed sets) first
+    gp.device_single = False
     new = fcc_cell(seed=77, reps=1, species=(46, 78), sigma=0.08)
     new.fixed = np.array([1])
     E, F, S, E_std, F_std = gp.predict_structure(new, stress=False, return_std=True, f_tol=1e-8)
+    gp.device_single = True            # ... and the device-resident single-structure route gives the same numbers
+    Ed, Fd, _, Ed_std, Fd_std = gp.predict_structure(new, stress=False, return_std=True, f_tol=1e-8)
+    assert abs(Ed - E) < 1e-9 and np.abs(Fd - F).max() < 1e-9 and abs(Ed_std - E_std) < 1e-8 and np.abs(Fd_std - F_std).max() < 1e-8
+    gp.device_single = False
     des = oracle_descriptor()
     d = des.calculate(new)
     from gpr_calculator_amd.utilities import species_numbers
