@@ -146,7 +146,13 @@ def main():
     _lib.require_gpu()
 
     gp = build_model(args.kernel, args.n_train, comm)
-    fit_ms = time_fit(gp)                          # K assembly (sharded over ranks) + Cholesky + alpha
+    # fit(opt=False): with the Dot kernel at zeta = 2 the model is fitted in weight space (F x F system); the dense
+    # route (K assembly sharded over ranks + N x N Cholesky + alpha) is what every other kernel takes and what
+    # L_ / alpha_ / _K_inv trigger lazily -- both are timed
+    gp.weight_space_fit = False
+    fit_dense_ms = time_fit(gp)
+    gp.weight_space_fit = True
+    fit_ms = time_fit(gp)
     # weak scaling: every rank predicts its own batch of images with the replicated model
     batch = neb_images(args.batch, seed=100 + 10 * rank)
     gp.comm = _Serial()      # predict_structures shards a batch over gp.comm; here each rank owns a whole batch
@@ -229,7 +235,7 @@ def main():
                                        f"energy points (N={N}), {args.kernel} kernel zeta=2, SO3(3,4,5.0), predict "
                                        f"E/F/sigma batch of {args.batch} 32-atom structures per GPU",
                            "kernel": args.kernel, "n_train": args.n_train, "batch_per_gpu": args.batch, "N": int(N),
-                           "train_force_rows": int(len(tX)), "fit_ms": fit_ms,
+                           "train_force_rows": int(len(tX)), "fit_ms": fit_ms, "fit_dense_ms": fit_dense_ms,
                            "parallelism": f"replicated model, structure-parallel predict x{world}; fit K sharded x{world}"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line))

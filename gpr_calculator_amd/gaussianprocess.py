@@ -79,8 +79,9 @@ class GP():
         self.N_queue = 0
 
         # device-resident model state
-        self._L_dev = None          # lower Cholesky factor of K + noise  [N, N]
-        self._alpha_dev = None      # (K + noise)^-1 y                    [N, 1]
+        self._dense = {"L": None, "alpha": None, "dinv": None}   # Cholesky factor of K + noise [N, N], (K + noise)^-1 y
+        self._dense_pending = False  # a weight-space fit leaves the N x N factorisation until somebody asks for it
+        self._fitted = False
         self._K_inv_dev = None
         self._Linv_dev = None
         self._ws_cache = None
@@ -92,10 +93,43 @@ class GP():
         if self.rank == 0:
             self.logging.info(self)
 
+    # ------------------------------------------------------------------ dense factor state (lazy after a weight-space fit)
+    def _ensure_dense(self):
+        if self._dense_pending:
+            self._dense_pending = False
+            self._factor_dense()
+
+    @property
+    def _L_dev(self):
+        self._ensure_dense()
+        return self._dense["L"]
+
+    @_L_dev.setter
+    def _L_dev(self, v):
+        self._dense["L"] = v
+
+    @property
+    def _alpha_dev(self):
+        self._ensure_dense()
+        return self._dense["alpha"]
+
+    @_alpha_dev.setter
+    def _alpha_dev(self, v):
+        self._dense["alpha"] = v
+
+    @property
+    def _dinv_dev(self):
+        self._ensure_dense()
+        return self._dense["dinv"]
+
+    @_dinv_dev.setter
+    def _dinv_dev(self, v):
+        self._dense["dinv"] = v
+
     # ------------------------------------------------------------------ reference attribute mirrors
     @property
     def alpha_(self):
-        if self._alpha_dev is None:
+        if not self._fitted:
             return None
         if "alpha" not in self._host:
             self._host["alpha"] = self._alpha_dev.cpu().numpy()
@@ -103,7 +137,7 @@ class GP():
 
     @property
     def L_(self):
-        if self._L_dev is None:
+        if not self._fitted:
             return None
         if "L" not in self._host:
             self._host["L"] = self._L_dev.cpu().numpy()
@@ -111,7 +145,7 @@ class GP():
 
     @property
     def _K_inv(self):
-        if self._L_dev is None:
+        if not self._fitted:
             return None
         self.set_K_inv()
         if "K_inv" not in self._host:
@@ -248,28 +282,76 @@ class GP():
             else:
                 self.kernel.update(params)
 
-        K = self._train_K()
-        NE = self._n_energy_points(self.train_x)
-        dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
-        info, self._dinv_dev = dev.potrf_lower_(K, want_dinv=True)
-        if int(info.item()) != 0:
-            raise np.linalg.LinAlgError(f"{int(info.item())}-th leading minor of K + noise is not positive definite")
-        self._L_dev = K
-        alpha = dev.to_dev(self.y_train).clone()
-        dev.trsm_lower_(self._L_dev, alpha, dinv=self._dinv_dev)
-        dev.trsm_lower_(self._L_dev, alpha, trans=True, dinv=self._dinv_dev)
-        self._alpha_dev = alpha
+        self._dense = {"L": None, "alpha": None, "dinv": None}
+        self._dense_pending = False
         self._K_inv_dev = None
         self._Linv_dev = None
         self._ws_cache = None
         self._host = {}
-        self.logging.info("Cholesky Decomp is Complete")
+        if self.weight_space_fit and self._fit_weight_space():
+            self._dense_pending = True          # L_, alpha_, _K_inv are factored on first access
+            self.logging.info("Weight-space fit is complete")
+        else:
+            self._factor_dense()
+            self.logging.info("Cholesky Decomp is Complete")
+        self._fitted = True
         self.comm.barrier()
 
         self.N_energy_queue = 0
         self.N_forces_queue = 0
         self.N_queue = 0
         self.fits += 1
+
+    def _factor_dense(self):
+        """K + noise -> L -> alpha on the device (gaussianprocess.py:286-317)"""
+        K = self._train_K()
+        NE = self._n_energy_points(self.train_x)
+        dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
+        info, dinv = dev.potrf_lower_(K, want_dinv=True)
+        if int(info.item()) != 0:
+            raise np.linalg.LinAlgError(f"{int(info.item())}-th leading minor of K + noise is not positive definite")
+        alpha = dev.to_dev(self.y_train).clone()
+        dev.trsm_lower_(K, alpha, dinv=dinv)
+        dev.trsm_lower_(K, alpha, trans=True, dinv=dinv)
+        self._dense = {"L": K, "alpha": alpha, "dinv": dinv}
+
+    # kernels with an explicit feature map (Dot_mb at zeta = 2): K + D = Psi' Psi'^T + D with Psi' = sigma Psi [N, F],
+    # F = 466 per species << N, so by the Woodbury identity everything a prediction needs comes from the F x F matrix
+    #   G = I + Psi'^T D^-1 Psi':   w = sigma^2 Psi^T alpha = sigma G^-1 Psi'^T D^-1 y,
+    #   M = sigma^4 Psi^T (K + D)^-1 Psi = sigma^2 (I - G^-1)
+    # -- the same w and M the dense route derives from L and alpha (_weight_space), without forming K at all.
+    weight_space_fit = True
+
+    def _fit_weight_space(self):
+        if not hasattr(self.kernel, "_feature_path"):
+            return False
+        train_x = self.train_x
+        species = self.kernel._feature_path(train_x, None, self.kernel.zeta)
+        if species is None:
+            return False
+        Psi = self.kernel._psi(train_x, species)                                  # [N, F]
+        N, F = Psi.shape
+        NE = self._n_energy_points(train_x)
+        rs = torch.empty(N, dtype=dev.F64, device=Psi.device)                    # D^-1/2
+        rs[:NE] = 1.0 / self.noise_e
+        rs[NE:] = 1.0 / self.noise_f
+        sig = float(self.kernel.sigma)
+        S = Psi * (sig * rs)[:, None]                                             # D^-1/2 Psi'
+        y = dev.to_dev(self.y_train).reshape(-1) * rs
+        G = dev.gemm(S, S, transa=True)
+        G.diagonal().add_(1.0)
+        b = dev.gemm(S, y.reshape(-1, 1), transa=True)                            # Psi'^T D^-1 y
+        info, dinv = dev.potrf_lower_(G, want_dinv=True)
+        if int(info.item()) != 0:
+            return False
+        dev.trsm_lower_(G, b, dinv=dinv)
+        dev.trsm_lower_(G, b, trans=True, dinv=dinv)                              # G^-1 b
+        Ci = torch.eye(F, dtype=dev.F64, device=Psi.device)
+        dev.trsm_lower_(G, Ci, dinv=dinv)                                         # C^-1, G = C C^T
+        M = dev.gemm(Ci, Ci, transa=True, alpha=-sig * sig)                       # -sigma^2 G^-1
+        M.diagonal().add_(sig * sig)
+        self._ws_cache = (species, M, b * sig)
+        return True
 
     # ------------------------------------------------------------------ prediction
     def _predict_dev(self, X, train_x, f_tol, return_std, want_flat=False):
@@ -761,7 +843,7 @@ class GP():
         force = force - force_off
         my_data = convert_train_data([(atoms, energy, force)], self.descriptor)
 
-        if self._alpha_dev is not None:
+        if self._fitted:
             E, E1, E_std, F, F1, F_std = self.validate_data(my_data, return_std=True)
             E_std = E_std[0]
             F_std = F_std.reshape((len(atoms), 3))

@@ -108,3 +108,31 @@ def test_sharded_assembly_is_exact_at_full_size(model):
     finally:
         dev.set_shard(1, 0)
     assert torch.equal(acc, full)
+
+
+def test_dot_weight_space_fit_matches_dense_route_at_full_size():
+    """cfg3 Dot model: the weight-space fit (Woodbury on the 466-wide feature Gram, N x N never formed) against the
+    dense route (K + noise -> L -> alpha, then w and M from L) on a batch prediction; north-star tolerances"""
+    import bench
+    from gpr_calculator_amd.parallel import Comm
+    from gpr_calculator_amd.synthetic import neb_images
+    gp = bench.build_model("Dot", 2000, Comm())
+    batch = neb_images(8, seed=500)
+    gp.weight_space_fit = True
+    gp.fit(show=False, opt=False)
+    assert gp._dense_pending and gp._dense["L"] is None          # nothing N x N was factored
+    Ew, Fw, Ews, Fws = gp.predict_structures(batch, return_std=True)
+    assert gp._dense_pending
+    gp.weight_space_fit = False
+    gp.fit(show=False, opt=False)
+    assert not gp._dense_pending and gp._dense["L"] is not None
+    Ed, Fd, Eds, Fds = gp.predict_structures(batch, return_std=True)
+    n = len(batch[0])
+    for k in range(len(batch)):
+        assert abs(Ew[k] - Ed[k]) / n < 1e-6 and np.abs(Fw[k] - Fd[k]).max() < 1e-5
+        assert abs(Ews[k] - Eds[k]) < 1e-6 and np.abs(Fws[k] - Fds[k]).max() < 1e-5
+    # the lazy mirrors of a weight-space fit are the dense ones
+    gp.weight_space_fit = True
+    gp.fit(show=False, opt=False)
+    a_lazy = gp.alpha_
+    assert not gp._dense_pending and a_lazy.shape == (6063, 1)

@@ -103,6 +103,12 @@ def test_fit_predict_structure_matches_oracle(kind, port_natives):
     assert abs(E_std - std[0]) < E_TOL
     assert np.abs(F_std[free] - std[1:].reshape(-1, 3)).max() < F_TOL and S is None
 
+    if kind == "Dot":       # the fit above ran in weight space; the dense route gives the same predictions
+        gp.weight_space_fit = False
+        gp.fit(show=False, opt=False)
+        Ef, Ff, _, Ef_std, Ff_std = gp.predict_structure(new, stress=False, return_std=True, f_tol=1e-8)
+        assert abs(Ef - E) < E_TOL and np.abs(Ff - F).max() < F_TOL
+        assert abs(Ef_std - E_std) < E_TOL and np.abs(Ff_std - F_std).max() < F_TOL
     if kind == "Dot":       # weight-space mean (Psi* w) and training-point mean (K_trans alpha) are the same number
         gp.weight_space_mean = False
         E2, F2, _ = gp.predict_structure(new, stress=False, return_std=False, f_tol=1e-8)
