@@ -292,10 +292,23 @@ class SO3:
             ptrs = [nbr.ptrs[k] for k in ("vec", "w", "centre_pair0", "centre_row0", "row_pair0", "self_row")]
         x = torch.empty((nc, d), dtype=dev.F64, device=D)
         dxdr = torch.empty((S, d, 3), dtype=dev.F64, device=D)
-        dev.check(_lib.lib().gpr_so3_power_spectrum(
-            dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nseg, ncheb, dev.ptr(table),
-            nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr)), "gpr_so3_power_spectrum")
-        out = dict(x=x, dxdr=dxdr, atom0=atom0, row0=row0, numbers_all=numbers, nbr=nbr,
+        rdxdr = None
+        if self._stress:
+            # stress rows (SO3.py:240-306): centre positions as given (not wrapped) and 1 / cell volume per centre
+            arrs = [atoms_arrays(s) for s in strucs]
+            pos = np.concatenate([a[1] for a in arrs], axis=0)
+            ivol = np.concatenate([np.full(len(a[0]), 1.0 / abs(np.linalg.det(a[2]))) for a in arrs])
+            d_pos, d_ivol = dev.to_dev(pos), dev.to_dev(ivol)
+            rdxdr = torch.empty((S, d, 3, 3), dtype=dev.F64, device=D)
+            dev.check(_lib.lib().gpr_so3_power_spectrum_stress(
+                dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nseg, ncheb, dev.ptr(table),
+                nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr), dev.ptr(d_pos), dev.ptr(d_ivol), dev.ptr(rdxdr)),
+                "gpr_so3_power_spectrum_stress")
+        else:
+            dev.check(_lib.lib().gpr_so3_power_spectrum(
+                dev.stream_ptr(), self.nmax, self.lmax, float(self.rcut), float(self.alpha), nseg, ncheb, dev.ptr(table),
+                nc, P, S, *ptrs, dev.ptr(x), dev.ptr(dxdr)), "gpr_so3_power_spectrum")
+        out = dict(x=x, dxdr=dxdr, rdxdr=rdxdr, atom0=atom0, row0=row0, numbers_all=numbers, nbr=nbr,
                    numbers=[numbers[atom0[k]:atom0[k + 1]] for k in range(len(strucs))])
         if host_index:
             seq = nb["seq"]
@@ -312,13 +325,11 @@ class SO3:
         '''
         if atom_ids is not None:
             raise NotImplementedError("atom_ids subsets are not used on the GPR hot path")
-        if self._stress:
-            raise NotImplementedError("stress=True (rdxdr) belongs to the path the reference marks obsolete "
-                                      "(RBF_mb.py:210); not built on the GPU yet")
         out = self.calculate_batch_dev([atoms], host_index=True)
         numbers = out["numbers"][0]
         symbols = list(atoms.symbols) if hasattr(atoms, "symbols") else [symbol_of(z) for z in numbers]
-        return {'x': out["x"].cpu().numpy(), 'dxdr': out["dxdr"].cpu().numpy(), 'rdxdr': None,
+        return {'x': out["x"].cpu().numpy(), 'dxdr': out["dxdr"].cpu().numpy(),
+                'rdxdr': None if out["rdxdr"] is None else out["rdxdr"].cpu().numpy(),
                 'elements': [str(s) for s in symbols], 'seq': out["seq"][0]}
 
 

@@ -226,6 +226,10 @@ struct so3_args {
     const int *self_row;        // [nc]   seq row (i, i)
     double *x;                  // [nc][d]
     double *dxdr;               // [S][d][3]
+    // optional stress rows (SO3.py:240-306): rdxdr[S][d][3][3] = -pstress / volume
+    const double *positions;    // [nc][3] centre positions as the caller gave them (not wrapped)
+    const double *inv_vol;      // [nc] 1 / cell volume of the centre's structure
+    double *rdxdr;              // NULL: not wanted
 };
 
 constexpr int SO3_PC = 48;       // pairs whose tables are resident in LDS at a time
@@ -235,7 +239,8 @@ constexpr int SO3_NLP = 16;      // padded nmax (lmax+1)
 // (c_tot folded onto m >= 0), Tf [NL][3][2][LT+1] cplx (gradient coefficients contracted with c_tot, folded onto
 // m' >= 0), self sums [4][96], per wavefront R [16] | S [48]; then SO3_PC pair records of `rec` doubles:
 //   ux uy uz 1/r r fc fc' w | A [16] | B [16] | Y_l^m, 0 <= m <= l <= lmax+1, triangular, cplx
-struct so3_lds { int oNY, oRI, oNL, oCtot, oRf, oTf, oSelf, oRS, oRec, rec, tri, total; };
+// (sII: with stress output, dP and R (x) dP summed over the periodic images of the centre itself, [4][96])
+struct so3_lds { int oNY, oRI, oNL, oCtot, oRf, oTf, oSelf, oII, oRS, oRec, rec, tri, total; };
 __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
     const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, LT = lmax + 1, NLM = nmax * L * M, NL = nmax * L;
     so3_lds o;
@@ -248,6 +253,7 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
     o.oRf = off; off += NL * L * 2;
     o.oTf = off; off += NL * 3 * 2 * (LT + 1) * 2;
     o.oSelf = off; off += SO3_WAVES * 96;
+    o.oII = off; off += 96 * 4;             // stress only: dP sum and R (x) dP sum of the (i, i) image pairs
     o.oRS = off; off += SO3_WAVES * 64;
     o.tri = (LT + 1) * (LT + 2) / 2;
     o.rec = 8 + 2 * SO3_NLP + 2 * o.tri;
@@ -434,15 +440,26 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         e_k[rnd] = e % 3; iA1[rnd] = n1 * L + l; iA2[rnd] = n2 * L + l;
     }
     double self0 = 0.0, self1 = 0.0;
+    const bool stress = P.rdxdr != nullptr;
+    double *sII = smem + lay.oII;
+    double Ri[3] = {0.0, 0.0, 0.0};
+    if (stress) {
+        Ri[0] = P.positions[3 * (size_t)ic]; Ri[1] = P.positions[3 * (size_t)ic + 1]; Ri[2] = P.positions[3 * (size_t)ic + 2];
+        for (int e = tid; e < 96 * 4; e += 256) sII[e] = 0.0;
+        __syncthreads();
+    }
+    const double ivol = stress ? P.inv_vol[ic] : 0.0;
     for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
         const int npc = min(SO3_PC, p1 - c0), c1 = c0 + npc;
         if (nchunks > 1) build_records(c0, npc);        // a single chunk is still resident from pass 1
         for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
-            if (row == rself) continue;
+            const bool is_self = row == rself;
+            if (is_self && !stress) continue;
             const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
             const int a = max(q0, c0), b = min(q1, c1);
             if (a >= b) continue;
             double s[2] = {0.0, 0.0};
+            double rs[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // sum over pairs of R_j[a] * dP[c, k]
             for (int p = a; p < b; p++) {
                 const double *rec = recs + (p - c0) * REC;
                 const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
@@ -475,7 +492,14 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                     if (lane + 64 * rnd < ne) {
                         const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
                         const double *A = rec + 8, *B = rec + 8 + SO3_NLP;
-                        s[rnd] += rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
+                        const double term = rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
+                        s[rnd] += term;
+                        if (stress) {                       // R_j = R_i + r u (SO3.py:225-226, 254)
+                            const double rr = rec[4];
+                            rs[rnd][0] += (Ri[0] + rr * rec[0]) * term;
+                            rs[rnd][1] += (Ri[1] + rr * rec[1]) * term;
+                            rs[rnd][2] += (Ri[2] + rr * rec[2]) * term;
+                        }
                     }
                 }
                 so3_wave_lds_sync();
@@ -483,11 +507,25 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
 #pragma unroll
             for (int rnd = 0; rnd < 2; rnd++)
                 if (lane + 64 * rnd < ne) {
-                    double *o = P.dxdr + (size_t)row * ne + lane + 64 * rnd;
+                    const int e = lane + 64 * rnd;
+                    if (is_self) {      // periodic images of the centre itself: only the stress rows use them (SO3.py:264, 272-273)
+                        sII[e] += s[rnd];
+                        sII[96 + e] += rs[rnd][0]; sII[192 + e] += rs[rnd][1]; sII[288 + e] += rs[rnd][2];
+                        continue;
+                    }
+                    double *o = P.dxdr + (size_t)row * ne + e;
                     // a row whose pairs straddle a chunk boundary: this lane wrote the earlier part itself
                     *o = (q0 < c0) ? *o + s[rnd] : s[rnd];
+                    if (stress) {
+                        double *so = P.rdxdr + (size_t)row * ne * 3 + (e / 3) * 9 + (e % 3);
+#pragma unroll
+                        for (int a3 = 0; a3 < 3; a3++) {
+                            const double v = rs[rnd][a3] * ivol;        // rdxdr = -pstress / vol, pstress = -sum R_j (x) dP
+                            so[3 * a3] = (q0 < c0) ? so[3 * a3] + v : v;
+                        }
+                    }
                 }
-            self0 += s[0]; self1 += s[1];
+            if (!is_self) { self0 += s[0]; self1 += s[1]; }
         }
         if (nchunks > 1) __syncthreads();
     }
@@ -498,6 +536,13 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         double s = 0.0;
         for (int w2 = 0; w2 < SO3_WAVES; w2++) s += sSelf[w2 * 96 + e];
         P.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
+        if (stress) {
+            // pstress(i, i) = -sum_{images of i} R_j (x) dP + R_i (x) sum_{all pairs} dP  (SO3.py:264, 272-273)
+            const double tot = s + sII[e];
+            double *so = P.rdxdr + (size_t)rself * ne * 3 + (e / 3) * 9 + (e % 3);
+#pragma unroll
+            for (int a3 = 0; a3 < 3; a3++) so[3 * a3] = (sII[96 * (a3 + 1) + e] - Ri[a3] * tot) * ivol;
+        }
     }
 }
 
@@ -571,7 +616,21 @@ extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double r
                                       const double *vec, const double *wj, const int *centre_pair0,
                                       const int *centre_row0, const int *row_pair0, const int *self_row,
                                       double *x, double *dxdr) {
+    return gpr_so3_power_spectrum_stress(stream, nmax, lmax, rcut, alpha, nseg, ncheb, table, ncentres, npairs, nrows, vec, wj,
+                                         centre_pair0, centre_row0, row_pair0, self_row, x, dxdr, nullptr, nullptr, nullptr);
+}
+
+// same with the stress rows rdxdr[S, d, 3, 3] = -pstress / volume of SO3.calculate(stress=True) (SO3.py:240-306);
+// positions[nc, 3] = centre positions as given by the caller, inv_vol[nc] = 1 / cell volume per centre (device);
+// rdxdr == NULL switches the stress rows off
+extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                                             const double *table, int ncentres, int npairs, int nrows,
+                                             const double *vec, const double *wj, const int *centre_pair0,
+                                             const int *centre_row0, const int *row_pair0, const int *self_row,
+                                             double *x, double *dxdr, const double *positions, const double *inv_vol,
+                                             double *rdxdr) {
     hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(!rdxdr || (positions && inv_vol), "gpr_so3_power_spectrum_stress: rdxdr needs positions and inv_vol");
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1);
     int rc = so3_check_limits(nmax, lmax, 1, nseg, ncheb, "gpr_so3_power_spectrum");
     if (rc) return rc;
@@ -585,6 +644,7 @@ extern "C" int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double r
     { const char *dbg = getenv("GPR_SO3_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }   // phase ablation for profiling only
     A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
+    A.positions = positions; A.inv_vol = inv_vol; A.rdxdr = rdxdr;
     const so3_lds lay = so3_layout(nmax, lmax);
     const size_t lds_bytes = (size_t)lay.total * sizeof(double);
     if (lds_bytes > 96 * 1024) {

@@ -235,6 +235,15 @@ int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double
                            const double *vec, const double *wj, const int *centre_pair0,
                            const int *centre_row0, const int *row_pair0, const int *self_row,
                            double *x, double *dxdr);
+/* same plus the stress rows rdxdr[nrows, d, 3, 3] = -pstress / volume of SO3.calculate(stress=True)
+ * (SO3.py:240-306): positions[ncentres, 3] = centre positions as the caller gave them (not wrapped),
+ * inv_vol[ncentres] = 1 / cell volume of the centre's structure, both device; rdxdr == NULL: as above */
+int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                                  const double *table, int ncentres, int npairs, int nrows,
+                                  const double *vec, const double *wj, const int *centre_pair0,
+                                  const int *centre_row0, const int *row_pair0, const int *self_row,
+                                  double *x, double *dxdr, const double *positions, const double *inv_vol,
+                                  double *rdxdr);
 
 /* ------------------------------------------------------------------ dense FP64 linear algebra */
 /* Row-major device matrices.  Lower Cholesky in place: on return the lower triangle of a holds

@@ -197,3 +197,46 @@ def test_dot_direct_features_match_packed_features_and_diag():
     assert float((P_direct - P_packed).abs().max()) < 1e-13 * scale
     assert float((diag_direct - diag_packed).abs().max()) < 1e-12 * float(diag_packed.abs().max())
     assert frees[0] is None and len(frees[2]) == len(batch[2]) - 3
+
+
+def test_predict_structure_with_stress_matches_oracle(port_natives):
+    """predict_structure(stress=True): SO3 stress rows (rdxdr) on the GPU -> 9-wide force rows -> K_trans1 alpha
+    (gaussianprocess.py:846-918, RBF_mb.py:206-229) against the oracle descriptor + the plain-C stress natives"""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from gpr_calculator_amd.utilities import species_numbers
+    from gpr_calculator_amd.neighbors import symbol_of
+    from oracle import gp_numpy as og
+    from oracle.so3_numpy import so3_calculate
+    strucs = training_structures(3, species=(46, 78))
+    force_ids = [0, 1, 3]
+    gp = GP(kernel=RBF_mb(para=[2.5, 1.3], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0, stress=True),
+            noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+    gp.fit(gp.points_from_structures([(a, E, F, True, force_ids) for (a, E, F) in strucs]), show=False, opt=False)
+    new = fcc_cell(seed=91, reps=1, species=(46, 78), sigma=0.08)
+    E, F, S = gp.predict_structure(new, stress=True, return_std=False, f_tol=1e-10)
+    assert S.shape == (len(new), 6)
+
+    okern = og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=port_natives)
+    train_x, y, NE = oracle_train(okern, strucs, force_ids)
+    K = okern.k_total(train_x)
+    _, alpha, _ = og.fit_core(K, y, NE, 0.002, 0.1)
+    d = so3_calculate(new.numbers, new.positions, new.cell, new.pbc, 3, 4, 5.0, 2.0, stress=True)
+    ele = species_numbers([symbol_of(z) for z in new.numbers])
+    energy = og.list_to_tuple([(d["x"], ele)], mode="energy")
+    force9 = []
+    for a in range(len(new)):                                   # every atom carries stress rows (gaussianprocess.py:852-870)
+        ids = np.argwhere(d["seq"][:, 1] == a).flatten()
+        ci = d["seq"][ids, 0]
+        rd = d["rdxdr"][ids].reshape(len(ids), d["x"].shape[1], 9)[:, :, [0, 4, 8, 1, 2, 5]]
+        force9.append((d["x"][ci], np.concatenate((d["dxdr"][ids], rd), axis=2), ele[ci]))
+    W = okern.w
+    f9 = og.list_to_tuple(force9, stress=True)
+    C_fe, C_se = W.rbf_kef(train_x["energy"], f9, 2.5, 1.3, 2.0, stress=True, transpose=True)
+    C_ff, C_sf = W.rbf_kff(f9, train_x["force"], 2.5, 1.3, 2.0, stress=True, tol=1e-10)
+    S_ref = (np.hstack((C_se, C_sf)) @ alpha).reshape(len(new), 6)
+    F_ref = (np.hstack((C_fe, C_ff)) @ alpha).reshape(len(new), 3)
+    assert np.abs(F - F_ref).max() < F_TOL
+    assert np.abs(S - S_ref).max() < 1e-5 * max(1.0, np.abs(S_ref).max())

@@ -27,6 +27,11 @@ def test_so3_matches_reference_golden(path):
     assert np.array_equal(out["seq"], z["seq"])
     assert rel(out["x"], z["x"]) < REL and rel(out["dxdr"], z["dxdr"]) < REL
     assert out["rdxdr"] is None and len(out["elements"]) == len(z["numbers"])
+    if "rdxdr" in z.files:      # stress rows of the reference's own SO3.calculate(stress=True)
+        des.stress = True
+        out = des.calculate(atoms)
+        assert rel(out["x"], z["x"]) < REL and rel(out["dxdr"], z["dxdr"]) < REL
+        assert out["rdxdr"].shape == z["rdxdr"].shape and rel(out["rdxdr"], z["rdxdr"]) < REL
 
 
 def test_so3_batch_matches_oracle_on_bench_cells():
@@ -140,7 +145,9 @@ def test_so3_dense_small_cell_matches_oracle(scale):
     des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
     nb = des.neighbor_index_batch([s])
     assert np.diff(nb["centre_pair0"]).min() > (48 if scale == 1.0 else 96) and np.diff(nb["row_pair0"]).max() > 20
+    des.stress = True           # the centre's own periodic images enter the (i, i) stress row only
     out = des.calculate(s)
-    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, 3, 4, 5.0, 2.0)
+    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, 3, 4, 5.0, 2.0, stress=True)
     assert np.array_equal(out["seq"], ref["seq"])
     assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
+    assert rel(out["rdxdr"], ref["rdxdr"]) < REL
