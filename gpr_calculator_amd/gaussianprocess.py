@@ -963,8 +963,23 @@ class GP():
         return pts
 
     def sparsify(self, e_tol=1e-10, f_tol=1e-10):
-        raise NotImplementedError("CUR sparsification (gaussianprocess.py:1004-1023) is not called by any driver "
-                                  "of the reference and is outside the hot path (SURVEY.md section 2 #16)")
+        """Remove training points the covariance matrix does not need (gaussianprocess.py:1004-1023): CUR leverage
+        scores of the energy block and of the force block of K; a force point goes when all three of its rows are
+        selected.  K comes from the device; the symmetric eigen-decomposition runs on the host with numpy like the
+        reference's (an offline maintenance call, not on the prediction / fit path)."""
+        K = self.kernel.k_total(self.train_x)
+        N_e = len(self.train_x["energy"][-1])
+        N_f = len(self.train_x["force"][-1])
+        pts_e = CUR(K[:N_e, :N_e], e_tol)
+        pts = CUR(K[N_e:, N_e:], f_tol)
+        pts_f = []
+        if N_f > 1:
+            chosen = set(int(p) for p in pts)
+            pts_f = [i for i in range(N_f) if all(3 * i + c in chosen for c in range(3))]
+        print("{:d} energy and {:d} forces will be removed".format(len(pts_e), len(pts_f)))
+        if len(pts_e) + len(pts_f) > 0:
+            self.remove_train_pts([int(p) for p in pts_e], pts_f)
+        return list(pts_e), pts_f
 
     @classmethod
     def set_GPR(cls, images, base, kernel='RBF', zeta=2.0, noise_e=0.002, noise_f=0.1, lmax=4, nmax=3, rcut=5.0,
@@ -1044,6 +1059,17 @@ class GP():
         instance.f_coef = dict0["noise"]["f_coef"]
         instance.noise_bounds = dict0["noise"]["bounds"]
         return instance
+
+
+def CUR(K, l_tol=1e-10):
+    """rows of a covariance block ranked by their weight in the near-null eigenvectors (eigenvalue < l_tol), the first
+    N_low of them (gaussianprocess.py:1165-1182; Appendix D of Jinnouchi et al., Phys. Rev. B 100, 014105 (2019))"""
+    if K.shape[0] == 0:
+        return np.zeros(0, dtype=np.int64)
+    L, U = np.linalg.eigh(K)
+    low = L < l_tol
+    omega = (U[:, low] ** 2).sum(axis=1)
+    return np.argsort(-omega, kind="stable")[:int(low.sum())]
 
 
 def _concat_energy(tuples):

@@ -66,3 +66,19 @@ def test_native_batch_index_matches_numpy_index():
             assert np.array_equal(nb["row_pair0"][r0:r1 + 1] - p0, ref["row_pair0"])
             assert np.array_equal(nb["self_row"][a0:a1] - r0, ref["self_row"])
             p0 += P
+
+
+def test_cur_selection_matches_leverage_score_definition():
+    """CUR (gaussianprocess.py:1165-1182): rows ranked by summed squared components in the eigenvectors with
+    eigenvalue below the tolerance; as many rows as there are such eigenvectors"""
+    from gpr_calculator_amd.gaussianprocess import CUR
+    rng = np.random.default_rng(4)
+    A = rng.normal(size=(14, 6))
+    K = A @ A.T                                  # rank 6: eight near-null directions
+    ids = CUR(K, 1e-8)
+    lam, U = np.linalg.eigh(K)
+    null = [k for k in range(len(lam)) if lam[k] < 1e-8]
+    assert len(ids) == len(null) == 8
+    score = np.array([sum(U[j, k] ** 2 for k in null) for j in range(len(lam))])
+    assert set(int(i) for i in ids) == set(int(i) for i in np.argsort(-score)[:8])
+    assert len(CUR(np.eye(5), 1e-10)) == 0
