@@ -265,7 +265,6 @@ __global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double 
 __global__ void __launch_bounds__(256) potrf_diag_inv_kernel(double *a, long long lda, int kb, int k0, int *info,
                                                               double *dinv) {
     __shared__ double T[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
     const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6;
     for (int i = ty; i < NB; i += 4) {
         double v = (i == c) ? 1.0 : 0.0;                       // identity padding beyond kb
@@ -284,20 +283,24 @@ __global__ void __launch_bounds__(256) potrf_diag_inv_kernel(double *a, long lon
             if (c > j && c <= i) T[i][c] -= T[i][j] * T[c][j];
         __syncthreads();
     }
-    // inverse: thread c < 64 solves L x = e_c by forward substitution (rows >= c only)
+    // inverse: lane c of the first wavefront solves L x = e_c by forward substitution with x in registers (fully
+    // unrolled, static indices; x_i = 0 for i < c falls out of the arithmetic, so the control flow is uniform and every
+    // T[i][q] read is an LDS broadcast); two partial sums per row halve the dependent FMA chain
     if (ty == 0) {
-        for (int i = 0; i < NB; i++) X[i][c] = 0.0;
-        for (int i = c; i < NB; i++) {
-            double v = (i == c) ? 1.0 : 0.0;
-            for (int q = c; q < i; q++) v -= T[i][q] * X[q][c];
-            X[i][c] = v / T[i][i];
+        double x[NB];
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            double v0 = (i == c) ? 1.0 : 0.0, v1 = 0.0;
+#pragma unroll
+            for (int q = 0; q + 1 < i; q += 2) { v0 -= T[i][q] * x[q]; v1 -= T[i][q + 1] * x[q + 1]; }
+            if (i & 1) v0 -= T[i][i - 1] * x[i - 1];
+            x[i] = (v0 + v1) / T[i][i];
         }
+#pragma unroll
+        for (int i = 0; i < NB; i++) dinv[i * NB + c] = (i < kb && c < kb) ? x[i] : 0.0;
     }
-    __syncthreads();
-    for (int i = ty; i < NB; i += 4) {
+    for (int i = ty; i < NB; i += 4)
         if (i < kb && c < kb) a[(long long)i * lda + c] = (c <= i) ? T[i][c] : 0.0;
-        dinv[i * NB + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
-    }
 }
 
 // 64-wide slabs times a 64 x 64 block W (= L_kk^-1, zero padded):
