@@ -185,53 +185,6 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
             }
 }
 
-// unblocked Cholesky of the kb x kb diagonal block at a (lower), one workgroup
-__global__ void __launch_bounds__(256) potrf_diag_kernel(double *a, long long lda, int kb, int k0, int *info) {
-    __shared__ double T[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < kb * kb; e += 256) { int i = e / kb, j = e % kb; T[i][j] = a[(long long)i * lda + j]; }
-    __syncthreads();
-    for (int j = 0; j < kb; j++) {
-        if (tid == 0) {
-            double p = T[j][j];
-            if (!(p > 0.0)) { if (info) atomicCAS(info, 0, k0 + j + 1); }
-            T[j][j] = sqrt(p);
-        }
-        __syncthreads();
-        const double piv = T[j][j];
-        if (tid > j && tid < kb) T[tid][j] /= piv;
-        __syncthreads();
-        const int rem = kb - j - 1;
-        for (int e = tid; e < rem * rem; e += 256) {
-            int i = j + 1 + e / rem, c = j + 1 + e % rem;
-            if (c <= i) T[i][c] -= T[i][j] * T[c][j];
-        }
-        __syncthreads();
-    }
-    for (int e = tid; e < kb * kb; e += 256) {
-        int i = e / kb, j = e % kb;
-        a[(long long)i * lda + j] = (j <= i) ? T[i][j] : 0.0;
-    }
-}
-
-// panel solve X L^T = P for the rows below the diagonal block: one thread per row
-__global__ void __launch_bounds__(256) potrf_panel_kernel(const double *lkk, double *p, long long lda, int kb, int rows) {
-    __shared__ double L[NB][NB + 1];
-    const int tid = threadIdx.x;
-    for (int e = tid; e < kb * kb; e += 256) { int i = e / kb, j = e % kb; L[i][j] = lkk[(long long)i * lda + j]; }
-    __syncthreads();
-    const int r = blockIdx.x * 256 + tid;
-    if (r >= rows) return;
-    double *x = p + (long long)r * lda;
-    double xr[NB];
-    for (int c = 0; c < kb; c++) {
-        double v = x[c];
-        for (int q = 0; q < c; q++) v -= xr[q] * L[c][q];
-        xr[c] = v / L[c][c];
-    }
-    for (int c = 0; c < kb; c++) x[c] = xr[c];
-}
-
 // diagonal-block solve of the blocked TRSM: one thread per right-hand-side column
 // trans = 0: L x = b (forward) ; trans = 1: L^T x = b (backward)
 __global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double *lkk, long long ldl, int kb,
@@ -259,48 +212,128 @@ __global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double 
     for (int i = 0; i < kb; i++) b[(long long)i * ldb + col] = x[i];
 }
 
-// Cholesky of one kb x kb diagonal block (kb <= 64) in LDS by a single workgroup, followed by the inverse
-// of the factor.  Writes L back (upper part zeroed) and L^-1 as a zero-padded 64 x 64 row-major block to
-// `dinv`: panel solves and triangular solves then become small matrix products (tri_apply_kernel).
+// Cholesky of one kb x kb diagonal block (kb <= 64) in LDS by one workgroup, followed by the inverse of the factor;
+// writes L back (upper part zeroed) and L^-1 as a zero-padded 64 x 64 row-major block to `dinv`: panel solves and
+// triangular solves then become small matrix products (tri_apply_kernel).  This kernel sits on the critical path of
+// the blocked factorisation (one launch per 64 columns), so it is built for latency: the block is split 32 + 32,
+//   L = [[L11, 0], [L21, L22]],   L^-1 = [[W1, 0], [-W2 L21 W1, W2]],   W = inverse of the diagonal factor,
+// the two 32 x 32 factorisations / inversions run in one wavefront with compact loops (no block barriers inside; a
+// fully unrolled register version was instruction-fetch bound at ~90 us), and the three coupling products use all
+// 256 threads.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// one wavefront: in-place Cholesky of the 32 x 32 block of T at offset o and its inverse into the same block of X
+// (X zero-initialised).  Left-looking, lane = row (factor) / column (inverse): per column one dot product over the
+// finished columns, one v_readlane broadcast of the pivot, one reciprocal square root, one LDS store and one
+// wavefront-level LDS sync -- the 32-step dependency chain carries nothing else.
+__device__ __forceinline__ double readlane_f64(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ void chol32_inv(double (*T)[NB + 1], double (*X)[NB + 1], double *D, int o, int lane, int k0, int *info) {
+    const int i = lane & 31;
+    for (int j = 0; j < 32; j++) {
+        double s0 = 0.0, s1 = 0.0;
+        int q = 0;
+        for (; q + 1 < j; q += 2) {
+            s0 += T[o + i][o + q] * T[o + j][o + q];
+            s1 += T[o + i][o + q + 1] * T[o + j][o + q + 1];
+        }
+        if (q < j) s0 += T[o + i][o + q] * T[o + j][o + q];
+        const double s = T[o + i][o + j] - (s0 + s1);          // meaningful for rows i >= j
+        const double ajj = readlane_f64(s, j);
+        if (lane == 0 && !(ajj > 0.0) && info) atomicCAS(info, 0, k0 + o + j + 1);
+        const double inv = rsqrt(ajj);
+        if (lane < 32 && i >= j) T[o + i][o + j] = (i == j) ? ajj * inv : s * inv;
+        if (lane == j) D[o + j] = inv;                          // 1 / L_jj
+        wave_lds_sync();
+    }
+    for (int r = 0; r < 32; r++) {                              // forward substitution L x = e_i, column i per lane
+        double v0 = (r == i) ? 1.0 : 0.0, v1 = 0.0;
+        int q = 0;
+        for (; q + 1 < r; q += 2) {
+            v0 -= T[o + r][o + q] * X[o + q][o + i];
+            v1 -= T[o + r][o + q + 1] * X[o + q + 1][o + i];
+        }
+        if (q < r) v0 -= T[o + r][o + q] * X[o + q][o + i];
+        if (lane < 32) X[o + r][o + i] = (v0 + v1) * D[o + r];
+        wave_lds_sync();
+    }
+}
+
 __global__ void __launch_bounds__(256) potrf_diag_inv_kernel(double *a, long long lda, int kb, int k0, int *info,
                                                               double *dinv) {
     __shared__ double T[NB][NB + 1];
+    __shared__ double X[NB][NB + 1];
+    __shared__ double D[NB];
     const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6;
     for (int i = ty; i < NB; i += 4) {
         double v = (i == c) ? 1.0 : 0.0;                       // identity padding beyond kb
         if (i < kb && c < kb) v = (c <= i) ? a[(long long)i * lda + c] : 0.0;
         T[i][c] = v;
+        X[i][c] = 0.0;
     }
     __syncthreads();
-    for (int j = 0; j < kb; j++) {
-        const double ajj = T[j][j];
-        if (tid == 0 && !(ajj > 0.0) && info) atomicCAS(info, 0, k0 + j + 1);
-        const double piv = sqrt(ajj);
-        __syncthreads();
-        if (ty == 0) { if (c == j) T[j][j] = piv; else if (c > j && c < kb) T[c][j] /= piv; }
-        __syncthreads();
-        for (int i = j + 1 + ty; i < kb; i += 4)               // row i, column c in (j, i]
-            if (c > j && c <= i) T[i][c] -= T[i][j] * T[c][j];
-        __syncthreads();
+    if (ty == 0) chol32_inv(T, X, D, 0, c, k0, info);          // L11, W1
+    __syncthreads();
+    const int pr = tid >> 5, pc = tid & 31;                    // product threads: rows pr + 8u, column pc
+    double acc[4];
+    // L21 = A21 W1^T
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] = 0.0;
+    for (int k = 0; k <= pc; k++) {
+        const double w = X[pc][k];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
     }
-    // inverse: lane c of the first wavefront solves L x = e_c by forward substitution with x in registers (fully
-    // unrolled, static indices; x_i = 0 for i < c falls out of the arithmetic, so the control flow is uniform and every
-    // T[i][q] read is an LDS broadcast); two partial sums per row halve the dependent FMA chain
-    if (ty == 0) {
-        double x[NB];
+    __syncthreads();
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            double v0 = (i == c) ? 1.0 : 0.0, v1 = 0.0;
+    for (int u = 0; u < 4; u++) T[32 + pr + 8 * u][pc] = acc[u];
+    __syncthreads();
+    // A22 -= L21 L21^T
 #pragma unroll
-            for (int q = 0; q + 1 < i; q += 2) { v0 -= T[i][q] * x[q]; v1 -= T[i][q + 1] * x[q + 1]; }
-            if (i & 1) v0 -= T[i][i - 1] * x[i - 1];
-            x[i] = (v0 + v1) / T[i][i];
-        }
+    for (int u = 0; u < 4; u++) acc[u] = 0.0;
+    for (int k = 0; k < 32; k++) {
+        const double w = T[32 + pc][k];
 #pragma unroll
-        for (int i = 0; i < NB; i++) dinv[i * NB + c] = (i < kb && c < kb) ? x[i] : 0.0;
+        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
     }
-    for (int i = ty; i < NB; i += 4)
+#pragma unroll
+    for (int u = 0; u < 4; u++) T[32 + pr + 8 * u][32 + pc] -= acc[u];
+    __syncthreads();
+    if (ty == 0) chol32_inv(T, X, D, 32, c, k0, info);         // L22, W2
+    __syncthreads();
+    // Y = L21 W1 (parked in the upper-right block of X), then X21 = -W2 Y
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] = 0.0;
+    for (int k = pc; k < 32; k++) {                            // W1 is lower triangular: rows k >= pc of column pc
+        const double w = X[k][pc];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) X[pr + 8 * u][32 + pc] = acc[u];
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) acc[u] = 0.0;
+    for (int k = 0; k < 32; k++) {
+        const double y = X[k][32 + pc];
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc[u] -= X[32 + pr + 8 * u][32 + k] * y;     // W2 upper part is zero
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) { X[32 + pr + 8 * u][pc] = acc[u]; X[pr + 8 * u][32 + pc] = 0.0; }
+    __syncthreads();
+    for (int i = ty; i < NB; i += 4) {
         if (i < kb && c < kb) a[(long long)i * lda + c] = (c <= i) ? T[i][c] : 0.0;
+        dinv[i * NB + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
+    }
 }
 
 // 64-wide slabs times a 64 x 64 block W (= L_kk^-1, zero padded):
