@@ -201,6 +201,14 @@ class GP():
         kernel = self.kernel
         kernel.update(kernel_params)
 
+        if self.weight_space_fit:
+            res = self._lml_weight_space(noise_e, noise_f, eval_gradient)
+            if res is not None:
+                if not eval_gradient:
+                    return res[0]
+                llg = res[1] if self.noise_bounds is not None else res[1][:-1]
+                return res[0], llg
+
         if eval_gradient:
             K, dK0, dK1, _ = self._train_K(grad=True)
         else:
@@ -234,6 +242,61 @@ class GP():
         if self.noise_bounds is None:
             llg = llg[:-1]
         return MLL, llg
+
+    def _lml_weight_space(self, noise_e, noise_f, eval_gradient):
+        """(LML, gradient[sigma, sigma0, noise]) of a kernel with an explicit feature map through the F x F matrix
+        G = I + Psi'^T D^-1 Psi' (Psi' = sigma Psi, D the noise diagonal) instead of the N x N factorisation:
+            y^T (K+D)^-1 y = y^T D^-1 y - b^T G^-1 b,   log det(K+D) = log det D + log det G,   b = Psi'^T D^-1 y,
+            Psi'^T alpha = G^-1 b,   Psi'^T (K+D)^-1 Psi' = I - G^-1,   diag (K+D)^-1 = D^-1 - D^-1 diag(Psi' G^-1 Psi'^T) D^-1
+        with the same dK/dtheta as the dense route (dK/dsigma = 2 K / sigma; the constant 1.6 sigma^2 sigma0 energy
+        block of dot_kernel.py:58; the noise column).  None when the kernel has no feature map for this data."""
+        kernel = self.kernel
+        if not hasattr(kernel, "_feature_path"):
+            return None
+        train_x = self.train_x
+        species = kernel._feature_path(train_x, None, kernel.zeta)
+        if species is None:
+            return None
+        Psi = kernel._psi(train_x, species)
+        N, F = Psi.shape
+        NE = self._n_energy_points(train_x)
+        sig, sig0 = float(kernel.sigma), float(kernel.sigma0)
+        rs = torch.empty(N, dtype=dev.F64, device=Psi.device)
+        rs[:NE] = 1.0 / noise_e
+        rs[NE:] = 1.0 / noise_f
+        S = Psi * (sig * rs)[:, None]
+        yt = dev.to_dev(self.y_train).reshape(-1) * rs
+        G = dev.gemm(S, S, transa=True)
+        G.diagonal().add_(1.0)
+        b = dev.gemm(S, yt.reshape(-1, 1), transa=True)
+        info, dinv = dev.potrf_lower_(G, want_dinv=True)
+        if int(info.item()) != 0:
+            return (-np.inf, np.zeros(3)) if eval_gradient else (-np.inf,)
+        u = b.clone()
+        dev.trsm_lower_(G, u, dinv=dinv)
+        dev.trsm_lower_(G, u, trans=True, dinv=dinv)                      # G^-1 b = Psi'^T alpha
+        quad = float((yt * yt).sum().item()) - dev.frob_dot(b, u).item()
+        logdet = 2.0 * (NE * np.log(noise_e) + (N - NE) * np.log(noise_f)) + 2.0 * dev.sum_log_diag(G).item()
+        MLL = -0.5 * quad - 0.5 * logdet - N / 2 * np.log(2 * np.pi)
+        if not eval_gradient:
+            return (MLL,)
+        # every G^-1 quadratic form goes through C^-1 (G = C C^T): x^T G^-1 x = |C^-1 x|^2 keeps the cancellations below
+        # (N_E / noise_e^2 - ..., 1 - ...) at working precision, which an explicit G^-1 (cond ~ 1e10) does not
+        Ci = torch.eye(F, dtype=dev.F64, device=Psi.device)
+        dev.trsm_lower_(G, Ci, dinv=dinv)                                   # C^-1
+        tr_Ginv = dev.frob_dot(Ci, Ci).item()
+        g_sigma = (dev.frob_dot(u, u).item() - (F - tr_Ginv)) / sig
+        alpha = rs * (yt - dev.gemm(S, u).reshape(-1))                     # (K+D)^-1 y
+        uE = (S[:NE] * rs[:NE, None]).sum(dim=0).reshape(-1, 1)            # Psi'^T D^-1 1_E
+        zE = dev.gemm(Ci, uE)
+        one_Kinv_one = NE / noise_e ** 2 - dev.frob_dot(zE, zE).item()
+        c0 = 0.8 * 2 * sig ** 2 * sig0                                      # dot_kernel.py:58 (sic)
+        g_sigma0 = 0.5 * c0 * (float(alpha[:NE].sum().item()) ** 2 - one_Kinv_one)
+        W = dev.gemm(S, Ci, transb=True)                                    # rows C^-1 s_i
+        kd = rs * rs * (1.0 - dev.rowdot(W, W))                             # diag (K+D)^-1
+        a2 = alpha * alpha - kd
+        g_noise = 0.5 * (2 * noise_e * a2[:NE].sum().item() + 2 * noise_f * a2[NE:].sum().item())
+        return MLL, np.array([g_sigma, g_sigma0, g_noise])
 
     def optimize(self, fun, theta0, bounds, maxiter=10):
         """scipy L-BFGS-B on the host, exactly the reference's call (gaussianprocess.py:204-220)"""
