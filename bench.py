@@ -134,6 +134,7 @@ def main():
     ap.add_argument("--n-train", type=int, default=N_TRAIN)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pair-route", action="store_true", help="skip the extra pair-kernel measurement of the Dot run")
     args = ap.parse_args()
 
     from gpr_calculator_amd import _lib, device as dev
@@ -224,6 +225,33 @@ def main():
                     "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "flop_per_step": flops,
                     "work_unit": unit_note,
                     "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}}
+        # the same step through the row-pair route (what every other kernel / zeta takes): the Dot kernel object with its
+        # feature map switched off builds K_trans with kblock_kernel<FF> -- the FP64-MFMA kernel of SURVEY section 8d --
+        # measured live here so that its roofline point sits next to the headline's
+        if world == 1 and args.kernel == "Dot" and not args.no_pair_route:
+            gp.kernel.use_feature_map = False
+            gp._ws_cache = None
+            gp.predict_structures(batch, return_std=True, f_tol=1e-8)
+            dev.profile_enable(True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                gp.predict_structures(batch, return_std=True, f_tol=1e-8)
+            torch.cuda.synchronize()
+            pr_ms = (time.perf_counter() - t1) / 2 * 1e3
+            pprof = dev.profile_fetch()
+            dev.profile_enable(False)
+            gp.kernel.use_feature_map = True
+            gp._ws_cache = None
+            ff_ms, ff_n = pprof.get("ff", (0.0, 0))
+            if ff_n:
+                ff_flop = same_species_pairs(ele_rows, tE) * FLOP_PER_PAIR_FF
+                ach = ff_flop / (ff_ms / ff_n * 1e-3) / 1e12
+                roofline["pair_route"] = {"kernel": "kblock_kernel<FF>: force-force block of K_trans, Dot zeta=2 pair form",
+                                          "bound": "mfma", "avg_launch_ms": ff_ms / ff_n, "achieved": ach,
+                                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
+                                          "ms_per_step": pr_ms, "structures_per_s": args.batch / (pr_ms * 1e-3),
+                                          "work_unit": "1.10 kflop per same-species row pair (SURVEY.md section 8d)"}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(gp, batch)
