@@ -1,0 +1,103 @@
+"""GPU: edge cases of the device-resident prediction front end (neighbour search, descriptor, force-point gather,
+feature / pair routes) -- ragged batches, fixed atoms, atoms without neighbours, structures larger than one
+wavefront of atoms, non-periodic clusters, the empty batch -- each checked against the one-structure tuple route
+(host descriptor download, packed sets), which in turn is pinned to the oracle in test_gpu_gp.py."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(kind):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    kern = RBF_mb(para=[2.5, 1.3], zeta=2.0) if kind == "RBF" else Dot_mb(para=[2.0, 2.0], zeta=2.0)
+    gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+    rows = []
+    for seed in range(3):
+        a = fcc_cell(seed=seed, reps=1, species=(46, 78), sigma=0.08)
+        E, F = lj_energy_forces(a)
+        rows.append((a, E, F, True, [0, 1, 3]))
+    gp.fit(gp.points_from_structures(rows), show=False, opt=False)
+    return gp
+
+
+def _ragged_batch():
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    rng = np.random.default_rng(11)
+    big = fcc_cell(seed=5, reps=3, species=(46, 78), sigma=0.05)             # 108 atoms: more than one wavefront of j
+    small = fcc_cell(seed=6, reps=1, species=(46, 78), sigma=0.08)
+    small.fixed = np.array([0, 2])
+    mid = fcc_cell(seed=7, reps=2, species=(46,), sigma=0.1)
+    mid.fixed = np.array([31])
+    cluster = SimpleAtoms(numbers=[46, 78, 46, 46, 78], positions=rng.normal(size=(5, 3)) * 1.6,
+                          cell=np.eye(3) * 30.0, pbc=[False, False, False])
+    # one atom 9 A away from everything: no neighbour within rcut, its descriptor row is zero
+    lonely = SimpleAtoms(numbers=[46, 46, 78, 46], positions=[[0, 0, 0], [2.6, 0.1, 0], [0.2, 2.7, 0.1], [12.0, 12.0, 12.0]],
+                         cell=np.eye(3) * 40.0, pbc=[False, False, False])
+    return [big, small, mid, cluster, lonely]
+
+
+@pytest.mark.parametrize("kind", ["Dot", "RBF"])
+def test_ragged_batch_matches_one_structure_tuple_route(kind):
+    gp = _model(kind)
+    batch = _ragged_batch()
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True, f_tol=1e-10)
+    gp.device_single = False
+    for k, s in enumerate(batch):
+        e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True, f_tol=1e-10)
+        assert Fs[k].shape == (len(s), 3)
+        assert abs(Es[k] - e1) < 1e-8 * max(1.0, abs(e1)) and np.abs(Fs[k] - f1).max() < 1e-8
+        assert abs(Es_std[k] - es1) < 1e-7 and np.abs(Fs_std[k] - fs1).max() < 1e-7
+    for k in (1, 2):                                                           # fixed atoms: zero force and zero std rows
+        fx = batch[k].fixed
+        assert np.all(Fs[k][fx] == 0.0) and np.all(Fs_std[k][fx] == 0.0)
+    # the atom without neighbours: finite outputs, zero descriptor row
+    d = gp.descriptor.calculate(batch[4])
+    assert np.all(d["x"][3] == 0.0) and np.isfinite(Fs[4]).all() and np.isfinite(Fs_std[4]).all()
+    # the device-resident single-structure route agrees as well
+    gp.device_single = True
+    e2, f2, _, es2, fs2 = gp.predict_structure(batch[0], stress=False, return_std=True, f_tol=1e-10)
+    assert abs(e2 - Es[0]) < 1e-9 * max(1.0, abs(e2)) and np.abs(f2 - Fs[0]).max() < 1e-9
+
+
+def test_empty_batch_and_results_without_std():
+    gp = _model("Dot")
+    assert gp.predict_structures([], return_std=True) == ([], [], [], [])
+    batch = _ragged_batch()[:2]
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=False)
+    Es2, Fs2, _, _ = gp.predict_structures(batch, return_std=True)
+    assert Es_std == [None, None] and Fs_std == [None, None]
+    for k in range(2):
+        assert abs(Es[k] - Es2[k]) < 1e-10 * max(1.0, abs(Es2[k])) and np.abs(Fs[k] - Fs2[k]).max() < 1e-10
+
+
+def test_more_than_four_species_falls_back_to_pair_kernels():
+    """the Dot feature map covers up to four species; beyond that the same calls take the row-pair kernels"""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    sp = (8, 13, 46, 78, 79)
+    gp = GP(kernel=Dot_mb(para=[2.0, 2.0], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002, noise_f=0.1,
+            log_file="/tmp/gpr_test.log")
+    rows = []
+    for seed in range(3):
+        a = fcc_cell(seed=seed, reps=1, sigma=0.08)
+        a.numbers = np.array([sp[(seed + i) % 5] for i in range(len(a))])
+        a.numbers[0], a.numbers[1] = sp[seed % 5], sp[(seed + 3) % 5]
+        E, F = lj_energy_forces(a)
+        rows.append((a, E, F, True, [0, 1, 2, 3]))
+    gp.fit(gp.points_from_structures(rows), show=False, opt=False)
+    assert not gp._dense_pending                        # no weight-space fit: five species in the training set
+    new = fcc_cell(seed=9, reps=2, sigma=0.08)
+    new.numbers = np.array([sp[i % 5] for i in range(len(new))])
+    Es, Fs, Es_std, Fs_std = gp.predict_structures([new], return_std=True)
+    gp.device_single = False
+    e1, f1, _, es1, fs1 = gp.predict_structure(new, stress=False, return_std=True)
+    assert abs(Es[0] - e1) < 1e-8 * max(1.0, abs(e1)) and np.abs(Fs[0] - f1).max() < 1e-8
+    assert abs(Es_std[0] - es1) < 1e-7 and np.abs(Fs_std[0] - fs1).max() < 1e-7
