@@ -37,12 +37,13 @@ constexpr int GPR_KPAD = 4 * GPR_KSTEPS;
 constexpr int GPR_PLANE = GPR_KSTEPS * GPR_WAVE;   // doubles per 16x(4*KSTEPS) operand plane (4 KiB)
 constexpr int GPR_CHUNK_TILES = 8;     // stream tiles staged per LDS buffer (32 KiB)
 constexpr int GPR_GROUP_ROWS = 16;     // rows per resident group (one MFMA N extent)
+constexpr int GPR_WU_MAX_GROUPS = 8;   // resident groups one wavefront owns at most (a wave unit: consecutive points)
 constexpr int GPR_ELE_PAD_STREAM = INT_MIN;        // species code of padded / skipped stream rows
 constexpr int GPR_ELE_PAD_RESIDENT = INT_MIN + 1;  // ... resident rows (never equal to the above)
 
 // chunk descriptor of the stream side: tiles [tile0, tile0+ntiles) all belong to packed point `pt`
 struct gpr_chunk { int tile0, ntiles, pt, last; };
-// resident point descriptor: groups [group0, group0+ngroups)
+// resident wave-unit descriptor: groups [group0, group0+ngroups) hold the rows of the unit's points back to back
 struct gpr_rpoint { int group0, ngroups; };
 
 struct gpr_set {
@@ -61,13 +62,16 @@ struct gpr_set {
     int *ir_chunk0 = nullptr;       // stream only [nranges+1] chunk range of each launch range
     int *ir_pt0 = nullptr;          // stream only [nranges+1] first packed point of each range
     int nranges = 0;
-    gpr_rpoint *rpts = nullptr;     // resident only [npts]
+    gpr_rpoint *rpts = nullptr;     // resident only [nwu] wave units
+    int *wu_pt0 = nullptr;          // resident only [nwu+1] first packed point of each wave unit
+    int *rowpt = nullptr;           // resident only [rpad] packed point of every padded row (-1: padding)
+    int nwu = 0;
     int nchunks = 0, maxgroups = 0;
     // host mirrors used for launch planning
-    std::vector<int> h_perm, h_cnt, h_pt_chunk0, h_pt_tiles, h_groups;
+    std::vector<int> h_perm, h_cnt, h_pt_chunk0, h_pt_tiles;
     // host sources of the asynchronous uploads: kept alive with the set so that no stream
     // synchronisation is needed at creation time
-    std::vector<int> hk_src_row, hk_irc, hk_irp;
+    std::vector<int> hk_src_row, hk_irc, hk_irp, hk_rowpt, hk_wu_pt0;
     std::vector<double> hk_inv_cnt;
     std::vector<gpr_chunk> hk_chunks;
     std::vector<gpr_rpoint> hk_rpts;

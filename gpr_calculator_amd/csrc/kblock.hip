@@ -26,9 +26,10 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct kb_args {
     const double *a_ops; const int *a_ele; const double *a_norm; const gpr_chunk *a_chunks;
     const int *a_perm; const double *a_inv; const int *a_pt_chunk0;
-    const double *b_ops; const int *b_ele; const double *b_norm; const gpr_rpoint *b_pts;
+    const double *b_ops; const int *b_ele; const double *b_norm; const gpr_rpoint *b_wu;
+    const int *b_wu_pt0, *b_rowpt;   // first packed point of every wave unit [nwu+1]; packed point of every resident row
     const int *b_perm; const double *b_inv;
-    int b_npts, a_npts;
+    int b_npts, a_npts, b_nwu;
     const int *ir_chunk0;   // [nir+1] chunk range of each stream range
     const int *ir_pt0;      // [nir+1] first packed point of each stream range
     int njb, nir;
@@ -78,15 +79,16 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jb = blockIdx.x % P.njb, ir = blockIdx.x / P.njb;
-    const int jp = jb * NW + wave;                     // packed resident point of this wavefront
-    const bool active = jp < P.b_npts;
-    const int jlast = min((jb + 1) * NW, P.b_npts) - 1;
+    const int ju = jb * NW + wave;                     // resident wave unit of this wavefront (consecutive packed points)
+    const bool active = ju < P.b_nwu;
+    const int blk_pt0 = P.b_wu_pt0[jb * NW], blk_pt1 = P.b_wu_pt0[min((jb + 1) * NW, P.b_nwu)];   // points of this block
+    const int jlast = blk_pt1 - 1;
     if ((jb + ir) % P.shard_mod != P.shard_rem) return;   // multi-GPU: this task belongs to another rank
 
     int c0, c1;
     if (P.diag_only) {                                 // only the chunks of this block's own points
-        c0 = P.a_pt_chunk0[jb * NW];
-        c1 = P.a_pt_chunk0[jlast + 1];
+        c0 = P.a_pt_chunk0[blk_pt0];
+        c1 = P.a_pt_chunk0[blk_pt1];
     } else {
         if (P.symmetric && P.ir_pt0[ir] > jlast) return;   // range entirely below the diagonal
         c0 = P.ir_chunk0[ir];
@@ -94,16 +96,20 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
     }
     if (c0 >= c1) return;
 
-    gpr_rpoint pj = active ? P.b_pts[jp] : gpr_rpoint{0, 0};
-    const int maxg = P.b_pts[jb * NW].ngroups;         // packed order is descending in groups
-    const int j_orig = active ? P.b_perm[jp] : 0;
-    const double fac_j = (active && P.norm2) ? P.b_inv[jp] : 1.0;
+    gpr_rpoint pj = active ? P.b_wu[ju] : gpr_rpoint{0, 0};
+    __shared__ int sMaxg;                              // the wavefronts of a block walk their groups in lock step
+    if (tid == 0) sMaxg = 0;
+    __syncthreads();
+    if (lane == 0 && active) atomicMax(&sMaxg, pj.ngroups);
+    __syncthreads();
+    const int maxg = sMaxg;
 
     for (int g = 0; g < maxg; ++g) {
         const bool has = active && g < pj.ngroups;
         double Breg[NCB][KS];
         int eleB = GPR_ELE_PAD_RESIDENT;
         double normB = 0.0;
+        int my_pt = -1;                                // packed resident point of this lane's column (-1: padding)
         if (has) {
             const double *bp = P.b_ops + (size_t)(pj.group0 + g) * NCB * GPR_PLANE;
 #pragma unroll
@@ -111,6 +117,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
 #pragma unroll
                 for (int s = 0; s < KS; s++) Breg[t][s] = bp[(t * KS + s) * 64 + lane];
             eleB = P.b_ele[(pj.group0 + g) * 16 + (lane & 15)];
+            my_pt = P.b_rowpt[(pj.group0 + g) * 16 + (lane & 15)];
             if (MODE == GPR_MODE_EE) normB = P.b_norm[(pj.group0 + g) * 16 + (lane & 15)];
         } else {
 #pragma unroll
@@ -119,6 +126,14 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                 for (int s = 0; s < KS; s++) Breg[t][s] = 0.0;
         }
 
+        // the rows of a group belong to a contiguous run of points [pt_lo, pt_hi] (one point unless a boundary falls
+        // inside the group); every lane accumulates the bin of its own column's point
+        int pt_lo = my_pt < 0 ? INT_MAX : my_pt, pt_hi = my_pt;
+#pragma unroll
+        for (int o = 8; o >= 1; o >>= 1) {
+            pt_lo = min(pt_lo, __shfl_xor(pt_lo, o, 64));
+            pt_hi = max(pt_hi, __shfl_xor(pt_hi, o, 64));
+        }
         double bin[NOUT], bin2[GRAD ? NOUT : 1];
 #pragma unroll
         for (int k = 0; k < NOUT; k++) bin[k] = 0.0;
@@ -160,8 +175,8 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
             if (c + 1 < c1) GPR_STAGE_LOAD(c + 1)
 
             bool mine = has;
-            if (P.symmetric && ch.pt > jp) mine = false;     // below the diagonal
-            if (P.diag_only && ch.pt != jp) mine = false;
+            if (P.symmetric && ch.pt > pt_hi) mine = false;  // every point of the group is below the diagonal
+            if (P.diag_only && (ch.pt < pt_lo || ch.pt > pt_hi)) mine = false;
             if (mine) {
                 for (int tile = 0; tile < ch.ntiles; ++tile) {
                     const double *At = sA[buf] + tile * GPR_PLANE;
@@ -247,67 +262,73 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                 }
                 if (ch.last) {
                     const int i_orig = P.a_perm[ch.pt];
-                    const double fac = fac_j * (P.norm1 ? P.a_inv[ch.pt] : 1.0);
-                    // halving reduction, in place on the bin registers: the first NH (power of two) values are reduced
-                    // in log2(NH) exchange steps that each keep half of them, then plain xor steps; the value(s) beyond NH
-                    // take the plain 6-step butterfly.  Afterwards lane l holds in bin[0] the total of value `idx`
-                    // (bits of l above log2(64/NH)), and every lane holds the totals of the values >= NH.
-                    constexpr int NH = (NOUT >= 8) ? 8 : (NOUT >= 2 ? 2 : 1);
-                    int idx = 0;
+                    const double fac_i = P.norm1 ? P.a_inv[ch.pt] : 1.0;
+                    // one reduction and one set of adds per resident point present in the group
+                    for (int sp = pt_lo; sp <= pt_hi; ++sp) {
+                        if (P.symmetric && ch.pt > sp) continue;          // this point's pair lies below the diagonal
+                        if (P.diag_only && ch.pt != sp) continue;
+                        const bool inseg = (my_pt == sp);
+                        const int j_orig = P.b_perm[sp];
+                        const double fac = fac_i * (P.norm2 ? P.b_inv[sp] : 1.0);
+                        // halving reduction on a masked copy of the bins (lanes of other points contribute zeros): the first
+                        // NH (power of two) values are reduced in log2(NH) exchange steps that each keep half of them, then
+                        // plain xor steps; the value(s) beyond NH take the plain 6-step butterfly.  Afterwards lane l holds
+                        // the total of value `idx` (bits of l above log2(64/NH)), and every lane the totals of the values
+                        // >= NH.  Value and derivative bins go through it one after the other (register pressure).
+                        constexpr int NH = (NOUT >= 8) ? 8 : (NOUT >= 2 ? 2 : 1);
+                        constexpr int SHARE = 64 / NH;
+                        int idx = (NH == 8) ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)
+                                            : (NH == 2 ? (lane >> 5) & 1 : 0);
+                        // writer lanes: (l % SHARE == 0) owns value idx < NH; lane 1 owns the extra value NH (if any)
+                        const bool w_main = (lane & (SHARE - 1)) == 0;
+                        const bool w_extra = (NOUT > NH) && lane == 1;
+                        if (w_extra) idx = NH;
 #define GPR_HALVE(ARR, OFF, HALF)                                                                 \
-                    {   const bool up_ = (lane & (OFF)) != 0;                                      \
-                        _Pragma("unroll") for (int k_ = 0; k_ < (HALF); k_++) {                    \
-                            const double send_ = up_ ? ARR[k_] : ARR[k_ + (HALF)];                 \
-                            const double keep_ = up_ ? ARR[k_ + (HALF)] : ARR[k_];                 \
-                            ARR[k_] = keep_ + __shfl_xor(send_, (OFF), 64); } }
+                        {   const bool up_ = (lane & (OFF)) != 0;                                  \
+                            _Pragma("unroll") for (int k_ = 0; k_ < (HALF); k_++) {                \
+                                const double send_ = up_ ? ARR[k_] : ARR[k_ + (HALF)];             \
+                                const double keep_ = up_ ? ARR[k_ + (HALF)] : ARR[k_];             \
+                                ARR[k_] = keep_ + __shfl_xor(send_, (OFF), 64); } }
 #define GPR_PLAIN(X, FROM)                                                                        \
-                    { _Pragma("unroll") for (int o_ = (FROM); o_ > 0; o_ >>= 1) X += __shfl_xor(X, o_, 64); }
-                    if (NH == 8) {
-                        idx = ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1);
-                        GPR_HALVE(bin, 32, 4) GPR_HALVE(bin, 16, 2) GPR_HALVE(bin, 8, 1) GPR_PLAIN(bin[0], 4)
-                        if (GRAD) { GPR_HALVE(bin2, 32, 4) GPR_HALVE(bin2, 16, 2) GPR_HALVE(bin2, 8, 1) GPR_PLAIN(bin2[0], 4) }
-                    } else if (NH == 2) {
-                        idx = (lane >> 5) & 1;
-                        GPR_HALVE(bin, 32, 1) GPR_PLAIN(bin[0], 16)
-                        if (GRAD) { GPR_HALVE(bin2, 32, 1) GPR_PLAIN(bin2[0], 16) }
-                    } else {
-                        GPR_PLAIN(bin[0], 32)
-                        if (GRAD) { GPR_PLAIN(bin2[0], 32) }
-                    }
-#pragma unroll
-                    for (int k = NH; k < NOUT; k++) { GPR_PLAIN(bin[k], 32) if (GRAD) { GPR_PLAIN(bin2[k], 32) } }
+                        { _Pragma("unroll") for (int o_ = (FROM); o_ > 0; o_ >>= 1) X += __shfl_xor(X, o_, 64); }
+#define GPR_SEG_REDUCE(SRC, VAL)                                                                  \
+                        {   double tb_[NOUT];                                                      \
+                            _Pragma("unroll") for (int k_ = 0; k_ < NOUT; k_++) tb_[k_] = inseg ? SRC[k_] : 0.0;  \
+                            if (NH == 8) { GPR_HALVE(tb_, 32, 4) GPR_HALVE(tb_, 16, 2) GPR_HALVE(tb_, 8, 1) GPR_PLAIN(tb_[0], 4) } \
+                            else if (NH == 2) { GPR_HALVE(tb_, 32, 1) GPR_PLAIN(tb_[0], 16) }      \
+                            else { GPR_PLAIN(tb_[0], 32) }                                         \
+                            _Pragma("unroll") for (int k_ = NH; k_ < NOUT; k_++) GPR_PLAIN(tb_[k_], 32)           \
+                            VAL = w_extra ? tb_[NOUT - 1] : tb_[0]; }
+                        double v, v2 = 0.0;
+                        GPR_SEG_REDUCE(bin, v)
+                        if (GRAD) GPR_SEG_REDUCE(bin2, v2)
+#undef GPR_SEG_REDUCE
 #undef GPR_HALVE
 #undef GPR_PLAIN
-                    constexpr int SHARE = 64 / NH;
-                    // writer lanes: (l % SHARE == 0) owns value idx < NH; lane 1 owns the extra value NH (if any)
-                    const bool w_main = (lane & (SHARE - 1)) == 0;
-                    const bool w_extra = (NOUT > NH) && lane == 1;
-                    if (w_extra) idx = NH;
-                    double v[1] = {w_extra ? bin[NOUT - 1] : bin[0]};
-                    double v2[1] = {GRAD ? (w_extra ? bin2[NOUT - 1] : bin2[0]) : 0.0};
-#pragma unroll
-                    for (int k = 0; k < NOUT; k++) { bin[k] = 0.0; if (GRAD) bin2[k] = 0.0; }
-                    // one lane per value adds it to the output.  The hardware FP64 atomic add returns nothing, so the
-                    // wavefront does not wait for memory; exactly one wavefront ever adds to a given element and its
-                    // adds are issued in program order, so the result does not depend on scheduling.
-                    if ((w_main || w_extra) && idx < NOUT) {
-                        const int a = (MODE == GPR_MODE_FF) ? idx / 3 : 0;
-                        const int b = (MODE == GPR_MODE_FF) ? idx % 3 : idx;
-                        const double val = v[0] * fac * P.scale;
-                        if (P.diag_only) {
-                            if (a == b) unsafeAtomicAdd(P.out + (long long)j_orig * P.s_j + b * P.s_b, val);
-                        } else {
-                            unsafeAtomicAdd(P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b, val);
-                            if (P.symmetric && ch.pt != jp)
-                                unsafeAtomicAdd(P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b, val);
-                            if (GRAD) {
-                                const double vald = v2[0] * fac * P.dl_scale;
-                                unsafeAtomicAdd(P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b, vald);
-                                if (P.symmetric && ch.pt != jp)
-                                    unsafeAtomicAdd(P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b, vald);
+                        // one lane per value adds it to the output.  The hardware FP64 atomic add returns nothing, so
+                        // the wavefront does not wait for memory; exactly one wavefront ever adds to a given element
+                        // and its adds are issued in program order, so the result does not depend on scheduling.
+                        if ((w_main || w_extra) && idx < NOUT) {
+                            const int a = (MODE == GPR_MODE_FF) ? idx / 3 : 0;
+                            const int b = (MODE == GPR_MODE_FF) ? idx % 3 : idx;
+                            const double val = v * fac * P.scale;
+                            if (P.diag_only) {
+                                if (a == b) unsafeAtomicAdd(P.out + (long long)j_orig * P.s_j + b * P.s_b, val);
+                            } else {
+                                unsafeAtomicAdd(P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b, val);
+                                if (P.symmetric && ch.pt != sp)
+                                    unsafeAtomicAdd(P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b, val);
+                                if (GRAD) {
+                                    const double vald = v2 * fac * P.dl_scale;
+                                    unsafeAtomicAdd(P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b, vald);
+                                    if (P.symmetric && ch.pt != sp)
+                                        unsafeAtomicAdd(P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b, vald);
+                                }
                             }
                         }
                     }
+#pragma unroll
+                    for (int k = 0; k < NOUT; k++) { bin[k] = 0.0; if (GRAD) bin2[k] = 0.0; }
                 }
             }
             if (c + 1 < c1) GPR_STAGE_STORE(c + 1, buf ^ 1)
@@ -357,9 +378,9 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     if (s1->npts == 0 || s2->npts == 0 || s1->nchunks == 0 || s2->maxgroups == 0) return GPR_OK;
 
     // workgroup width: 8 wavefronts when that still leaves >= 2 blocks per CU, else 4
-    int nw = (s2->npts >= 8 * 512) ? 8 : 4;
+    int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
     if (c.diag_only) nw = 4;
-    const int njb = (s2->npts + nw - 1) / nw;
+    const int njb = (s2->nwu + nw - 1) / nw;
 
     // stream ranges (consecutive packed points, ~128 tiles each) were laid out at pack time
     const int nir = c.diag_only ? 1 : s1->nranges;
@@ -367,7 +388,8 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     kb_args a;
     a.a_ops = s1->ops; a.a_ele = s1->ele; a.a_norm = s1->norms; a.a_chunks = s1->chunks;
     a.a_perm = s1->perm; a.a_inv = s1->inv_cnt; a.a_pt_chunk0 = s1->pt_chunk0;
-    a.b_ops = s2->ops; a.b_ele = s2->ele; a.b_norm = s2->norms; a.b_pts = s2->rpts;
+    a.b_ops = s2->ops; a.b_ele = s2->ele; a.b_norm = s2->norms; a.b_wu = s2->rpts;
+    a.b_wu_pt0 = s2->wu_pt0; a.b_rowpt = s2->rowpt; a.b_nwu = s2->nwu;
     a.b_perm = s2->perm; a.b_inv = s2->inv_cnt;
     a.b_npts = s2->npts; a.a_npts = s1->npts;
     a.ir_chunk0 = s1->ir_chunk0; a.ir_pt0 = s1->ir_pt0;

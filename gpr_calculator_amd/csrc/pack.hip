@@ -202,33 +202,55 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     std::vector<double> &inv_cnt = s->hk_inv_cnt;
     inv_cnt.assign(npts, 0.0);
     std::vector<gpr_chunk> &chunks = s->hk_chunks;
-    std::vector<gpr_rpoint> &rpts = s->hk_rpts;
-    rpts.assign(npts, gpr_rpoint{0, 0});
+    std::vector<gpr_rpoint> &rpts = s->hk_rpts;     // resident: one entry per wave unit
     s->h_pt_chunk0.assign(npts + 1, 0);
     s->h_pt_tiles.assign(npts, 0);
-    s->h_groups.assign(npts, 0);
     int unit = 0;
     s->maxgroups = 0;
-    for (int p = 0; p < npts; p++) {
-        int o = order[p], cnt = counts_host[o];
-        s->h_cnt[p] = cnt;
-        inv_cnt[p] = cnt > 0 ? 1.0 / cnt : 0.0;
-        int units = (cnt + s->tile_rows - 1) / s->tile_rows;
-        for (int r = 0; r < units * s->tile_rows; r++)
-            src_row.push_back(r < cnt ? (int)(row0[o] + r) : -1);
-        s->h_pt_tiles[p] = units;
-        s->h_pt_chunk0[p] = (int)chunks.size();
-        if (role == GPR_ROLE_STREAM) {
+    std::vector<int> &rowpt = s->hk_rowpt, &wu_pt0 = s->hk_wu_pt0;
+    if (role == GPR_ROLE_STREAM) {
+        for (int p = 0; p < npts; p++) {
+            int o = order[p], cnt = counts_host[o];
+            s->h_cnt[p] = cnt;
+            inv_cnt[p] = cnt > 0 ? 1.0 / cnt : 0.0;
+            int units = (cnt + s->tile_rows - 1) / s->tile_rows;
+            for (int r = 0; r < units * s->tile_rows; r++)
+                src_row.push_back(r < cnt ? (int)(row0[o] + r) : -1);
+            s->h_pt_tiles[p] = units;
+            s->h_pt_chunk0[p] = (int)chunks.size();
             for (int t = 0; t < units; t += GPR_CHUNK_TILES) {
                 int nt = std::min(GPR_CHUNK_TILES, units - t);
                 chunks.push_back(gpr_chunk{unit + t, nt, p, (t + nt >= units) ? 1 : 0});
             }
-        } else {
-            rpts[p] = gpr_rpoint{unit, units};
-            s->h_groups[p] = units;
-            s->maxgroups = std::max(s->maxgroups, units);
+            unit += units;
         }
-        unit += units;
+    } else {
+        // Resident side: the rows of consecutive packed points are laid out back to back and cut into 16-row MFMA
+        // groups per *wave unit* (the points one wavefront owns: as many consecutive points as fit in 8 groups), so
+        // the padding to a multiple of 16 rows is paid once per unit, not once per point (28-row force points: 4
+        // points = 7 groups exactly instead of 8).  rowpt gives the packed point of every padded row (-1: padding).
+        wu_pt0.assign(1, 0);
+        int p = 0;
+        while (p < npts) {
+            int rows = 0, q = p;
+            while (q < npts && (q == p || rows + counts_host[order[q]] <= GPR_WU_MAX_GROUPS * GPR_GROUP_ROWS)) {
+                const int o = order[q], cnt = counts_host[o];
+                s->h_cnt[q] = cnt;
+                inv_cnt[q] = cnt > 0 ? 1.0 / cnt : 0.0;
+                for (int r = 0; r < cnt; r++) { src_row.push_back((int)(row0[o] + r)); rowpt.push_back(q); }
+                s->h_pt_tiles[q] = 0;
+                rows += cnt;
+                q++;
+            }
+            const int groups = (rows + GPR_GROUP_ROWS - 1) / GPR_GROUP_ROWS;
+            for (int r = rows; r < groups * GPR_GROUP_ROWS; r++) { src_row.push_back(-1); rowpt.push_back(-1); }
+            rpts.push_back(gpr_rpoint{unit, groups});
+            wu_pt0.push_back(q);
+            s->maxgroups = std::max(s->maxgroups, groups);
+            unit += groups;
+            p = q;
+        }
+        s->nwu = (int)rpts.size();
     }
     s->h_pt_chunk0[npts] = (int)chunks.size();
     s->nunits = unit;
@@ -246,13 +268,16 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     if (role == GPR_ROLE_STREAM) {
         if ((rc = upload(&s->chunks, chunks, st, &bytes))) return fail(rc);
         if ((rc = upload(&s->pt_chunk0, s->h_pt_chunk0, st, &bytes))) return fail(rc);
-        // launch ranges: consecutive packed points, about 128 tiles each (one task = range x point block)
+        // launch ranges: consecutive packed points, about 128 tiles each (one task = range x resident block); small
+        // sets are cut finer (down to 8 tiles) so that a launch against them still has a few dozen ranges to spread
+        // over the CUs -- the resident side contributes only npts / (points per wave unit) / NW blocks
         std::vector<int> &irc = s->hk_irc, &irp = s->hk_irp;
         irc.assign(1, 0); irp.assign(1, 0);
+        const int range_tiles = std::max(8, std::min(128, unit / 64));
         int tiles = 0;
         for (int p = 0; p < npts; p++) {
             tiles += s->h_pt_tiles[p];
-            if (tiles >= 128 && p + 1 < npts) { irc.push_back(s->h_pt_chunk0[p + 1]); irp.push_back(p + 1); tiles = 0; }
+            if (tiles >= range_tiles && p + 1 < npts) { irc.push_back(s->h_pt_chunk0[p + 1]); irp.push_back(p + 1); tiles = 0; }
         }
         irc.push_back(s->nchunks); irp.push_back(npts);
         s->nranges = (int)irc.size() - 1;
@@ -260,6 +285,8 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
         if ((rc = upload(&s->ir_pt0, irp, st, &bytes))) return fail(rc);
     } else {
         if ((rc = upload(&s->rpts, rpts, st, &bytes))) return fail(rc);
+        if ((rc = upload(&s->wu_pt0, wu_pt0, st, &bytes))) return fail(rc);
+        if ((rc = upload(&s->rowpt, rowpt, st, &bytes))) return fail(rc);
     }
     size_t planes = (size_t)s->nunits * (role == GPR_ROLE_RESIDENT ? s->nc : 1);
     size_t ops_bytes = planes * GPR_PLANE * sizeof(double);
@@ -321,7 +348,7 @@ extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
     // stream-ordered frees: kernels already queued on `st` still see the arrays
     gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
     gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
-    gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st);
+    gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st); gpr_dev_free(s->wu_pt0, st); gpr_dev_free(s->rowpt, st);
     gpr_dev_free(s->ir_chunk0, st); gpr_dev_free(s->ir_pt0, st);
     s->ops = nullptr;
     hipEvent_t ev;
