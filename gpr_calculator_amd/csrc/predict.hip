@@ -1,0 +1,98 @@
+// predict.hip -- one native entry for the whole batched prediction of the Dot kernel at zeta = 2
+// (GP.predict_structures, gaussianprocess.py:834-918 for many structures at once): neighbour search, descriptor,
+// force-point regrouping, feature rows + prior variances, weight-space mean and variance, all queued on one stream
+// from one host call.  It only composes the library's own entry points (nbr.hip, so3.hip, features.hip, dense.hip);
+// the single synchronisation is the size download inside gpr_nbr_build_device.
+#include <algorithm>
+#include "gpr_internal.h"
+
+extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                                      const double *so3_table, int nstruct, const int *atom0, const double *positions,
+                                      const double *cells, const int *pbc, const int *numbers, int weight_on,
+                                      const unsigned char *free_mask, int ns, const int *species_host, double sigma,
+                                      double sigma0, const double *w_dev, const double *M_dev, int want_std,
+                                      double *out_dev, long long out_len) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(nstruct >= 0 && atom0 && so3_table && species_host && w_dev && out_dev && (!want_std || M_dev),
+                "gpr_predict_dot2_batch: null pointer");
+    if (nstruct == 0) return GPR_OK;
+    const int natoms = atom0[nstruct];
+    const int d = nmax * (nmax + 1) / 2 * (lmax + 1);
+    const int npair = d * (d + 1) / 2, F = ns * (npair + 1);
+    int nfree = natoms;
+    if (free_mask) { nfree = 0; for (int a = 0; a < natoms; a++) nfree += free_mask[a] ? 1 : 0; }
+    const long long m = (long long)nstruct + 3LL * nfree;
+    GPR_REQUIRE(out_len >= (want_std ? 2 : 1) * m + 1, "gpr_predict_dot2_batch: out holds %lld doubles, %lld needed",
+                out_len, (want_std ? 2 : 1) * m + 1);
+
+    gpr_nbr *nb = nullptr;
+    int rc = gpr_nbr_build_device(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on);
+    if (rc) return rc;
+    std::vector<void *> temps;
+    auto cleanup = [&](int code) {
+        for (void *p : temps) gpr_dev_free(p, st);
+        gpr_nbr_destroy(nb);
+        return code;
+    };
+    auto dalloc = [&](size_t bytes, void **p) { int r = gpr_dev_alloc(p, bytes, st); if (!r) temps.push_back(*p); return r; };
+
+    int P = 0, S = 0;
+    gpr_nbr_sizes(nb, &P, &S);
+    const double *d_vec, *d_w; const int *d_cp0, *d_cr0, *d_rp0, *d_self, *d_seq, *d_num, *d_atom0;
+    if ((rc = gpr_nbr_device_arrays(nb, &d_vec, &d_w, &d_cp0, &d_cr0, &d_rp0, &d_self, &d_seq, &d_num, &d_atom0))) return cleanup(rc);
+
+    // force points: every free atom; its rows are found on the device (gpr_nbr_force_rows)
+    void *p;
+    int frows = S;
+    const int *d_fatoms = nullptr, *d_frow0 = nullptr;
+    if (free_mask) {
+        std::vector<int> cr0(natoms + 1), meta(2 * (size_t)nfree + 1);
+        if ((rc = gpr_nbr_export(nb, nullptr, nullptr, nullptr, cr0.data(), nullptr, nullptr, nullptr, nullptr))) return cleanup(rc);
+        int k = 0, acc = 0;
+        for (int a = 0; a < natoms; a++)
+            if (free_mask[a]) { meta[k] = a; meta[nfree + k] = acc; acc += cr0[a + 1] - cr0[a]; k++; }
+        meta[2 * (size_t)nfree] = acc;
+        frows = acc;
+        if ((rc = dalloc(meta.size() * sizeof(int), &p))) return cleanup(rc);
+        hipError_t e = hipMemcpyAsync(p, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, st);   // pageable: staged before return
+        if (e != hipSuccess) { gpr_set_error("gpr_predict_dot2_batch: upload failed: %s", hipGetErrorString(e)); return cleanup(GPR_ERR_HIP); }
+        d_fatoms = (const int *)p; d_frow0 = d_fatoms + nfree;
+    }
+    int *d_rowidx = nullptr, *d_xidx = nullptr;
+    if ((rc = dalloc((size_t)std::max(frows, 1) * 2 * sizeof(int), &p))) return cleanup(rc);
+    d_rowidx = (int *)p; d_xidx = d_rowidx + std::max(frows, 1);
+    if ((rc = gpr_nbr_force_rows(nb, nfree, d_fatoms, d_frow0, frows, d_rowidx, d_xidx))) return cleanup(rc);
+
+    // descriptor
+    double *d_x = nullptr, *d_dxdr = nullptr;
+    if ((rc = dalloc((size_t)std::max(natoms, 1) * d * sizeof(double), &p))) return cleanup(rc);
+    d_x = (double *)p;
+    if ((rc = dalloc((size_t)std::max(S, 1) * d * 3 * sizeof(double), &p))) return cleanup(rc);
+    d_dxdr = (double *)p;
+    if ((rc = gpr_so3_power_spectrum(stream, nmax, lmax, rcut, alpha, nseg, ncheb, so3_table, natoms, P, S, d_vec, d_w,
+                                     d_cp0, d_cr0, d_rp0, d_self, d_x, d_dxdr))) return cleanup(rc);
+
+    // feature rows [energies ; forces] and prior variances
+    double *d_psi = nullptr, *d_diag = nullptr, *d_q = nullptr;
+    if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
+    d_psi = (double *)p;
+    if (want_std) {
+        if ((rc = dalloc((size_t)m * sizeof(double), &p))) return cleanup(rc);
+        d_diag = (double *)p;
+    }
+    if ((rc = gpr_dot2_features_direct(stream, d, 0, nstruct, d_atom0, nullptr, nullptr, d_x, nullptr, d_num, ns, species_host,
+                                       sigma, sigma0, d_psi, F, d_diag))) return cleanup(rc);
+    if (nfree > 0 &&
+        (rc = gpr_dot2_features_direct(stream, d, 3, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr, d_num,
+                                       ns, species_host, sigma, 0.0, d_psi + (size_t)nstruct * F, F,
+                                       d_diag ? d_diag + nstruct : nullptr))) return cleanup(rc);
+    // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0)
+    if (want_std) {
+        if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
+        d_q = (double *)p;
+        if ((rc = gpr_gemm(stream, 0, 0, (int)m, F, F, 1.0, d_psi, F, M_dev, F, 0.0, d_q, F))) return cleanup(rc);
+    }
+    if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev))) return cleanup(rc);
+    if ((rc = gpr_nbr_status_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
+    return cleanup(GPR_OK);
+}

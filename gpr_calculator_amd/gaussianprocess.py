@@ -768,6 +768,80 @@ class GP():
             return E, F, S, E_std, F_std
         return E, F, S
 
+    def _predict_batch_generic(self, mine_strucs, return_std, f_tol):
+        """(mean, std, frees) of a batch through the kernel-object route (any kernel): device descriptor and
+        regrouping, then K_trans / feature rows as the kernel decides"""
+        X, frees = self._batch_data_dev(mine_strucs)
+        mean, var, flat = self._predict_dev(X, self.get_train_x(), f_tol, return_std, want_flat=True)
+        nbr = getattr(X["force"], "_nbr", None) if "force" in X else None
+        if flat is not None:
+            # [mean | var | status] share one buffer (weight-space path): one download, no extra synchronisation
+            if nbr is not None:
+                nbr.status_into(flat[-1:])
+            host = flat.cpu().numpy()
+            if nbr is not None and host[-1] != 0.0:
+                raise RuntimeError(f"neighbour table is not symmetric: {int(host[-1])} force rows missing")
+            m_ = mean.numel()
+            mean, std = host[:m_], (np.sqrt(host[m_:2 * m_]) if return_std else None)
+        else:
+            if return_std:
+                mean, std = mean.cpu().numpy(), np.sqrt(var.cpu().numpy())
+            else:
+                mean, std = mean.cpu().numpy(), None
+            if nbr is not None:
+                nbr.check()
+        return mean, std, frees
+
+    def _predict_batch_native(self, mine_strucs, return_std):
+        """(mean, std, frees) through the one-call native pipeline gpr_predict_dot2_batch (csrc/predict.hip) when the
+        model is a Dot kernel at zeta = 2 with its weight-space tables and the descriptor is the device SO3; None
+        otherwise.  Same kernels as the generic route, queued from one host call."""
+        if not self.native_batch or not hasattr(self.descriptor, "_device_tables"):
+            return None
+        ws = self._weight_space()
+        if ws is None or not self.weight_space_mean or getattr(self.descriptor, "_stress", False):
+            return None
+        from . import _lib
+        import ctypes as C
+        from .neighbors import batch_arrays
+        des = self.descriptor
+        if not des.derivative:
+            return None
+        atom0, numbers, pos, cells, pbc = batch_arrays(mine_strucs)
+        natoms = int(atom0[-1])
+        mask, frees = None, []
+        for k, s in enumerate(mine_strucs):
+            fix = self._get_fixed_atoms(s) if has_fixed_atoms(s) else ()
+            if len(fix):
+                if mask is None:
+                    mask = np.ones(natoms, dtype=np.uint8)
+                mask[atom0[k] + np.asarray(fix, dtype=np.int64)] = 0
+                fixset = set(int(i) for i in fix)
+                frees.append([i for i in range(int(atom0[k + 1] - atom0[k])) if i not in fixset])
+            else:
+                frees.append(None)
+        nfree = natoms if mask is None else int(mask.sum())
+        m = len(mine_strucs) + 3 * nfree
+        table, nseg, ncheb = des._device_tables()[:3]
+        species, M, w = ws
+        sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
+        a0 = atom0.astype(np.int32)
+        num = numbers.astype(np.int32)
+        out = torch.empty((2 if return_std else 1) * m + 1, dtype=dev.F64, device=dev.device())
+        ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+        dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+        dev.check(_lib.lib().gpr_predict_dot2_batch(
+            dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
+            len(mine_strucs), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num), int(bool(des.weight_on)),
+            None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)), len(sp), ip(sp),
+            float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), int(bool(return_std)),
+            dev.ptr(out), int(out.numel())), "gpr_predict_dot2_batch")
+        host = out.cpu().numpy()
+        if host[-1] != 0.0:
+            raise RuntimeError(f"neighbour table is not symmetric: {int(host[-1])} force rows missing")
+        return host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
+
+    native_batch = True
     device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
@@ -779,25 +853,11 @@ class GP():
         mine = list(range(rank, nb, size)) if size > 1 else list(range(nb))
         results = {}
         if mine:
-            X, frees = self._batch_data_dev([strucs[k] for k in mine])
-            mean, var, flat = self._predict_dev(X, self.get_train_x(), f_tol, return_std, want_flat=True)
-            nbr = getattr(X["force"], "_nbr", None) if "force" in X else None
-            if flat is not None:
-                # [mean | var | status] share one buffer (weight-space path): one download, no extra synchronisation
-                if nbr is not None:
-                    nbr.status_into(flat[-1:])
-                host = flat.cpu().numpy()
-                if nbr is not None and host[-1] != 0.0:
-                    raise RuntimeError(f"neighbour table is not symmetric: {int(host[-1])} force rows missing")
-                m_ = mean.numel()
-                mean, std = host[:m_], (np.sqrt(host[m_:2 * m_]) if return_std else None)
+            fast = self._predict_batch_native([strucs[k] for k in mine], return_std)
+            if fast is not None:
+                mean, std, frees = fast
             else:
-                if return_std:
-                    mean, std = mean.cpu().numpy(), np.sqrt(var.cpu().numpy())
-                else:
-                    mean, std = mean.cpu().numpy(), None
-                if nbr is not None:
-                    nbr.check()
+                mean, std, frees = self._predict_batch_generic([strucs[k] for k in mine], return_std, f_tol)
             nS = len(mine)
             ns_atoms = [len(strucs[k]) for k in mine]
             uniform = all(f is None for f in frees) and len(set(ns_atoms)) == 1 and self.base_potential is None

@@ -148,6 +148,21 @@ int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int
                              const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
                              double sigma, double sigma0, double *psi, long long ld, double *diag);
 
+/* Batched prediction of the Dot kernel at zeta = 2 in one call (what GP.predict_structures does for that kernel;
+ * reference: one GP.predict_structure per structure, gaussianprocess.py:834-918): host arrays of the structures in
+ * (layout of gpr_nbr_build), device-resident model in (so3_table from gpr_so3_tables; w[F] and M[F, F] of the
+ * weight-space fit, F = ns (d(d+1)/2 + 1)), out_dev[(want_std ? 2 : 1) m + 1] = [mean | var | status] with
+ * m = nstruct + 3 nfree rows ordered energies (per atom) then (fx, fy, fz) of every free atom; free_mask[natoms]
+ * (host, may be NULL = every atom free) marks the atoms that get force rows (FixAtoms, gaussianprocess.py:823-832);
+ * status = number of force rows the neighbour symmetry check could not find (0).  Queues neighbour search,
+ * descriptor, regrouping, features, GEMM and the tail kernel on `stream`; the caller downloads out_dev. */
+int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
+                           const double *so3_table, int nstruct, const int *atom0, const double *positions,
+                           const double *cells, const int *pbc, const int *numbers, int weight_on,
+                           const unsigned char *free_mask, int ns, const int *species_host, double sigma,
+                           double sigma0, const double *w_dev, const double *M_dev, int want_std,
+                           double *out_dev, long long out_len);
+
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
  * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 10 entries

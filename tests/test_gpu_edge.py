@@ -101,3 +101,21 @@ def test_more_than_four_species_falls_back_to_pair_kernels():
     e1, f1, _, es1, fs1 = gp.predict_structure(new, stress=False, return_std=True)
     assert abs(Es[0] - e1) < 1e-8 * max(1.0, abs(e1)) and np.abs(Fs[0] - f1).max() < 1e-8
     assert abs(Es_std[0] - es1) < 1e-7 and np.abs(Fs_std[0] - fs1).max() < 1e-7
+
+
+def test_native_batch_entry_matches_kernel_object_route():
+    """gpr_predict_dot2_batch (one native call) against the same prediction assembled call by call through the kernel
+    object (device descriptor, SetPairs, gpr_dot2_features_direct, gpr_gemm, gpr_ws_finish): identical kernels, so
+    identical numbers; with and without fixed atoms, with and without the variance"""
+    gp = _model("Dot")
+    batch = _ragged_batch()
+    for return_std in (True, False):
+        gp.native_batch = True
+        a = gp.predict_structures(batch, return_std=return_std)
+        gp.native_batch = False
+        b = gp.predict_structures(batch, return_std=return_std)
+        for k in range(len(batch)):
+            assert a[0][k] == b[0][k] and np.array_equal(a[1][k], b[1][k])
+            if return_std:
+                assert a[2][k] == b[2][k] and np.array_equal(a[3][k], b[3][k])
+    gp.native_batch = True
