@@ -79,9 +79,13 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jb = blockIdx.x % P.njb, ir = blockIdx.x / P.njb;
-    const int ju = jb * NW + wave;                     // resident wave unit of this wavefront (consecutive packed points)
+    // resident wave unit of this wavefront (consecutive packed points).  Diagonal launches are tiny, so there every
+    // block takes ONE unit and its wavefronts share the unit's points (wave w flushes points w, w + NW, ...: the MFMA
+    // passes are repeated per wave, but four times as many blocks exist and each bin still has a single writer)
+    const int ju = P.diag_only ? jb : jb * NW + wave;
     const bool active = ju < P.b_nwu;
-    const int blk_pt0 = P.b_wu_pt0[jb * NW], blk_pt1 = P.b_wu_pt0[min((jb + 1) * NW, P.b_nwu)];   // points of this block
+    const int u_first = P.diag_only ? jb : jb * NW, u_end = P.diag_only ? jb + 1 : min((jb + 1) * NW, P.b_nwu);
+    const int blk_pt0 = P.b_wu_pt0[u_first], blk_pt1 = P.b_wu_pt0[u_end];                           // points of this block
     const int jlast = blk_pt1 - 1;
     if ((jb + ir) % P.shard_mod != P.shard_rem) return;   // multi-GPU: this task belongs to another rank
 
@@ -266,7 +270,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                     // one reduction and one set of adds per resident point present in the group
                     for (int sp = pt_lo; sp <= pt_hi; ++sp) {
                         if (P.symmetric && ch.pt > sp) continue;          // this point's pair lies below the diagonal
-                        if (P.diag_only && ch.pt != sp) continue;
+                        if (P.diag_only && (ch.pt != sp || ((sp - blk_pt0) & (NW - 1)) != wave)) continue;
                         const bool inseg = (my_pt == sp);
                         const int j_orig = P.b_perm[sp];
                         const double fac = fac_i * (P.norm2 ? P.b_inv[sp] : 1.0);
@@ -380,7 +384,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     // workgroup width: 8 wavefronts when that still leaves >= 2 blocks per CU, else 4
     int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
     if (c.diag_only) nw = 4;
-    const int njb = (s2->nwu + nw - 1) / nw;
+    const int njb = c.diag_only ? s2->nwu : (s2->nwu + nw - 1) / nw;
 
     // stream ranges (consecutive packed points, ~128 tiles each) were laid out at pack time
     const int nir = c.diag_only ? 1 : s1->nranges;
