@@ -24,6 +24,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
     const int bm0 = blockIdx.y * BM, bn0 = blockIdx.x * BN;
     if ((lower_only & 1) && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
     if (lower_only & 2) k = min(k, bm0 + BM);                // op(A) lower triangular: zero beyond the row block
+    if (lower_only & 4) k = min(k, bn0 + BN);                // op(B) = B^T with B lower triangular: zero beyond the column block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     d4 acc[2][2];
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
     const int bm0 = blockIdx.y * GM, bn0 = blockIdx.x * GN;
     if ((lower_only & 1) && bn0 > bm0 + GM - 1) return;
     if (lower_only & 2) k = min(k, bm0 + GM);
+    if (lower_only & 4) k = min(k, bn0 + GN);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     d4 acc[4][4];
@@ -459,20 +461,25 @@ __global__ void __launch_bounds__(256) rowdot_kernel(int m, int n, const double 
 
 // weight-space prediction tail: mean[i] = P[i,:] . w and var[i] = max(diag[i] - Q[i,:] . P[i,:], 0) in one pass over
 // the rows (Q = P M); one wavefront per row, fixed summation order.  out = [mean (m) | var (m)]
+// vsq > 0 selects the factored form: Q = P C^-T (G = C C^T) and var = diag - vsq (|p|^2 - |q|^2), vsq = sigma^2
 __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const double *P, long long ldp, const double *Q,
-                                                         long long ldq, const double *w, const double *diag, double *out) {
+                                                         long long ldq, const double *w, const double *diag, double *out,
+                                                         double vsq) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= m) return;
     double a1 = 0.0, a2 = 0.0;
     for (int j = lane; j < n; j += 64) {
         const double pv = P[(long long)row * ldp + j];
         a1 += pv * w[j];
-        if (Q) a2 += pv * Q[(long long)row * ldq + j];
+        if (Q) {
+            const double qv = Q[(long long)row * ldq + j];
+            a2 += (vsq > 0.0) ? (pv * pv - qv * qv) : pv * qv;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) { a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64); }
     if (lane == 0) {
         out[row] = a1;
-        if (Q) out[m + row] = fmax(diag[row] - a2, 0.0);
+        if (Q) out[m + row] = fmax(diag[row] - ((vsq > 0.0) ? vsq * a2 : a2), 0.0);
     }
 }
 
@@ -704,12 +711,25 @@ extern "C" int gpr_rowdot(void *stream, int m, int n, const double *a, long long
 }
 
 extern "C" int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, const double *Q, long long ldq,
-                             const double *w, const double *diag, double *out) {
+                             const double *w, const double *diag, double *out, double vsq) {
     if (m <= 0) return GPR_OK;
     GPR_REQUIRE(out && P && w && ldp >= n && (!Q || (diag && ldq >= n)), "gpr_ws_finish: bad arguments");
-    hipLaunchKernelGGL(ws_finish_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, P, ldp, Q, ldq, w, diag, out);
+    hipLaunchKernelGGL(ws_finish_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, P, ldp, Q, ldq, w, diag, out, vsq);
     LAUNCH_CHECK("ws_finish");
     return GPR_OK;
+}
+
+// C[m, n] = alpha A[m, n] B^T with B n x n lower triangular: the k range of every column block stops at its diagonal block
+extern "C" int gpr_gemm_nt_lower(void *stream, int m, int n, double alpha, const double *a, long long lda, const double *bl,
+                                 long long ldb, double *c, long long ldc) {
+    GPR_REQUIRE(m >= 0 && n >= 0, "gpr_gemm_nt_lower: negative dimension");
+    if (m == 0 || n == 0) return GPR_OK;
+    GPR_REQUIRE(a && bl && c && lda >= n && ldb >= n && ldc >= n, "gpr_gemm_nt_lower: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
+    const int rc = launch_gemm(st, 0, 1, m, n, n, alpha, a, lda, bl, ldb, 0.0, c, ldc, 4);
+    gpr_prof_end(st, pid);
+    return rc;
 }
 
 // out[j] = sum_i a[i*lda+j] * x[i]  (A^T x for a row-major n x ncols matrix): the predictive mean K_trans alpha

@@ -10,10 +10,10 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
                                       const double *so3_table, int nstruct, const int *atom0, const double *positions,
                                       const double *cells, const int *pbc, const int *numbers, int weight_on,
                                       const unsigned char *free_mask, int ns, const int *species_host, double sigma,
-                                      double sigma0, const double *w_dev, const double *M_dev, int want_std,
-                                      double *out_dev, long long out_len) {
+                                      double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev,
+                                      int want_std, double *out_dev, long long out_len) {
     hipStream_t st = (hipStream_t)stream;
-    GPR_REQUIRE(nstruct >= 0 && atom0 && so3_table && species_host && w_dev && out_dev && (!want_std || M_dev),
+    GPR_REQUIRE(nstruct >= 0 && atom0 && so3_table && species_host && w_dev && out_dev && (!want_std || M_dev || Cinv_dev),
                 "gpr_predict_dot2_batch: null pointer");
     if (nstruct == 0) return GPR_OK;
     const int natoms = atom0[nstruct];
@@ -90,9 +90,13 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     if (want_std) {
         if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
         d_q = (double *)p;
-        if ((rc = gpr_gemm(stream, 0, 0, (int)m, F, F, 1.0, d_psi, F, M_dev, F, 0.0, d_q, F))) return cleanup(rc);
+        // factored form when C^-1 is at hand: Q = Psi C^-T touches only the lower triangle of C^-1
+        if (Cinv_dev) rc = gpr_gemm_nt_lower(stream, (int)m, F, 1.0, d_psi, F, Cinv_dev, F, d_q, F);
+        else rc = gpr_gemm(stream, 0, 0, (int)m, F, F, 1.0, d_psi, F, M_dev, F, 0.0, d_q, F);
+        if (rc) return cleanup(rc);
     }
-    if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev))) return cleanup(rc);
+    if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev,
+                            (want_std && Cinv_dev) ? sigma * sigma : 0.0))) return cleanup(rc);
     if ((rc = gpr_nbr_status_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
     return cleanup(GPR_OK);
 }

@@ -377,7 +377,7 @@ def ws_finish(P, w, Q=None, diag=None, tail=0):
     flat = torch.empty(k * m + tail, dtype=F64, device=P.device)
     out = flat[:k * m].view(k, m)
     check(_lib.lib().gpr_ws_finish(stream_ptr(), m, n, ptr(P), int(P.stride(0)), ptr(Q),
-                                   int(Q.stride(0)) if Q is not None else 0, ptr(w), ptr(diag), ptr(out)), "gpr_ws_finish")
+                                   int(Q.stride(0)) if Q is not None else 0, ptr(w), ptr(diag), ptr(out), 0.0), "gpr_ws_finish")
     return (out, flat) if tail else out
 
 

@@ -413,7 +413,7 @@ class GP():
         dev.trsm_lower_(G, Ci, dinv=dinv)                                         # C^-1, G = C C^T
         M = dev.gemm(Ci, Ci, transa=True, alpha=-sig * sig)                       # -sigma^2 G^-1
         M.diagonal().add_(sig * sig)
-        self._ws_cache = (species, M, b * sig)
+        self._ws_cache = (species, M, b * sig, Ci)                        # Ci = C^-1 feeds the factored variance form
         return True
 
     # ------------------------------------------------------------------ prediction
@@ -823,7 +823,8 @@ class GP():
         nfree = natoms if mask is None else int(mask.sum())
         m = len(mine_strucs) + 3 * nfree
         table, nseg, ncheb = des._device_tables()[:3]
-        species, M, w = ws
+        species, M, w = ws[:3]
+        Cinv = ws[3] if len(ws) > 3 else None
         sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
         a0 = atom0.astype(np.int32)
         num = numbers.astype(np.int32)
@@ -834,7 +835,7 @@ class GP():
             dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
             len(mine_strucs), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num), int(bool(des.weight_on)),
             None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)), len(sp), ip(sp),
-            float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), int(bool(return_std)),
+            float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std)),
             dev.ptr(out), int(out.numel())), "gpr_predict_dot2_batch")
         host = out.cpu().numpy()
         if host[-1] != 0.0:

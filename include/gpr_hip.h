@@ -151,7 +151,8 @@ int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int
 /* Batched prediction of the Dot kernel at zeta = 2 in one call (what GP.predict_structures does for that kernel;
  * reference: one GP.predict_structure per structure, gaussianprocess.py:834-918): host arrays of the structures in
  * (layout of gpr_nbr_build), device-resident model in (so3_table from gpr_so3_tables; w[F] and M[F, F] of the
- * weight-space fit, F = ns (d(d+1)/2 + 1)), out_dev[(want_std ? 2 : 1) m + 1] = [mean | var | status] with
+ * weight-space fit, F = ns (d(d+1)/2 + 1); Cinv[F, F] = C^-1 lower triangular with I + Psi'^T D^-1 Psi' = C C^T may be
+ * given instead of M (NULL otherwise): the variance product then skips the zero half), out_dev[(want_std ? 2 : 1) m + 1] = [mean | var | status] with
  * m = nstruct + 3 nfree rows ordered energies (per atom) then (fx, fy, fz) of every free atom; free_mask[natoms]
  * (host, may be NULL = every atom free) marks the atoms that get force rows (FixAtoms, gaussianprocess.py:823-832);
  * status = number of force rows the neighbour symmetry check could not find (0).  Queues neighbour search,
@@ -160,7 +161,7 @@ int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double
                            const double *so3_table, int nstruct, const int *atom0, const double *positions,
                            const double *cells, const int *pbc, const int *numbers, int weight_on,
                            const unsigned char *free_mask, int ns, const int *species_host, double sigma,
-                           double sigma0, const double *w_dev, const double *M_dev, int want_std,
+                           double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev, int want_std,
                            double *out_dev, long long out_len);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
@@ -297,7 +298,12 @@ int gpr_rowdot(void *stream, int m, int n, const double *a, long long lda, const
 /* Tail of the weight-space prediction (Dot kernel, zeta = 2): out[i] = P[i,:] . w (mean) and, when Q = P M is
  * given, out[m+i] = max(diag[i] - Q[i,:] . P[i,:], 0) (variance, gaussianprocess.py:903-907), one pass */
 int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, const double *Q, long long ldq,
-                  const double *w, const double *diag, double *out);
+                  const double *w, const double *diag, double *out, double vsq);
+/* (vsq > 0 selects the factored form of the same variance: Q = P C^-T with I + Psi'^T D^-1 Psi' = C C^T, and
+ * out[m+i] = max(diag[i] - vsq (|P[i,:]|^2 - |Q[i,:]|^2), 0), vsq = sigma^2; vsq = 0: the form above)
+ * C[m, n] = alpha A[m, n] B^T with B n x n lower triangular (zero blocks of B^T are skipped) */
+int gpr_gemm_nt_lower(void *stream, int m, int n, double alpha, const double *a, long long lda, const double *b_lower,
+                      long long ldb, double *c, long long ldc);
 /* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
  * gaussianprocess.py:196-198), deterministic reduction order */
 int gpr_frob_dot(void *stream, int m, int n, const double *a, long long lda, const double *b,
