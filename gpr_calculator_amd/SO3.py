@@ -1,11 +1,12 @@
 """SO3: SO(3) power-spectrum descriptor with the reference's class interface
 (gpr_calc/SO3.py:7-323), evaluated by csrc/so3.hip on the GPU.
 
-Host side (this file): neighbour search and index bookkeeping (which pair belongs to which centre and
-to which (i, j) row of `seq`), and the 3 x 80 table of radial quadrature weights, which depends only
-on (nmax, lmax, rcut, alpha) and is built once.  Device side: everything per neighbour pair and per
-centre -- Bessel functions, spherical harmonics and gradients, expansion coefficients, power
-spectrum and its derivatives."""
+Host side (this file): gathering the structures' arrays and the 3 x 80 table of radial quadrature weights, which
+depends only on (nmax, lmax, rcut, alpha) and is built once.  Device side: the periodic neighbour search and the
+(centre, neighbour) row bookkeeping (csrc/nbr.hip; a host builder with identical output serves the single-structure
+`calculate` API), the radial Chebyshev table built from that quadrature (gpr_so3_tables), and everything per
+neighbour pair and per centre -- spherical harmonics, expansion coefficients, power spectrum, its derivatives and,
+with stress=True, the stress rows."""
 import ctypes as C
 
 import numpy as np

@@ -11,8 +11,12 @@ What runs where
     predictions of a batch of structures are sharded by structure.
 
 Differences kept on purpose (documented in DESIGN.md): the predictive variance is evaluated as
-diag - |L^-1 k|^2 (triangular solve) instead of through an explicit K^-1; `_K_inv`, `L_` and
-`alpha_` remain available as (lazily downloaded) numpy arrays.
+diag - |L^-1 k|^2 (triangular solve) instead of through an explicit K^-1; with the Dot kernel at zeta = 2 the fit,
+the log-marginal likelihood and the prediction run in weight space (explicit 466-per-species feature map, F x F system
+instead of N x N); `_K_inv`, `L_` and `alpha_` keep the reference's dense definitions and are factored / downloaded
+lazily on first access.  Batched prediction (`predict_structures`, and `predict_structure` without stress) keeps
+neighbour search, descriptor and regrouping on the device; for the weight-space model it is one native call
+(csrc/predict.hip).
 """
 import json
 import logging
@@ -846,8 +850,9 @@ class GP():
     device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
-        """Batched predict_structure(stress=False): one descriptor pass, one K_trans build, one
-        triangular solve for the whole batch; over ranks the batch is split by structure.
+        """Batched predict_structure(stress=False): one neighbour search, one descriptor launch and one prediction
+        (feature rows x weight-space tables for the Dot kernel at zeta = 2, K_trans + triangular product otherwise) for
+        the whole batch; over ranks the batch is split by structure.
         Returns lists (E, F, E_std, F_std) ordered like `strucs` (identical on every rank)."""
         nb = len(strucs)
         size, rank = self.comm.size, self.comm.rank
