@@ -120,3 +120,35 @@ def test_native_batch_entry_matches_kernel_object_route():
             if return_std:
                 assert abs(a[2][k] - b[2][k]) < 1e-11 and np.abs(a[3][k] - b[3][k]).max() < 1e-11
     gp.native_batch = True
+
+
+def test_error_paths_fail_loudly():
+    """no silent fallbacks: a covariance that is not positive definite, a descriptor too long for this build, a
+    mismatched counts vector and an unfitted model all raise"""
+    import torch
+    from gpr_calculator_amd import device as dev, _lib
+    from gpr_calculator_amd.synthetic import fcc_cell
+    # Cholesky of an indefinite matrix reports the failing pivot
+    A = torch.eye(70, dtype=torch.float64, device="cuda")
+    A[40, 40] = -1.0
+    info = dev.potrf_lower_(A)
+    info = info[0] if isinstance(info, tuple) else info
+    assert int(info.item()) == 41
+    # GP.fit turns that into LinAlgError: two identical structures with zero noise give a singular K
+    gp = _model("RBF")
+    s = fcc_cell(seed=1, reps=1, species=(46, 78), sigma=0.08)
+    from gpr_calculator_amd.synthetic import lj_energy_forces
+    E, F = lj_energy_forces(s)
+    gp.noise_e, gp.noise_f = 0.0, 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        gp.fit(gp.points_from_structures([(s, E, F, True, [0, 1]), (s, E, F, True, [0, 1])]), show=False, opt=False)
+    # descriptor longer than the packed operand width
+    with pytest.raises(_lib.GprHipError):
+        dev.PackedSet(_lib.ROLE_STREAM, np.ones((4, 40)), None, np.full(4, 46), [4])
+    # counts that do not add up
+    with pytest.raises(ValueError):
+        dev.PackedSet(_lib.ROLE_STREAM, np.ones((4, 30)), None, np.full(4, 46), [3])
+    # SO3 configuration outside the descriptor kernel's limits
+    from gpr_calculator_amd.SO3 import SO3
+    with pytest.raises(_lib.GprHipError):
+        SO3(nmax=4, lmax=6, rcut=5.0).calculate(s)
