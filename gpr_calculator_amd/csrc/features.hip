@@ -285,6 +285,194 @@ __global__ void __launch_bounds__(256) dot2_diag_ee_direct_kernel(dfeat_args A) 
     }
 }
 
+
+// ---------------------------------------------------------------- force points on the matrix cores
+// The feature rows of a force point are a symmetric rank-2k update: with the rows r of the point,
+//     S_q = sum_r (a~_r A'_qr^T + A'_qr a~_r^T) = M_q + M_q^T,   M_q = A~^T A'_q   ([d x R] [R x d], q = x, y, z),
+// Psi_F[q] = -vech(S_q) -- an FP64 MFMA product with the rows as the K dimension (four rows per
+// v_mfma_f64_16x16x4_f64 step).  One wavefront per point, two passes (native operands for Psi, numpy-eps operands for
+// the prior variance sigma^2 |vech(S_eps)|^2 = sigma^2 sum_{k,m} (M_km + M_mk)^2), per species block (rows of other
+// species enter as zeros).  Row staging is the one of the VALU kernel above: 16 lanes per row, four rows per step.
+typedef double fm_d4 __attribute__((ext_vector_type(4)));
+constexpr int FM_LD = 33;                 // padded operand row stride (doubles)
+
+// sum over the 16 lanes of a DPP row (the 16 lanes that stage one descriptor row): four rotate-and-add steps on the
+// VALU (row_ror:8,4,2,1), every lane ends with the total; no LDS traffic, unlike a shuffle-based butterfly
+template <int CTRL>
+__device__ __forceinline__ double fm_row_ror(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double fm_row_sum16(double v) {
+    v += fm_row_ror<0x128>(v);
+    v += fm_row_ror<0x124>(v);
+    v += fm_row_ror<0x122>(v);
+    v += fm_row_ror<0x121>(v);
+    return v;
+}
+
+__device__ __forceinline__ void fm_lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_args A) {
+    __shared__ double smem[4][32 * FM_LD];                     // per wavefront: operands of one step / transpose buffer
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= A.npts) return;                                    // wavefront-uniform; no block barriers below
+    double *sm = smem[wave];
+    double *opA = sm, *opB = sm + 4 * FM_LD;                    // opA[row][k], opB[q][row][k]
+    const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
+    const int slot = lane >> 4, g = lane & 15;
+    double dacc[3] = {0.0, 0.0, 0.0};                           // sum over species and (k, m) of (M_km + M_mk)^2, eps pass
+    // this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once
+    int km[9];
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+        const int e = lane + 64 * t;
+        int k = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
+        while ((k + 1) * (k + 2) / 2 <= e) k++;
+        while (k * (k + 1) / 2 > e) k--;
+        km[t] = (e < A.npair) ? ((k << 8) | (e - k * (k + 1) / 2)) : -1;
+    }
+    for (int q = 0; q < 3; q++) {                               // the constant column of force rows is zero
+        double *o = A.out + (long long)(p * 3 + q) * A.ld;
+        if (lane < A.ns) o[A.ns * A.npair + lane] = 0.0;
+    }
+    for (int si = 0; si < A.ns; si++) {
+        const int zs = A.species[si];
+#pragma unroll 1
+        for (int pass = 0; pass < (A.diag ? 2 : 1); pass++) {  // 0: native operands -> Psi; 1: numpy-eps operands -> diag
+            fm_d4 acc[3][2][2];
+#pragma unroll
+            for (int q = 0; q < 3; q++)
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) acc[q][a][b] = fm_d4{0.0, 0.0, 0.0, 0.0};
+            // Row indices of up to 64 rows at a time sit in registers (lane j: row cb + j) and reach the staging lanes by
+            // shuffle; the x / dxdr values of the next four rows are requested before the current four are processed, so
+            // no dependent global load sits on the loop's critical path.
+            for (int cb = r0; cb < r1; cb += 64) {
+            int my_xs = -1, my_ds = -1;
+            {
+                const int rr = cb + lane;
+                if (rr < r1) {
+                    my_xs = A.x_index ? A.x_index[rr] : rr;
+                    my_ds = A.d_index ? A.d_index[rr] : rr;
+                    if (my_xs < 0 || my_ds < 0 || A.ele[my_xs] != zs) { my_xs = -1; my_ds = -1; }   // absent or other species
+                }
+            }
+            const int cend = min(r1, cb + 64);
+            double nx0 = 0.0, nx1 = 0.0, ndv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+            bool nok = false;
+#define FM_FETCH(RB)                                                                                       \
+            {   const int j_ = (RB) - cb + slot;                                                            \
+                const int xs_ = __shfl(my_xs, j_ & 63), ds_ = __shfl(my_ds, j_ & 63);                       \
+                nok = ((RB) + slot < cend) && xs_ >= 0;                                                     \
+                nx0 = 0.0; nx1 = 0.0;                                                                       \
+                _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) ndv[u_] = 0.0;                             \
+                if (nok) {                                                                                  \
+                    const double *xr_ = A.x + (size_t)xs_ * A.d;                                            \
+                    if (g < A.d) nx0 = xr_[g];                                                              \
+                    if (g + 16 < A.d) nx1 = xr_[g + 16];                                                    \
+                    const double *D_ = A.dxdr + (size_t)ds_ * A.d * 3;                                      \
+                    _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) { const int el_ = g + 16 * u_; if (el_ < 3 * A.d) ndv[u_] = D_[el_]; } } }
+            FM_FETCH(cb)
+            for (int rb = cb; rb < cend; rb += 4) {
+                // ---- stage four rows: 16 lanes per row (values fetched one step ahead)
+                const bool ok = nok;
+                const double x0 = nx0, x1 = nx1;
+                double raw[6];
+#pragma unroll
+                for (int u = 0; u < 6; u++) raw[u] = ndv[u];
+                if (rb + 4 < cend) FM_FETCH(rb + 4)
+                const double n = sqrt(fm_row_sum16(x0 * x0 + x1 * x1));
+                // native: rows with |x| <= 1e-8 are skipped (dot_kernel.cpp); numpy-eps: norm + 1e-8, nothing skipped
+                const bool live = ok && (pass == 1 || n > 1e-8);
+                const double inv = (live && n > 0.0) ? 1.0 / n : 0.0;
+                const double sc = (pass == 1) ? n / (n + 1e-8) : 1.0, s2 = sc * sc;
+                const double a0 = x0 * inv, a1 = x1 * inv;
+                // a~ goes to LDS first: the lanes that hold dxdr element (k, c) fetch a~_k from there
+                opA[slot * FM_LD + g] = sc * a0;
+                opA[slot * FM_LD + g + 16] = sc * a1;
+                fm_lds_sync();
+                double dv[6], ak[6], pr[3] = {0.0, 0.0, 0.0};
+                const double isc = (sc > 0.0) ? 1.0 / sc : 0.0;               // opA holds sc a~
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                    dv[u] = raw[u] * inv;                                        // zero beyond 3 d and for rows that are not live
+                    ak[u] = (kk < 32) ? opA[slot * FM_LD + kk] * isc : 0.0;
+                    const double t = ak[u] * dv[u];
+                    pr[0] += (c == 0) ? t : 0.0; pr[1] += (c == 1) ? t : 0.0; pr[2] += (c == 2) ? t : 0.0;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) pr[c] = fm_row_sum16(pr[c]);
+                // A'_c = sc (D/n - s2 a~ proj_c)
+#pragma unroll
+                for (int u = 0; u < 6; u++) {
+                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                    if (kk < 32) {
+                        const double prc = (c == 0) ? pr[0] : (c == 1 ? pr[1] : pr[2]);
+                        opB[(c * 4 + slot) * FM_LD + kk] = sc * (dv[u] - s2 * ak[u] * prc);
+                    }
+                }
+                fm_lds_sync();
+                // ---- M_q += A~^T A'_q for these four rows: A operand [m = monomial index k][k = row], B [row][n]
+                const int krow = lane >> 4, col = lane & 15;
+                const double av0 = opA[krow * FM_LD + col], av1 = opA[krow * FM_LD + 16 + col];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const double b0 = opB[(q * 4 + krow) * FM_LD + col], b1 = opB[(q * 4 + krow) * FM_LD + 16 + col];
+                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc[q][0][0], 0, 0, 0);
+                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc[q][0][1], 0, 0, 0);
+                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b0, acc[q][1][0], 0, 0, 0);
+                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc[q][1][1], 0, 0, 0);
+                }
+                fm_lds_sync();
+            }
+#undef FM_FETCH
+            }
+            // ---- S_q = M_q + M_q^T through a transpose buffer, vech with sqrt(2) on the off-diagonal entries
+            for (int q = 0; q < 3; q++) {
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            sm[(16 * a + (lane >> 4) + 4 * r) * FM_LD + 16 * b + (lane & 15)] = acc[q][a][b][r];
+                fm_lds_sync();
+                double part = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; t++) {
+                    if (km[t] >= 0) {
+                        const int k = km[t] >> 8, m = km[t] & 255, e = lane + 64 * t;
+                        const double sv = sm[k * FM_LD + m] + sm[m * FM_LD + k];
+                        if (pass == 0) A.out[(long long)(p * 3 + q) * A.ld + si * A.npair + e] = -((k == m) ? sv : 1.4142135623730951 * sv);
+                        else part += (k == m) ? sv * sv : 2.0 * sv * sv;
+                    }
+                }
+                if (pass == 1) dacc[q] += part;
+                fm_lds_sync();
+            }
+        }
+    }
+    if (A.diag) {
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            double t = dacc[q];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
+            if (lane == 0) A.diag[3 * (size_t)p + q] = A.sigma2 * t;
+        }
+    }
+}
+
 }  // namespace
 
 // Psi rows of the points of a STREAM-packed set: energy set -> out[npts, F]; force set -> out[3*npts, F]
@@ -337,6 +525,13 @@ extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts
     for (int s = 0; s < FEAT_MAX_SPECIES; s++) A.species[s] = s < ns ? species_host[s] : 0;
     A.sigma0 = sigma0; A.sigma2 = sigma * sigma; A.out = psi; A.ld = ld; A.diag = diag;
     const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
+    if (width == 3) {       // force points: symmetric rank-2k update on the matrix cores, one wavefront per point
+        hipLaunchKernelGGL(dot2_force_features_mfma_kernel, dim3((npts + 3) / 4), dim3(256), 0, st, A);
+        gpr_prof_end(st, pid);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { gpr_set_error("dot2_force_features_mfma launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
     const bool wide = npair > 512;
 #define GPR_DF_LAUNCH(NSV)                                                                                         \
     do {                                                                                                           \
