@@ -205,9 +205,10 @@ def main():
                     "~4 kflop per neighbour pair (30 Clenshaw sums of 16 terms, Y_lm recurrences, c_tot, R/S "
                     "contraction and 90 outputs per pair); the reference's own formulation (80-node Bessel quadrature "
                     "per pair) would be ~21 kflop"),
-            "features": ("dot2_features_direct_kernel: degree-2 feature rows + prior variances (FP64 vector; no matrix "
-                         "shape)", float(len(ele_rows)) * 465 * 66,
-                         "66 flop per descriptor row and packed (k,m) index (native and numpy-eps feature of 3 components)"),
+            "features": ("dot2_force_features_mfma_kernel (+ energy-point kernels): degree-2 feature rows and prior variances",
+                         float(len(ele_rows)) * 2 * 3 * 2 * 32 * 32,
+                         "two passes (native, numpy-eps) x 3 components x 2 x 32 x 32 flop per descriptor row: the symmetric "
+                         "rank-2k update M_q = A~^T A'_q on the FP64 matrix cores"),
         }
         dom = max((k for k in per_step if k in work), key=lambda k: per_step[k][0])
         name, flops, unit_note = work[dom]
