@@ -11,7 +11,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgprhip.so")
+LIB_PATH = os.environ.get("GPR_HIP_LIB") or os.path.join(_HERE, "libgprhip.so")   # GPR_HIP_LIB: A/B builds when tuning
 _lib = None
 
 c_double_p = C.POINTER(C.c_double)
