@@ -51,7 +51,7 @@ _L1_SIGNATURES = {
     "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),
     "gpr_colsumsq": ([_vp, _i, _i, _vp, _ll, _vp], _i),
     "gpr_sum_log_diag": ([_vp, _i, _vp, _ll, _vp], _i),
-    "gpr_dot2_features_direct": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, c_int_p, _d, _d, _vp, C.c_longlong, _vp], _i),
+    "gpr_dot2_features_direct": ([_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, c_int_p, _i, c_int_p, _d, _d, _vp, C.c_longlong, _vp], _i),
     "gpr_set_create_gather": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _vp, _vp, _i], _i),
     "gpr_nbr_build_device": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
     "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 9, _i),

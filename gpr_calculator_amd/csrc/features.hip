@@ -16,6 +16,7 @@
 namespace {
 
 constexpr int FEAT_MAX_SPECIES = 4;
+constexpr int FEAT_MAX_EXTRA = 8;
 
 struct feat_args {
     const double *ops; const int *ele; const gpr_chunk *chunks; const int *pt_chunk0; const int *perm;
@@ -102,6 +103,8 @@ struct dfeat_args {
     const int *pt_row0, *x_index, *d_index;
     int npts, nc, d, npair, ns;
     int species[FEAT_MAX_SPECIES];
+    int nsx, species_x[FEAT_MAX_EXTRA];   // species present in the predicted points but not in the model: they have no
+                                          // feature block, but their same-species row pairs belong to the prior variance
     double sigma0, sigma2;
     double *out; long long ld;
     double *diag;
@@ -342,10 +345,10 @@ __global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_arg
         double *o = A.out + (long long)(p * 3 + q) * A.ld;
         if (lane < A.ns) o[A.ns * A.npair + lane] = 0.0;
     }
-    for (int si = 0; si < A.ns; si++) {
-        const int zs = A.species[si];
+    for (int si = 0; si < A.ns + (A.diag ? A.nsx : 0); si++) {
+        const int zs = si < A.ns ? A.species[si] : A.species_x[si - A.ns];
 #pragma unroll 1
-        for (int pass = 0; pass < (A.diag ? 2 : 1); pass++) {  // 0: native operands -> Psi; 1: numpy-eps operands -> diag
+        for (int pass = (si < A.ns ? 0 : 1); pass < (A.diag ? 2 : 1); pass++) {  // 0: native operands -> Psi; 1: numpy-eps -> diag
             fm_d4 acc[3][2][2];
 #pragma unroll
             for (int q = 0; q < 3; q++)
@@ -510,11 +513,14 @@ extern "C" int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const
 extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int *pt_row0_dev,
                                         const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev,
                                         const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
+                                        int nsx, const int *species_extra_host,
                                         double sigma, double sigma0, double *psi, long long ld, double *diag) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(width == 0 || width == 3, "gpr_dot2_features_direct: width must be 0 or 3 (got %d)", width);
     GPR_REQUIRE(d >= 1 && d <= GPR_KPAD, "gpr_dot2_features_direct: d=%d unsupported (1..%d)", d, GPR_KPAD);
     GPR_REQUIRE(ns >= 1 && ns <= FEAT_MAX_SPECIES, "gpr_dot2_features_direct: 1..%d species supported (got %d)", FEAT_MAX_SPECIES, ns);
+    GPR_REQUIRE(nsx >= 0 && nsx <= FEAT_MAX_EXTRA && (nsx == 0 || species_extra_host),
+                "gpr_dot2_features_direct: 0..%d extra species supported (got %d)", FEAT_MAX_EXTRA, nsx);
     const int npair = d * (d + 1) / 2, F = ns * (npair + 1);
     GPR_REQUIRE(psi && ld >= F, "gpr_dot2_features_direct: output leading dimension %lld < %d", ld, F);
     if (npts <= 0) return GPR_OK;
@@ -523,6 +529,8 @@ extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts
     A.x = x_dev; A.dxdr = dxdr_dev; A.ele = ele_dev; A.pt_row0 = pt_row0_dev; A.x_index = x_index_dev; A.d_index = dxdr_index_dev;
     A.npts = npts; A.nc = width ? 4 : 1; A.d = d; A.npair = npair; A.ns = ns;
     for (int s = 0; s < FEAT_MAX_SPECIES; s++) A.species[s] = s < ns ? species_host[s] : 0;
+    A.nsx = nsx;
+    for (int s = 0; s < FEAT_MAX_EXTRA; s++) A.species_x[s] = s < nsx ? species_extra_host[s] : 0;
     A.sigma0 = sigma0; A.sigma2 = sigma * sigma; A.out = psi; A.ld = ld; A.diag = diag;
     const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
     if (width == 3) {       // force points: symmetric rank-2k update on the matrix cores, one wavefront per point

@@ -22,6 +22,14 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     int nfree = natoms;
     if (free_mask) { nfree = 0; for (int a = 0; a < natoms; a++) nfree += free_mask[a] ? 1 : 0; }
     const long long m = (long long)nstruct + 3LL * nfree;
+    // species of the batch that the model does not know: no feature block, but part of the prior variance
+    std::vector<int> extra;
+    for (int a = 0; a < natoms; a++) {
+        const int z = numbers[a];
+        bool known = false;
+        for (int k = 0; k < ns; k++) known = known || species_host[k] == z;
+        if (!known && std::find(extra.begin(), extra.end(), z) == extra.end()) extra.push_back(z);
+    }
     GPR_REQUIRE(out_len >= (want_std ? 2 : 1) * m + 1, "gpr_predict_dot2_batch: out holds %lld doubles, %lld needed",
                 out_len, (want_std ? 2 : 1) * m + 1);
 
@@ -81,10 +89,10 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         d_diag = (double *)p;
     }
     if ((rc = gpr_dot2_features_direct(stream, d, 0, nstruct, d_atom0, nullptr, nullptr, d_x, nullptr, d_num, ns, species_host,
-                                       sigma, sigma0, d_psi, F, d_diag))) return cleanup(rc);
+                                       (int)extra.size(), extra.data(), sigma, sigma0, d_psi, F, d_diag))) return cleanup(rc);
     if (nfree > 0 &&
         (rc = gpr_dot2_features_direct(stream, d, 3, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr, d_num,
-                                       ns, species_host, sigma, 0.0, d_psi + (size_t)nstruct * F, F,
+                                       ns, species_host, (int)extra.size(), extra.data(), sigma, 0.0, d_psi + (size_t)nstruct * F, F,
                                        d_diag ? d_diag + nstruct : nullptr))) return cleanup(rc);
     // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0)
     if (want_std) {

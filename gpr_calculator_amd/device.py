@@ -381,12 +381,18 @@ def ws_finish(P, w, Q=None, diag=None, tail=0):
     return (out, flat) if tail else out
 
 
-def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True, psi_out=None, diag_out=None):
+def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True, psi_out=None, diag_out=None, species_all=None):
     """(Psi rows, prior variances) of the points of an unpacked SetPair straight from its row tensors and
     index arrays (gpr_dot2_features_direct): [npts, F] / [npts] for energies, [3 npts, F] / [3 npts] for forces;
     psi_out / diag_out: preallocated row windows to write into"""
     species = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
     ns = len(species)
+    # species of these points that the model does not know (prior variance only)
+    if species_all is None:
+        ele = pair.ele.tensor() if isinstance(pair.ele, DevArray) else pair.ele
+        species_all = torch.unique(ele).cpu().tolist()
+    extra = np.ascontiguousarray([z for z in sorted(set(int(v) for v in species_all)) if z not in set(species.tolist())],
+                                 dtype=np.int32)
     d = int(pair.x.shape[1])
     width = 0 if pair.dxdr is None else 3
     if width and int(pair.dxdr.shape[-1]) != 3:
@@ -398,7 +404,8 @@ def dot2_features_direct(pair, species, sigma, sigma0, want_diag=True, psi_out=N
     assert tuple(psi.shape) == (rows, F) and psi.stride(1) == 1 and (diag is None or diag.shape[0] == rows)
     check(_lib.lib().gpr_dot2_features_direct(
         stream_ptr(), d, width, pair.npts, ptr(pair.row0_dev()), ptr(pair.x_index), ptr(pair.dxdr_index),
-        ptr(pair.x), ptr(pair.dxdr), ptr(pair.ele), ns, species.ctypes.data_as(_lib.c_int_p), float(sigma),
+        ptr(pair.x), ptr(pair.dxdr), ptr(pair.ele), ns, species.ctypes.data_as(_lib.c_int_p), len(extra),
+        extra.ctypes.data_as(_lib.c_int_p), float(sigma),
         float(sigma0), ptr(psi), int(psi.stride(0)), ptr(diag)), "gpr_dot2_features_direct")
     return psi, diag
 

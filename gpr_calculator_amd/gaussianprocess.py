@@ -954,6 +954,7 @@ class GP():
         F = dev.SetPair(desc["x"], desc["dxdr"], ele, counts_f, x_index=x_index, dxdr_index=row_index)
         F._row0_dev = f_row0
         F._nbr = nbr                                                # keeps the index owner alive with the set
+        E.species_all = F.species_all = tuple(int(z) for z in np.unique(nbr.numbers))
         return {"energy": E, "force": F}, frees
 
     def add_structure(self, data, N_max=20, tol_e_var=1.2, tol_f_var=1.2, add_force=True):

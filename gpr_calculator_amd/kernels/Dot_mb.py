@@ -101,7 +101,8 @@ class Dot_mb(DeviceKernel):
         r0 = 0
         for ent, n, s0 in ents:
             dev.dot2_features_direct(ent, species, self.sigma, s0, want_diag, psi_out=P[r0:r0 + n],
-                                     diag_out=None if diag is None else diag[r0:r0 + n])
+                                     diag_out=None if diag is None else diag[r0:r0 + n],
+                                     species_all=getattr(ent, "species_all", None))
             r0 += n
         return P, diag
 

@@ -146,7 +146,10 @@ int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const int *speci
 int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int *pt_row0_dev,
                              const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev,
                              const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
+                             int nsx, const int *species_extra_host,
                              double sigma, double sigma0, double *psi, long long ld, double *diag);
+/* (species_extra_host[nsx]: atomic numbers that occur in the predicted points but not among the model's ns species;
+ * they get no feature block -- the kernel is zero across species -- but their own row pairs are part of k(x*, x*)) */
 
 /* Batched prediction of the Dot kernel at zeta = 2 in one call (what GP.predict_structures does for that kernel;
  * reference: one GP.predict_structure per structure, gaussianprocess.py:834-918): host arrays of the structures in

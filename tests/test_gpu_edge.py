@@ -152,3 +152,18 @@ def test_error_paths_fail_loudly():
     from gpr_calculator_amd.SO3 import SO3
     with pytest.raises(_lib.GprHipError):
         SO3(nmax=4, lmax=6, rcut=5.0).calculate(s)
+
+
+@pytest.mark.parametrize("kind", ["Dot", "RBF"])
+def test_species_unseen_in_training_contributes_nothing(kind):
+    """a predicted structure with an element the training set never saw (the kernels are zero across species): the
+    batch routes and the tuple route agree, and the energy of the foreign atoms' rows is pure prior"""
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model(kind)
+    s = fcc_cell(seed=21, reps=1, species=(46, 78), sigma=0.08)
+    s.numbers = np.array([46, 78, 29, 46])                     # Cu is not in the training set
+    Es, Fs, Es_std, Fs_std = gp.predict_structures([s], return_std=True)
+    gp.device_single = False
+    e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True)
+    assert abs(Es[0] - e1) < 1e-9 * max(1.0, abs(e1)) and np.abs(Fs[0] - f1).max() < 1e-9
+    assert abs(Es_std[0] - es1) < 1e-8 and np.abs(Fs_std[0] - fs1).max() < 1e-8
