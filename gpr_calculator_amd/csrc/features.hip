@@ -113,25 +113,20 @@ struct dfeat_args {
 constexpr int DF_ROWS = 32;      // rows staged per pass (16 lanes per row: the first 512 threads stage)
 constexpr int DF_LD = 33;        // padded row stride of the staged operands (doubles)
 
+// energy points: Phi_i^s = (1/n_i) sum_{rows of species s} vech(a~ a~^T) and the constant column sigma0 n_i^s / n_i;
+// one workgroup per point, thread e owns monomial e.  (Force points: dot2_force_features_mfma_kernel below.)
 template <int NS, int THREADS>
 __global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_args A) {
     __shared__ double sA[DF_ROWS * DF_LD];            // a~ (native norm)
-    __shared__ double sD[3][DF_ROWS * DF_LD];         // D / n per component
-    __shared__ double sP[DF_ROWS][4];                 // proj[3], s
-    __shared__ int sE[DF_ROWS];                       // species code, INT_MIN for rows that do not exist
-    __shared__ int sLive[DF_ROWS];                    // native convention: norm > 1e-8
-    __shared__ double sRed[9][3];
+    __shared__ int sE[DF_ROWS];                       // species code, INT_MIN for rows that do not exist or are skipped
     const int p = blockIdx.x, tid = threadIdx.x, e = tid;
     const bool act = e < A.npair;
     int k = 0, m = 0;
     if (act) { while ((k + 1) * (k + 2) / 2 <= e) k++; m = e - k * (k + 1) / 2; }
     const double wgt = (k == m) ? 1.0 : 1.4142135623730951;
-    double acc[NS][3], ace[NS][3], cnt[NS];
+    double acc[NS], cnt[NS];
 #pragma unroll
-    for (int s = 0; s < NS; s++) {
-        cnt[s] = 0.0;
-        acc[s][0] = acc[s][1] = acc[s][2] = 0.0; ace[s][0] = ace[s][1] = ace[s][2] = 0.0;
-    }
+    for (int s = 0; s < NS; s++) { cnt[s] = 0.0; acc[s] = 0.0; }
     const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
     const int slot = tid >> 4, g = tid & 15;          // staging: 16 lanes per row
     for (int rb = r0; rb < r1; rb += DF_ROWS) {
@@ -140,12 +135,8 @@ __global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_arg
             const int r = rb + slot;
             const bool stager = slot < DF_ROWS;
             const bool have = stager && r < r1;
-            int xs = -1, ds = -1;
-            if (have) {
-                xs = A.x_index ? A.x_index[r] : r;
-                ds = A.d_index ? A.d_index[r] : r;
-            }
-            const bool ok = have && xs >= 0 && (A.nc == 1 || ds >= 0);
+            const int xs = have ? (A.x_index ? A.x_index[r] : r) : -1;
+            const bool ok = have && xs >= 0;
             double x0 = 0.0, x1 = 0.0;
             if (ok) {
                 const double *xr = A.x + (size_t)xs * A.d;
@@ -156,45 +147,12 @@ __global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_arg
 #pragma unroll
             for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 16);
             const double n = sqrt(ss);
-            const bool live = ok && n > 1e-8;          // rbf_kernel.cpp:26,37 / dot_kernel.cpp skip
-            const double inv = n > 0.0 ? 1.0 / n : 0.0;
+            const bool live = ok && n > 1e-8;          // dot_kernel.cpp:28-44 skip
+            const double inv = live ? 1.0 / n : 0.0;
             if (stager) {
                 sA[slot * DF_LD + g] = x0 * inv;
                 sA[slot * DF_LD + g + 16] = x1 * inv;
-            }
-            if (A.nc == 4) {
-                double pr[3] = {0.0, 0.0, 0.0};
-                double dv[6];
-                const double *D = ok ? A.dxdr + (size_t)ds * A.d * 3 : nullptr;
-#pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int el = g + 16 * u;
-                    dv[u] = (ok && el < 3 * A.d) ? D[el] * inv : 0.0;
-                }
-                // a~_k of the element's k: lanes hold k = g and g + 16; fetch through the group
-#pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
-                    const double alo = __shfl(x0 * inv, kk & 15, 16), ahi = __shfl(x1 * inv, kk & 15, 16);
-                    const double ak = (kk < 16) ? alo : ahi;
-                    const double t = (el < 3 * A.d) ? ak * dv[u] : 0.0;
-                    pr[0] += (c == 0) ? t : 0.0; pr[1] += (c == 1) ? t : 0.0; pr[2] += (c == 2) ? t : 0.0;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; c++)
-#pragma unroll
-                    for (int o = 8; o >= 1; o >>= 1) pr[c] += __shfl_xor(pr[c], o, 16);
-#pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
-                    if (stager && kk < 32) sD[c][slot * DF_LD + kk] = dv[u];
-                }
-                if (stager && g < 3) sP[slot][g] = (g == 0) ? pr[0] : (g == 1 ? pr[1] : pr[2]);
-            }
-            if (stager && g == 0) {
-                sP[slot][3] = n / (n + 1e-8);
-                sE[slot] = ok ? A.ele[xs] : INT_MIN;
-                sLive[slot] = live ? 1 : 0;
+                if (g == 0) sE[slot] = live ? A.ele[xs] : INT_MIN;
             }
         }
         __syncthreads();
@@ -203,60 +161,20 @@ __global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_arg
         for (int r = 0; r < nr; r++) {
             const int el = sE[r];
             if (el == INT_MIN) continue;
-            const double ak = sA[r * DF_LD + k], am = sA[r * DF_LD + m], sc = sP[r][3], s2 = sc * sc;
-            const double live = sLive[r] ? 1.0 : 0.0;
-            double v[3] = {0.0, 0.0, 0.0}, ve[3] = {0.0, 0.0, 0.0};
-            if (A.nc == 4) {
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const double dk = sD[q][r * DF_LD + k], dm = sD[q][r * DF_LD + m], pq = sP[r][q];
-                    v[q] = live * wgt * (ak * (dm - am * pq) + am * (dk - ak * pq));
-                    ve[q] = wgt * s2 * (ak * (dm - s2 * am * pq) + am * (dk - s2 * ak * pq));
-                }
-            } else {
-                v[0] = live * wgt * ak * am;
-            }
+            const double v = wgt * sA[r * DF_LD + k] * sA[r * DF_LD + m];
 #pragma unroll
             for (int s = 0; s < NS; s++)
-                if (el == A.species[s]) {
-                    acc[s][0] += v[0]; acc[s][1] += v[1]; acc[s][2] += v[2];
-                    ace[s][0] += ve[0]; ace[s][1] += ve[1]; ace[s][2] += ve[2];
-                    cnt[s] += live;
-                }
+                if (el == A.species[s]) { acc[s] += v; cnt[s] += 1.0; }
         }
     }
-    const int nq = (A.nc == 4) ? 3 : 1;
     const int npt_rows = r1 - r0;
     const double inv_cnt = npt_rows > 0 ? 1.0 / npt_rows : 0.0;
     if (act) {
-        const double scale = (A.nc == 4) ? -1.0 : inv_cnt;
-        for (int q = 0; q < nq; q++) {
-            double *o = A.out + (long long)(p * nq + q) * A.ld;
+        double *o = A.out + (long long)p * A.ld;
 #pragma unroll
-            for (int s = 0; s < NS; s++) {
-                    o[s * A.npair + e] = scale * acc[s][q];
-                    if (e == 0) o[A.ns * A.npair + s] = (A.nc == 4) ? 0.0 : A.sigma0 * cnt[s] * inv_cnt;
-                }
-        }
-    }
-    if (A.nc == 4 && A.diag) {                       // sigma^2 |Psi_eps|^2, fixed-order block reduction
-        double dq[3] = {0.0, 0.0, 0.0};
-        if (act)
-#pragma unroll
-            for (int s = 0; s < NS; s++)
-#pragma unroll
-                for (int q = 0; q < 3; q++) dq[q] += ace[s][q] * ace[s][q];
-#pragma unroll
-        for (int q = 0; q < 3; q++)
-#pragma unroll
-            for (int o = 32; o >= 1; o >>= 1) dq[q] += __shfl_xor(dq[q], o);
-        __syncthreads();
-        if ((tid & 63) == 0) { sRed[tid >> 6][0] = dq[0]; sRed[tid >> 6][1] = dq[1]; sRed[tid >> 6][2] = dq[2]; }
-        __syncthreads();
-        if (tid < 3) {
-            double t = 0.0;
-            for (int w = 0; w < (int)(blockDim.x >> 6); w++) t += sRed[w][tid];
-            A.diag[3 * (size_t)p + tid] = A.sigma2 * t;
+        for (int s = 0; s < NS; s++) {
+            o[s * A.npair + e] = inv_cnt * acc[s];
+            if (e == 0) o[A.ns * A.npair + s] = A.sigma0 * cnt[s] * inv_cnt;
         }
     }
 }
