@@ -163,3 +163,54 @@ class GPR(Calculator):
         if peratom:
             return self.results["energy"] / len(self.results["forces"])
         return self.results["energy"]
+
+
+class LJ:
+    """Pairwise Lennard-Jones base potential with the reference's interface (gpr_calc/calculator.py:183-283):
+    `LJ(parameters={'rc', 'sigma', 'epsilon'})`, `calculate(atoms) -> (energy, forces[n, 3], stress)`, `save_dict` /
+    `load_from_dict`, usable as `GP(base_potential=LJ(...))` (gaussianprocess.py:579-583).  Truncated at rc and
+    shifted by its value there; stress = per-atom virial in Voigt order (xx, yy, zz, yz, xz, xy) divided by the cell
+    volume for fully periodic cells, None otherwise.  Host arithmetic (numpy over the periodic pair list): the base
+    potential is not on the GPR hot path."""
+
+    def __init__(self, parameters=None):
+        _parameters = {'name': 'LJ', 'rc': 5.0, 'sigma': 1.0, 'epsilon': 1.0}
+        if parameters is not None:
+            _parameters.update(parameters)
+        self.load_from_dict(_parameters)
+
+    def __str__(self):
+        return "LJ(eps: {:.3f}, sigma: {:.3f}, cutoff: {:.3f})".format(self.epsilon, self.sigma, self.rc)
+
+    def load_from_dict(self, dict0):
+        self._parameters = dict0
+        self.name = self._parameters["name"]
+        self.epsilon = self._parameters["epsilon"]
+        self.sigma = self._parameters["sigma"]
+        self.rc = self._parameters["rc"]
+
+    def save_dict(self):
+        return self._parameters
+
+    def calculate(self, atoms):
+        from .neighbors import atoms_arrays, neighbor_pairs
+        sigma, epsilon, rc = self.sigma, self.epsilon, self.rc
+        numbers, pos, cell, pbc = atoms_arrays(atoms)
+        n = len(numbers)
+        ci, cj, vec = neighbor_pairs(atoms, rc)                 # both directions: every atom sees all its neighbours
+        r2 = (vec ** 2).sum(axis=1)
+        c6 = (sigma ** 2 / r2) ** 3
+        c12 = c6 ** 2
+        e0 = 4 * epsilon * ((sigma / rc) ** 12 - (sigma / rc) ** 6)
+        pair_e = 4 * epsilon * (c12 - c6) - e0
+        pair_f = (-24 * epsilon * (2 * c12 - c6) / r2)[:, None] * vec        # (du/dr / r) d, d pointing to the neighbour
+        energy = 0.5 * pair_e.sum()
+        forces = np.zeros((n, 3))
+        np.add.at(forces, ci, pair_f)
+        stress = None
+        if bool(np.all(pbc)):
+            s33 = np.zeros((n, 3, 3))
+            np.add.at(s33, ci, 0.5 * pair_f[:, :, None] * vec[:, None, :])
+            voigt = np.stack((s33[:, 0, 0], s33[:, 1, 1], s33[:, 2, 2], s33[:, 1, 2], s33[:, 0, 2], s33[:, 0, 1]), axis=1)
+            stress = voigt / abs(np.linalg.det(cell))
+        return energy, forces, stress

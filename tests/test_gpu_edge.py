@@ -167,3 +167,30 @@ def test_species_unseen_in_training_contributes_nothing(kind):
     e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True)
     assert abs(Es[0] - e1) < 1e-9 * max(1.0, abs(e1)) and np.abs(Fs[0] - f1).max() < 1e-9
     assert abs(Es_std[0] - es1) < 1e-8 and np.abs(Fs_std[0] - fs1).max() < 1e-8
+
+
+def test_base_potential_is_subtracted_and_added_back():
+    """GP(base_potential=LJ): the model is trained on the residuals (gaussianprocess.py:579-583, 930-936) and the base
+    is added to every prediction (:895-901); labels produced by that very LJ leave zero residuals, so predictions
+    reproduce the base potential and the batch route agrees with the one-structure route"""
+    from gpr_calculator_amd.calculator import LJ
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    lj = LJ({"epsilon": 0.5, "sigma": 2.5, "rc": 5.0})
+    gp = GP(kernel=Dot_mb(para=[2.0, 2.0], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), base_potential=lj,
+            noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+    for seed in range(3):
+        a = fcc_cell(seed=seed, reps=1, species=(46, 78), sigma=0.08)
+        E, F = lj_energy_forces(a)
+        gp.add_structure((a, E, F))
+    gp.fit(show=False, opt=False)
+    assert np.abs(gp.y_train).max() < 1e-10                     # residuals
+    new = fcc_cell(seed=33, reps=1, species=(46, 78), sigma=0.08)
+    E0, F0 = lj_energy_forces(new)
+    Es, Fs, _, _ = gp.predict_structures([new], return_std=True)
+    assert abs(Es[0] - E0) < 1e-8 and np.abs(Fs[0] - F0).max() < 1e-8
+    gp.device_single = False
+    e1, f1, _ = gp.predict_structure(new, stress=False)
+    assert abs(e1 - E0) < 1e-8 and np.abs(f1 - F0).max() < 1e-8

@@ -82,3 +82,33 @@ def test_cur_selection_matches_leverage_score_definition():
     score = np.array([sum(U[j, k] ** 2 for k in null) for j in range(len(lam))])
     assert set(int(i) for i in ids) == set(int(i) for i in np.argsort(-score)[:8])
     assert len(CUR(np.eye(5), 1e-10)) == 0
+
+
+def test_lj_base_potential_energy_forces_stress():
+    """LJ base potential (calculator.py:183-283): forces = -dE/dr and total stress = (1/V) dE/d(strain) by finite
+    differences; same energies and forces as the label generator of the synthetic benchmark"""
+    from gpr_calculator_amd.calculator import LJ
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    atoms = fcc_cell(seed=3, reps=2, sigma=0.08)
+    lj = LJ({"epsilon": 0.5, "sigma": 2.5, "rc": 5.0})
+    E, F, S = lj.calculate(atoms)
+    E0, F0 = lj_energy_forces(atoms)
+    assert abs(E - E0) < 1e-10 and np.abs(F - F0).max() < 1e-10 and S.shape == (len(atoms), 6)
+    h = 1e-5
+    for (i, c) in ((0, 0), (7, 2)):
+        p, m = atoms.positions.copy(), atoms.positions.copy()
+        p[i, c] += h; m[i, c] -= h
+        Ep = lj.calculate(SimpleAtoms(atoms.numbers, p, atoms.cell, atoms.pbc))[0]
+        Em = lj.calculate(SimpleAtoms(atoms.numbers, m, atoms.cell, atoms.pbc))[0]
+        assert abs(F[i, c] + (Ep - Em) / (2 * h)) < 1e-6
+    V = abs(np.linalg.det(atoms.cell))
+    for (a, b, v) in ((0, 0, 0), (1, 2, 3)):                     # Voigt: xx -> 0, yz -> 3
+        eps = np.zeros((3, 3)); eps[a, b] += h / 2; eps[b, a] += h / 2
+        def strained(sign):
+            D = np.eye(3) + sign * eps
+            return lj.calculate(SimpleAtoms(atoms.numbers, atoms.positions @ D.T, atoms.cell @ D.T, atoms.pbc))[0]
+        dE = (strained(+1) - strained(-1)) / (2 * h)
+        assert abs(S[:, v].sum() - dE / V) < 1e-6 * max(1.0, abs(dE / V))
+    cluster = SimpleAtoms([46, 46, 46], [[0, 0, 0], [2.7, 0, 0], [0, 2.8, 0.1]], np.eye(3) * 20.0, [False] * 3)
+    assert lj.calculate(cluster)[2] is None and str(lj).startswith("LJ(") and LJ().save_dict()["rc"] == 5.0
