@@ -608,6 +608,62 @@ extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, in
 // Blocked triangular solve L X = B (trans 0) / L^T X = B (trans 1), in place.  With `dinv` (from
 // gpr_potrf_lower_dinv) the diagonal-block solves are 64 x 64 products; without it they fall back to
 // per-column substitution.
+// One step of the blocked triangular solve for a handful of right-hand sides (alpha = K^-1 y is one): with two launches
+// per 64-row block (diagonal apply, then a GEMM update whose N is the number of right-hand sides) the solve is nothing
+// but launch latency.  Here every workgroup forms x_k = W_k b_k (W_k = stored inverse of the diagonal block) itself;
+// workgroup 0 stores it to `xs`, workgroup w >= 1 subtracts L_ik x_k from one 64-row slab of the pending right-hand
+// side.  b_k is only read in the step, so no workgroup depends on another one of the same launch.
+constexpr int TRSV_MAX_RHS = 8;
+
+template <bool TRANS>
+__global__ void __launch_bounds__(256) trsv_step_kernel(const double *__restrict__ w, const double *__restrict__ l, long long ldl,
+                                                         double *b, long long ldb, double *xs, int nrhs, int k0, int kb, int n) {
+    __shared__ double T[NB][NB + 1];
+    __shared__ double X[NB][TRSV_MAX_RHS + 1];
+    __shared__ double Bk[NB][TRSV_MAX_RHS + 1];
+    const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6;
+    for (int i = ty; i < NB; i += 4) T[i][c] = w[i * NB + c];
+    for (int e = tid; e < NB * nrhs; e += 256) {
+        const int r = e / nrhs, j = e - r * nrhs;
+        Bk[r][j] = (r < kb) ? b[(long long)(k0 + r) * ldb + j] : 0.0;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * nrhs; e += 256) {              // x_k = W b_k (forward) or W^T b_k (backward)
+        const int r = e % NB, j = e / NB;
+        double acc = 0.0;
+        for (int q = 0; q < NB; q++) acc += (TRANS ? T[q][r] : T[r][q]) * Bk[q][j];
+        X[r][j] = acc;
+    }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = tid; e < kb * nrhs; e += 256) { const int r = e / nrhs, j = e - r * nrhs; xs[(long long)(k0 + r) * nrhs + j] = X[r][j]; }
+        return;
+    }
+    // slab of 64 pending rows: below the block (forward) or above it (backward)
+    const int s0 = TRANS ? (blockIdx.x - 1) * NB : k0 + kb + (blockIdx.x - 1) * NB;
+    const int send = TRANS ? k0 : n;
+    for (int i = ty; i < NB; i += 4) {
+        double v = 0.0;
+        if (!TRANS) { if (s0 + i < send && c < kb) v = l[(long long)(s0 + i) * ldl + k0 + c]; }      // L[s0+i][k0+c]
+        else        { if (i < kb && s0 + c < send) v = l[(long long)(k0 + i) * ldl + s0 + c]; }      // L[k0+i][s0+c]
+        T[i][c] = v;
+    }
+    __syncthreads();
+    for (int e = tid; e < NB * nrhs; e += 256) {
+        const int r = e % NB, j = e / NB;
+        if (s0 + r < send) {
+            double acc = 0.0;
+            for (int q = 0; q < NB; q++) acc += (TRANS ? T[q][r] : T[r][q]) * X[q][j];
+            b[(long long)(s0 + r) * ldb + j] -= acc;
+        }
+    }
+}
+
+__global__ void trsv_copy_kernel(int n, int nrhs, const double *xs, double *b, long long ldb) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < n * nrhs) b[(long long)(e / nrhs) * ldb + e % nrhs] = xs[e];
+}
+
 extern "C" int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                                    const double *dinv, double *b, long long ldb) {
     hipStream_t st = (hipStream_t)stream;
@@ -615,6 +671,25 @@ extern "C" int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, con
     if (n == 0 || nrhs == 0) return GPR_OK;
     GPR_REQUIRE(l && b && ldl >= n && ldb >= nrhs, "gpr_trsm_lower: bad arguments");
     const int nblk = (n + NB - 1) / NB;
+    if (dinv && nrhs <= TRSV_MAX_RHS) {              // few right-hand sides: one fused launch per block
+        void *p;
+        int rc = gpr_dev_alloc(&p, (size_t)n * nrhs * sizeof(double), st);
+        if (rc) return rc;
+        double *xs = (double *)p;
+        for (int ib = 0; ib < nblk; ib++) {
+            const int blk = trans ? nblk - 1 - ib : ib;
+            const int k0 = blk * NB, kb = (n - k0 < NB) ? n - k0 : NB;
+            const int pending = trans ? k0 : n - k0 - kb;
+            const dim3 grid(1 + (pending + NB - 1) / NB);
+            if (trans) hipLaunchKernelGGL(trsv_step_kernel<true>, grid, dim3(256), 0, st, dinv + (size_t)blk * NB * NB, l, ldl, b, ldb, xs, nrhs, k0, kb, n);
+            else hipLaunchKernelGGL(trsv_step_kernel<false>, grid, dim3(256), 0, st, dinv + (size_t)blk * NB * NB, l, ldl, b, ldb, xs, nrhs, k0, kb, n);
+        }
+        hipLaunchKernelGGL(trsv_copy_kernel, dim3((n * nrhs + 255) / 256), dim3(256), 0, st, n, nrhs, xs, b, ldb);
+        hipError_t e = hipGetLastError();
+        gpr_dev_free(p, st);
+        if (e != hipSuccess) { gpr_set_error("trsv_step launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
     for (int ib = 0; ib < nblk; ib++) {
         const int blk = trans ? nblk - 1 - ib : ib;
         const int k0 = blk * NB, kb = (n - k0 < NB) ? n - k0 : NB;
