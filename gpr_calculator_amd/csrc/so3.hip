@@ -232,16 +232,20 @@ struct so3_args {
     double *rdxdr;              // NULL: not wanted
 };
 
-constexpr int SO3_PC = 48;       // pairs whose tables are resident in LDS at a time
+constexpr int SO3_PC = 44;       // pairs whose tables are resident in LDS at a time (with the tables below: < 40 KB,
+                                 // four workgroups per CU)
 constexpr int SO3_NLP = 16;      // padded nmax (lmax+1)
 
 // dynamic LDS layout (doubles).  Per-centre tables: NY | RI | NL constants, c_tot [NLM] cplx, Rf [NL][L] cplx
 // (c_tot folded onto m >= 0), Tf [NL][3][2][LT+1] cplx (gradient coefficients contracted with c_tot, folded onto
-// m' >= 0), self sums [4][96], per wavefront R [16] | S [48]; then SO3_PC pair records of `rec` doubles:
+// m' >= 0; compact: 2 l + 2 entries per (n, l, k)), per wavefront R [16] | S [48], with stress output the (i, i)
+// image sums [4][96]; then SO3_PC pair records of `rec` doubles (the self sums [4][96] reuse that area at the end):
 //   ux uy uz 1/r r fc fc' w | A [16] | B [16] | Y_l^m, 0 <= m <= l <= lmax+1, triangular, cplx
 // (sII: with stress output, dP and R (x) dP summed over the periodic images of the centre itself, [4][96])
 struct so3_lds { int oNY, oRI, oNL, oCtot, oRf, oTf, oSelf, oII, oRS, oRec, rec, tri, total; };
-__host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
+// compact Tf index: per n the l-blocks hold 3 (2 l + 2) entries, l (l + 1) 3 entries precede block l
+__host__ __device__ inline int so3_tf_base(int n, int l, int L) { return (n * (L * L + L) + l * (l + 1)) * 3; }
+__host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
     const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, LT = lmax + 1, NLM = nmax * L * M, NL = nmax * L;
     so3_lds o;
     int off = 0;
@@ -251,22 +255,23 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax) {
     off = (off + 1) & ~1;
     o.oCtot = off; off += NLM * 2;
     o.oRf = off; off += NL * L * 2;
-    o.oTf = off; off += NL * 3 * 2 * (LT + 1) * 2;
-    o.oSelf = off; off += SO3_WAVES * 96;
-    o.oII = off; off += 96 * 4;             // stress only: dP sum and R (x) dP sum of the (i, i) image pairs
+    o.oTf = off; off += nmax * (L * L + L) * 3 * 2;
+    o.oII = off; if (stress) off += 96 * 4;   // stress only: dP sum and R (x) dP sum of the (i, i) image pairs
     o.oRS = off; off += SO3_WAVES * 64;
     o.tri = (LT + 1) * (LT + 2) / 2;
     o.rec = 8 + 2 * SO3_NLP + 2 * o.tri;
     o.oRec = off; off += SO3_PC * o.rec;
+    o.oSelf = o.oRec;                         // the records are dead when the self sums are formed
     o.total = off;
+    (void)NL;
     return o;
 }
 
-__global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) so3_centre_kernel(so3_args P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
     const int YW = P.lmax + 3, LT = P.lmax + 1;
-    const so3_lds lay = so3_layout(P.nmax, P.lmax);
+    const so3_lds lay = so3_layout(P.nmax, P.lmax, P.rdxdr != nullptr);
     const so3_tab tab = so3_table_layout(P.nmax, P.lmax, P.nseg, P.ncheb);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double *sNY = smem + lay.oNY, *sRI = smem + lay.oRI, *sNL = smem + lay.oNL;
@@ -416,7 +421,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                     out.re += sg * t2.re; out.im -= sg * t2.im;
                 }
             }
-            sTf[e] = out;
+            if (lp >= 0 && mp <= lp && l >= 1) sTf[so3_tf_base(nl / L, l, L) + k * (2 * l + 2) + (side ? l : 0) + mp] = out;
         }
     }
     __syncthreads();
@@ -473,8 +478,8 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                             if (m <= t_l) { const cplx y = yl[m], c = rf[m]; acc += y.re * c.re + y.im * c.im; }
                         sR[t_nl] = acc;
                     } else {
-                        const int W = LT + 1;
-                        const cplx *tf = sTf + ((t_nl * 3 + t_k) * 2) * W;
+                        // compact Tf: l entries for l' = l - 1 (m' <= l - 1), then l + 2 for l' = l + 1
+                        const cplx *tf = sTf + so3_tf_base(t_nl / L, t_l, L) + t_k * (2 * t_l + 2);
                         const int lp = t_l - 1, lq = t_l + 1;
                         const cplx *y0 = Y + (lp > 0 ? lp * (lp + 1) / 2 : 0), *y1 = Y + lq * (lq + 1) / 2;
 #pragma unroll
@@ -482,7 +487,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
                             if (m <= lp) { const cplx y = y0[m], c = tf[m]; acc += y.re * c.re + y.im * c.im; }
 #pragma unroll
                         for (int m = 0; m < SO3_LCAP + 1; m++)
-                            if (m <= lq && t_l >= 1) { const cplx y = y1[m], c = tf[W + m]; acc += y.re * c.re + y.im * c.im; }
+                            if (m <= lq && t_l >= 1) { const cplx y = y1[m], c = tf[t_l + m]; acc += y.re * c.re + y.im * c.im; }
                         sS[t_nl * 3 + t_k] = acc * rec[3];
                     }
                 }
@@ -529,6 +534,7 @@ __global__ void __launch_bounds__(256) so3_centre_kernel(so3_args P) {
         }
         if (nchunks > 1) __syncthreads();
     }
+    __syncthreads();                                   // every wavefront is done with the records: their area takes the self sums
     sSelf[wave * 96 + lane] = self0;
     if (lane < 32) sSelf[wave * 96 + 64 + lane] = self1;
     __syncthreads();
@@ -645,7 +651,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
     A.positions = positions; A.inv_vol = inv_vol; A.rdxdr = rdxdr;
-    const so3_lds lay = so3_layout(nmax, lmax);
+    const so3_lds lay = so3_layout(nmax, lmax, rdxdr != nullptr);
     const size_t lds_bytes = (size_t)lay.total * sizeof(double);
     if (lds_bytes > 96 * 1024) {
         gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d) needs %zu bytes of LDS", nmax, lmax, lds_bytes);
