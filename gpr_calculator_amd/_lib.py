@@ -58,6 +58,8 @@ _L1_SIGNATURES = {
     "gpr_nbr_force_rows": ([_vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gpr_nbr_check": ([_vp, c_int_p], _i),
     "gpr_nbr_status_to": ([_vp, _vp], _i),
+    "gpr_nbr_info_to": ([_vp, _vp], _i),
+    "gpr_nbr_build_device_capped": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i, _i, _i], _i),
     "gpr_nbr_build": ([C.POINTER(_vp), _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),
     "gpr_nbr_export": ([_vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p], _i),
@@ -69,7 +71,7 @@ _L1_SIGNATURES = {
     "gpr_so3_power_spectrum": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _i] + [_vp] * 8, _i),
     "gpr_so3_power_spectrum_stress": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _i] + [_vp] * 11, _i),
     "gpr_predict_dot2_batch": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _i,
-                               C.POINTER(C.c_ubyte), _i, c_int_p, _d, _d, _vp, _vp, _vp, _i, _vp, _ll], _i),
+                               C.POINTER(C.c_ubyte), _i, c_int_p, _d, _d, _vp, _vp, _vp, _i, _i, _i, _vp, _ll], _i),
     "gpr_so3_table_size": ([_i, _i, _i, _i], _ll),
     "gpr_so3_tables": ([_vp, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp], _i),
     "gpr_so3_radial": ([_vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp], _i),

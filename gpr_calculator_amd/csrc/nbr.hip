@@ -31,6 +31,7 @@ struct gpr_nbr {
     int *d_off = nullptr;                       // [centre_row0 (natoms+1) | centre_pair0 (natoms+1) | counts | err]
     double *d_vec = nullptr, *d_w = nullptr;
     int *d_rp0 = nullptr, *d_self = nullptr, *d_seq = nullptr, *d_err = nullptr;
+    bool capped = false;                        // P, S are capacities; the true sizes live in d_err[1..3] only
 };
 
 static void cross3(const double *a, const double *b, double *c) {
@@ -183,6 +184,7 @@ struct nbrk_args {
     int *rp0, *self_row, *seq;
     double rc2;
     int natoms, weight_on;
+    const int *ovf;                  // fill pass of a capped build: non-zero = capacities exceeded, write nothing
 };
 
 __device__ inline int wave_incl_scan(int v, int lane) {
@@ -198,6 +200,7 @@ __device__ inline int wave_incl_scan(int v, int lane) {
 template <bool FILL>
 __global__ void __launch_bounds__(64) nbr_centre_kernel(nbrk_args a) {
     const int i = blockIdx.x, lane = threadIdx.x;
+    if (FILL && a.ovf && a.ovf[0]) return;
     const nbr_sinfo si = a.sinfo[a.sid[i]];
     const int il = i - si.atom0;
     const double pix = a.wpos[3 * (size_t)i], piy = a.wpos[3 * (size_t)i + 1], piz = a.wpos[3 * (size_t)i + 2];
@@ -252,8 +255,12 @@ __global__ void __launch_bounds__(64) nbr_centre_kernel(nbrk_args a) {
     if (!FILL && lane == 0) { a.cnt_pairs[i] = pair_run; a.cnt_rows[i] = row_run; }
 }
 
-// exclusive scans of the per-centre counts: off = [cr0 (n+1) | cp0 (n+1)]; one workgroup
-__global__ void __launch_bounds__(1024) nbr_scan_kernel(int n, const int *cnt_rows, const int *cnt_pairs, int *off) {
+// exclusive scans of the per-centre counts: off = [cr0 (n+1) | cp0 (n+1)]; one workgroup.
+// info = [overflow, pairs, rows] (true totals).  Capped build (cap_rows > 0): the arrays downstream were sized from a
+// guess; when the totals exceed it every offset is zeroed -- each centre then has no pairs and no rows, so whatever is
+// already queued behind this kernel runs over empty ranges -- and the caller repeats the build with exact sizes.
+__global__ void __launch_bounds__(1024) nbr_scan_kernel(int n, const int *cnt_rows, const int *cnt_pairs, int *off, int *info,
+                                                        int cap_pairs, int cap_rows, int *rp0) {
     __shared__ int wsum[2][16];
     __shared__ int carry[2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -273,7 +280,15 @@ __global__ void __launch_bounds__(1024) nbr_scan_kernel(int n, const int *cnt_ro
         if (tid == 1023) { carry[0] = cr + wr + ir; carry[1] = cp + wp + ip; }
         __syncthreads();
     }
-    if (tid == 0) { off[n] = carry[0]; off[2 * n + 1] = carry[1]; }
+    const int S = carry[0], P = carry[1];
+    const bool over = cap_rows > 0 && (S > cap_rows || P > cap_pairs);
+    if (over)
+        for (int k = tid; k < 2 * n + 2; k += 1024) off[k] = 0;
+    else if (tid == 0) {
+        off[n] = S; off[2 * n + 1] = P;
+        if (rp0) rp0[S] = P;
+    }
+    if (tid == 0) { info[0] = over ? 1 : 0; info[1] = P; info[2] = S; }
 }
 
 struct frow_args {
@@ -288,7 +303,7 @@ struct frow_args {
 // ordered by neighbour) and the seq row (i, a) found among the rows of centre i
 __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
     const int q = blockIdx.x * blockDim.x + threadIdx.x;
-    if (q >= f.nrows) return;
+    if (q >= f.nrows || q >= f.pt_row0[f.npts]) return;      // nrows may be a capacity (capped build)
     int lo = 0, hi = f.npts;                   // last p with pt_row0[p] <= q
     while (hi - lo > 1) {
         const int mid = (lo + hi) >> 1;
@@ -310,9 +325,9 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 
 }  // namespace
 
-extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
-                                    const double *cells, const int *pbc, const int *numbers, double rcut,
-                                    int weight_on) {
+static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                 const double *cells, const int *pbc, const int *numbers, double rcut,
+                                 int weight_on, int cap_pairs, int cap_rows) {
     GPR_REQUIRE(out && atom0 && (nstruct == 0 || (positions && cells && pbc && numbers)), "gpr_nbr_build_device: null pointer");
     GPR_REQUIRE(rcut > 0.0, "gpr_nbr_build_device: rcut must be positive");
     hipStream_t st = (hipStream_t)stream;
@@ -362,8 +377,8 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
     nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
     nb->d_sid = nb->d_numbers + natoms;
     nb->d_atom0 = nb->d_sid + natoms;
-    if ((rc = gpr_dev_alloc(&p, (size_t)(4 * natoms + 4) * sizeof(int), st))) return fail(rc);
-    nb->d_off = (int *)p;                       // [cr0 | cp0 | cnt_rows | cnt_pairs | err]
+    if ((rc = gpr_dev_alloc(&p, (size_t)(4 * natoms + 8) * sizeof(int), st))) return fail(rc);
+    nb->d_off = (int *)p;                       // [cr0 | cp0 | cnt_rows | cnt_pairs | err | overflow, pairs, rows]
     int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
     nb->d_err = cnt_pairs + natoms;
     if ((rc = gpr_dev_alloc(&p, (size_t)std::max(natoms, 1) * sizeof(int), st))) return fail(rc);
@@ -372,16 +387,39 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
     nbrk_args a{};
     a.wpos = nb->d_wpos; a.shift = nb->d_shift; a.numbers = nb->d_numbers; a.sid = nb->d_sid; a.sinfo = nb->d_sinfo;
     a.cnt_pairs = cnt_pairs; a.cnt_rows = cnt_rows; a.rc2 = rcut * rcut; a.natoms = natoms; a.weight_on = weight_on;
+    const bool capped = cap_pairs > 0 && cap_rows > 0 && natoms > 0;
+    if (capped) {
+        // sizes guessed by the caller: everything is queued without waiting for the count pass; the true sizes and the
+        // overflow flag stay on the device (gpr_nbr_info_to)
+        nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;
+        if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double), st))) return fail(rc);
+        nb->d_vec = (double *)p; nb->d_w = nb->d_vec + 3 * (size_t)cap_pairs;
+        if ((rc = gpr_dev_alloc(&p, ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
+        nb->d_seq = (int *)p; nb->d_rp0 = nb->d_seq + 2 * (size_t)cap_rows;
+        hipError_t e = hipMemsetAsync(nb->d_err, 0, sizeof(int), st);
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: memset failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+        hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
+        hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
+                           cap_pairs, cap_rows, nb->d_rp0);
+        a.cr0 = nb->d_off; a.cp0 = nb->d_off + natoms + 1; a.ovf = nb->d_err + 1;
+        a.vec = nb->d_vec; a.w = nb->d_w; a.rp0 = nb->d_rp0; a.self_row = nb->d_self; a.seq = nb->d_seq;
+        hipLaunchKernelGGL(nbr_centre_kernel<true>, dim3(natoms), dim3(64), 0, st, a);
+        e = hipGetLastError();
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+        *out = nb;
+        return GPR_OK;
+    }
     nb->centre_row0.assign(natoms + 1, 0);
     std::vector<int> h_off(2 * (size_t)natoms + 2, 0);
     {
         hipError_t e = hipMemsetAsync(nb->d_err, 0, sizeof(int), st);
         if (e == hipSuccess && natoms > 0) {
             hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
-            hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off);
+            hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
+                               0, 0, (int *)nullptr);
             e = hipMemcpyAsync(h_off.data(), nb->d_off, h_off.size() * sizeof(int), hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);      // the sizes decide every later allocation
-        }
+        } else if (e == hipSuccess) e = hipMemsetAsync(nb->d_err + 1, 0, 3 * sizeof(int), st);
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: count pass failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
     }
     std::copy(h_off.begin(), h_off.begin() + natoms + 1, nb->centre_row0.begin());
@@ -403,6 +441,22 @@ extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, co
     }
     *out = nb;
     return GPR_OK;
+}
+
+extern "C" int gpr_nbr_build_device(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                    const double *cells, const int *pbc, const int *numbers, double rcut,
+                                    int weight_on) {
+    return nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, 0, 0);
+}
+
+// Same with caller-guessed capacities (pairs, seq rows): no host wait inside; gpr_nbr_sizes reports the capacities.
+// When the guess was too small the handle describes an empty neighbour table (every centre has zero pairs and rows)
+// and gpr_nbr_info_to reports overflow = 1 next to the true sizes; repeat with gpr_nbr_build_device or larger caps.
+extern "C" int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstruct, const int *atom0,
+                                           const double *positions, const double *cells, const int *pbc,
+                                           const int *numbers, double rcut, int weight_on, int cap_pairs, int cap_rows) {
+    GPR_REQUIRE(cap_pairs > 0 && cap_rows > 0, "gpr_nbr_build_device_capped: capacities must be positive");
+    return nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows);
 }
 
 extern "C" int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
@@ -439,6 +493,15 @@ extern "C" int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_
 
 namespace {
 __global__ void nbr_status_kernel(const int *err, double *dst) { dst[0] = (double)err[0]; }
+__global__ void nbr_info_kernel(const int *err, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)err[threadIdx.x]; }
+}
+
+// [missing force rows, overflow, pairs, rows] as doubles into dst[0..3] on the handle's stream (see gpr_nbr_status_to)
+extern "C" int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev) {
+    GPR_REQUIRE(nb && nb->on_device && dst_dev, "gpr_nbr_info_to: needs a device-built handle and a device pointer");
+    hipLaunchKernelGGL(nbr_info_kernel, dim3(1), dim3(64), 0, nb->st, nb->d_err, dst_dev);
+    GPR_HIP_TRY(hipGetLastError());
+    return GPR_OK;
 }
 
 // device-side variant of gpr_nbr_check: writes the count (as a double) into dst[0] on the handle's stream, so that it
@@ -467,6 +530,7 @@ extern "C" int gpr_nbr_sizes(const gpr_nbr *nb, int *npairs, int *nrows) {
 extern "C" int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *centre_pair0, int *centre_row0,
                               int *row_pair0, int *self_row, int *seq, int *struct_row0) {
     GPR_REQUIRE(nb, "gpr_nbr_export: null handle");
+    GPR_REQUIRE(!nb->capped, "gpr_nbr_export: a capped build keeps its sizes on the device; use gpr_nbr_build_device");
     auto cp = [](auto *dst, const auto &src) { if (dst && !src.empty()) std::copy(src.begin(), src.end(), dst); };
     cp(centre_row0, nb->centre_row0); cp(struct_row0, nb->struct_row0);
     if (!nb->on_device) {

@@ -2,7 +2,7 @@
 // (GP.predict_structures, gaussianprocess.py:834-918 for many structures at once): neighbour search, descriptor,
 // force-point regrouping, feature rows + prior variances, weight-space mean and variance, all queued on one stream
 // from one host call.  It only composes the library's own entry points (nbr.hip, so3.hip, features.hip, dense.hip);
-// the single synchronisation is the size download inside gpr_nbr_build_device.
+// the single synchronisation is the size download inside gpr_nbr_build_device, and none with guessed capacities.
 #include <algorithm>
 #include "gpr_internal.h"
 
@@ -11,7 +11,7 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
                                       const double *cells, const int *pbc, const int *numbers, int weight_on,
                                       const unsigned char *free_mask, int ns, const int *species_host, double sigma,
                                       double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev,
-                                      int want_std, double *out_dev, long long out_len) {
+                                      int want_std, int cap_pairs, int cap_rows, double *out_dev, long long out_len) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(nstruct >= 0 && atom0 && so3_table && species_host && w_dev && out_dev && (!want_std || M_dev || Cinv_dev),
                 "gpr_predict_dot2_batch: null pointer");
@@ -30,11 +30,15 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         for (int k = 0; k < ns; k++) known = known || species_host[k] == z;
         if (!known && std::find(extra.begin(), extra.end(), z) == extra.end()) extra.push_back(z);
     }
-    GPR_REQUIRE(out_len >= (want_std ? 2 : 1) * m + 1, "gpr_predict_dot2_batch: out holds %lld doubles, %lld needed",
-                out_len, (want_std ? 2 : 1) * m + 1);
+    GPR_REQUIRE(out_len >= (want_std ? 2 : 1) * m + 4, "gpr_predict_dot2_batch: out holds %lld doubles, %lld needed",
+                out_len, (want_std ? 2 : 1) * m + 4);
 
+    // capacities guessed by the caller (from the sizes an earlier call reported): nothing below waits for the device
     gpr_nbr *nb = nullptr;
-    int rc = gpr_nbr_build_device(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on);
+    const bool capped = cap_pairs > 0 && cap_rows > 0 && !free_mask && natoms > 0;
+    int rc = capped ? gpr_nbr_build_device_capped(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
+                                                  cap_pairs, cap_rows)
+                    : gpr_nbr_build_device(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on);
     if (rc) return rc;
     std::vector<void *> temps;
     auto cleanup = [&](int code) {
@@ -105,6 +109,6 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     }
     if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev,
                             (want_std && Cinv_dev) ? sigma * sigma : 0.0))) return cleanup(rc);
-    if ((rc = gpr_nbr_status_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
+    if ((rc = gpr_nbr_info_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
     return cleanup(GPR_OK);
 }

@@ -429,7 +429,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     if (P.dbg == 2) return;
     // ---- pass 2: dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
     //      lanes e < 3 d then combine into the row's outputs.
-    const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1], rself = P.self_row[ic];
+    const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1];
+    if (r0 == r1) return;                         // no rows at all: the emptied table of an overflowed capped build (nbr.hip)
+    const int rself = P.self_row[ic];
     const int ne = P.d * 3;
     int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
     if (lane < NL) t_nl = lane;

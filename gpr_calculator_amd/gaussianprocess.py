@@ -832,19 +832,34 @@ class GP():
         sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
         a0 = atom0.astype(np.int32)
         num = numbers.astype(np.int32)
-        out = torch.empty((2 if return_std else 1) * m + 1, dtype=dev.F64, device=dev.device())
         ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
         dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
-        dev.check(_lib.lib().gpr_predict_dot2_batch(
-            dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
-            len(mine_strucs), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num), int(bool(des.weight_on)),
-            None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)), len(sp), ip(sp),
-            float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std)),
-            dev.ptr(out), int(out.numel())), "gpr_predict_dot2_batch")
-        host = out.cpu().numpy()
-        if host[-1] != 0.0:
-            raise RuntimeError(f"neighbour table is not symmetric: {int(host[-1])} force rows missing")
+        nout = (2 if return_std else 1) * m
+        out = torch.empty(nout + 4, dtype=dev.F64, device=dev.device())
+        # neighbour-table capacities guessed from the densest batch seen so far (pairs and seq rows per atom, 12 % spare):
+        # with them the call queues everything without waiting for the device; too small a guess comes back flagged
+        # and the batch is repeated with exact sizes
+        hint = self._nbr_hint if mask is None else None
+        caps = (0, 0) if hint is None else (int(hint[0] * natoms * 1.125) + 64, int(hint[1] * natoms * 1.125) + 64)
+        for attempt in range(2):
+            dev.check(_lib.lib().gpr_predict_dot2_batch(
+                dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
+                len(mine_strucs), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num), int(bool(des.weight_on)),
+                None if mask is None else mask.ctypes.data_as(C.POINTER(C.c_ubyte)), len(sp), ip(sp),
+                float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std)),
+                caps[0], caps[1], dev.ptr(out), int(out.numel())), "gpr_predict_dot2_batch")
+            host = out.cpu().numpy()
+            if host[nout + 1] == 0.0:
+                break
+            caps = (0, 0)
+        if natoms:
+            per_atom = (host[nout + 2] / natoms, host[nout + 3] / natoms)
+            self._nbr_hint = per_atom if self._nbr_hint is None else (max(per_atom[0], self._nbr_hint[0]), max(per_atom[1], self._nbr_hint[1]))
+        if host[nout] != 0.0:
+            raise RuntimeError(f"neighbour table is not symmetric: {int(host[nout])} force rows missing")
         return host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
+
+    _nbr_hint = None
 
     native_batch = True
     device_single = True

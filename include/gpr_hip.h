@@ -155,17 +155,21 @@ int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int
  * reference: one GP.predict_structure per structure, gaussianprocess.py:834-918): host arrays of the structures in
  * (layout of gpr_nbr_build), device-resident model in (so3_table from gpr_so3_tables; w[F] and M[F, F] of the
  * weight-space fit, F = ns (d(d+1)/2 + 1); Cinv[F, F] = C^-1 lower triangular with I + Psi'^T D^-1 Psi' = C C^T may be
- * given instead of M (NULL otherwise): the variance product then skips the zero half), out_dev[(want_std ? 2 : 1) m + 1] = [mean | var | status] with
+ * given instead of M (NULL otherwise): the variance product then skips the zero half), out_dev[(want_std ? 2 : 1) m + 4] = [mean | var | status[4]] with
  * m = nstruct + 3 nfree rows ordered energies (per atom) then (fx, fy, fz) of every free atom; free_mask[natoms]
  * (host, may be NULL = every atom free) marks the atoms that get force rows (FixAtoms, gaussianprocess.py:823-832);
- * status = number of force rows the neighbour symmetry check could not find (0).  Queues neighbour search,
- * descriptor, regrouping, features, GEMM and the tail kernel on `stream`; the caller downloads out_dev. */
+ * status = [force rows the neighbour symmetry check could not find (0), overflow, neighbour pairs, seq rows].
+ * cap_pairs / cap_rows > 0 (and no free_mask): sizes guessed from what an earlier call reported in status[2..3]; the
+ * neighbour build then runs capped (gpr_nbr_build_device_capped) and the call queues everything without waiting for
+ * the device.  overflow = 1 means the guess was too small and mean / var are meaningless: call again with 0, 0.
+ * Queues neighbour search, descriptor, regrouping, features, GEMM and the tail kernel on `stream`; the caller
+ * downloads out_dev. */
 int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
                            const double *so3_table, int nstruct, const int *atom0, const double *positions,
                            const double *cells, const int *pbc, const int *numbers, int weight_on,
                            const unsigned char *free_mask, int ns, const int *species_host, double sigma,
                            double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev, int want_std,
-                           double *out_dev, long long out_len);
+                           int cap_pairs, int cap_rows, double *out_dev, long long out_len);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
@@ -225,6 +229,15 @@ int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const 
 int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
 /* same count written as a double to dst_dev[0] in stream order (rides along with the caller's result download) */
 int gpr_nbr_status_to(const gpr_nbr *nb, double *dst_dev);
+/* gpr_nbr_build_device with caller-guessed capacities for the pair and seq-row arrays: the count pass is not waited
+ * for, gpr_nbr_sizes returns the capacities and gpr_nbr_export is refused.  If the true sizes exceed the guess the
+ * handle describes an EMPTY table (every centre: zero pairs, zero rows), so whatever was queued behind it runs over
+ * empty ranges; gpr_nbr_info_to reports it. */
+int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
+                                int cap_pairs, int cap_rows);
+/* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
+int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
 
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
 /* Tables of one descriptor configuration, built on the device once: piecewise Chebyshev coefficients (nseg

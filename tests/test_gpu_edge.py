@@ -122,6 +122,79 @@ def test_native_batch_entry_matches_kernel_object_route():
     gp.native_batch = True
 
 
+def test_guessed_neighbour_capacities_and_their_overflow():
+    """The native call sizes its neighbour arrays from the densest batch seen so far and does not wait for the count
+    pass; results are those of the exact-size call bit for bit, and a guess that is too small is detected on the
+    device, leaves every downstream kernel with empty ranges, and is repeated with exact sizes."""
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model("Dot")
+    batch = [fcc_cell(seed=70 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(5)]
+    gp._nbr_hint = None
+    exact = gp.predict_structures(batch, return_std=True)            # exact sizes; records pairs / rows per atom
+    hint = gp._nbr_hint
+    assert hint is not None and hint[0] > hint[1] > 1.0
+    capped = gp.predict_structures(batch, return_std=True)           # capacities from the hint
+    gp._nbr_hint = (0.5, 0.5)                                         # far too small: overflow, then the exact repeat
+    over = gp.predict_structures(batch, return_std=True)
+    assert gp._nbr_hint == hint                                       # the true sizes came back with the flagged result
+    for other in (capped, over):
+        for k in range(len(batch)):
+            assert exact[0][k] == other[0][k] and np.array_equal(exact[1][k], other[1][k])
+            assert exact[2][k] == other[2][k] and np.array_equal(exact[3][k], other[3][k])
+    # the capped builder on its own: same table as the exact one, or an empty one with the overflow flag
+    import ctypes as C
+    import torch
+    from gpr_calculator_amd import _lib, device as dev
+    from gpr_calculator_amd.neighbors import batch_arrays
+    L = _lib.lib()
+    atom0, numbers, pos, cells, pbc = batch_arrays(batch)
+    a0, num = atom0.astype(np.int32), numbers.astype(np.int32)
+    ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
+    dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
+    n = int(atom0[-1])
+
+    def build(caps):
+        h = C.c_void_p()
+        if caps is None:
+            dev.check(L.gpr_nbr_build_device(C.byref(h), dev.stream_ptr(), len(batch), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num), 5.0, 0), "b")
+        else:
+            dev.check(L.gpr_nbr_build_device_capped(C.byref(h), dev.stream_ptr(), len(batch), ip(a0), dp(pos), dp(cells), ip(pbc), ip(num),
+                                                    5.0, 0, caps[0], caps[1]), "b")
+        info = torch.zeros(4, dtype=torch.float64, device="cuda")
+        dev.check(L.gpr_nbr_info_to(h, dev.ptr(info)), "info")
+        ptrs = [C.c_void_p() for _ in range(9)]
+        dev.check(L.gpr_nbr_device_arrays(h, *[C.byref(q) for q in ptrs]), "arrays")
+        P_, S_ = C.c_int(), C.c_int()
+        L.gpr_nbr_sizes(h, C.byref(P_), C.byref(S_))
+        info = info.cpu().numpy()
+        P, S = int(info[2]), int(info[3])
+        def grab(ptr, count, dtype):
+            t = torch.empty(count, dtype=dtype, device="cuda")
+            dev.check(L.gpr_memcpy_dtod(dev.stream_ptr(), dev.ptr(t), ptr, t.numel() * t.element_size()), "copy")
+            return t.cpu().numpy()
+        out = {"info": info, "sizes": (P_.value, S_.value), "cp0": grab(ptrs[2], n + 1, torch.int32), "cr0": grab(ptrs[3], n + 1, torch.int32)}
+        if info[1] == 0:
+            out.update(vec=grab(ptrs[0], 3 * P, torch.float64), w=grab(ptrs[1], P, torch.float64), rp0=grab(ptrs[4], S + 1, torch.int32),
+                       self_row=grab(ptrs[5], n, torch.int32), seq=grab(ptrs[6], 2 * S, torch.int32))
+        torch.cuda.synchronize()
+        L.gpr_nbr_destroy(h)
+        return out
+
+    ref = build(None)
+    P, S = ref["sizes"]
+    assert ref["info"][1] == 0 and (int(ref["info"][2]), int(ref["info"][3])) == (P, S)
+    roomy = build((P + 100, S + 7))
+    assert roomy["sizes"] == (P + 100, S + 7) and roomy["info"][1] == 0
+    for k in ("cp0", "cr0", "vec", "w", "rp0", "self_row", "seq"):
+        assert np.array_equal(ref[k], roomy[k]), k
+    tight = build((P, S))
+    assert tight["info"][1] == 0 and np.array_equal(tight["seq"], ref["seq"])
+    for caps in ((P - 1, S), (P, S - 1)):
+        small = build(caps)
+        assert small["info"][1] == 1 and (int(small["info"][2]), int(small["info"][3])) == (P, S)
+        assert not small["cp0"].any() and not small["cr0"].any()
+
+
 def test_error_paths_fail_loudly():
     """no silent fallbacks: a covariance that is not positive definite, a descriptor too long for this build, a
     mismatched counts vector and an unfitted model all raise"""
