@@ -1062,33 +1062,40 @@ class GP():
         return dict0
 
     def export_ase_db(self, db_filename, permission="w"):
-        from ase.db import connect       # ASE is optional at import time, required here
-        if permission == "w" and os.path.exists(db_filename):
-            os.remove(db_filename)
-        with connect(db_filename, serial=True) as db:
-            for _data in self.train_db:
-                (struc, energy, force, energy_in, force_in, _, _) = _data
-                actual_energy = deepcopy(energy)
-                actual_forces = force.copy()
-                if self.base_potential is not None:
-                    energy_off, force_off, _ = self.compute_base_potential(struc)
-                    actual_energy += energy_off
-                    actual_forces += force_off
-                data = {"energy": energy, "force": force, "energy_in": energy_in, "force_in": force_in}
-                kvp = {"dft_energy": actual_energy / len(force), "dft_fmax": np.max(np.abs(actual_forces.flatten()))}
-                struc.set_constraint()
-                db.write(struc, data=data, key_value_pairs=kvp)
+        """Training structures and labels as an ASE sqlite db with the reference's row layout
+        (gaussianprocess.py:689-724): data = {energy, force, energy_in, force_in}, key-value pairs dft_energy (per
+        atom, base potential added back) and dft_fmax.  Written by asedb.write_db (standard library; the file opens in
+        ase.db).  permission: "w" resets the file, "a+" appends."""
+        from .asedb import write_db
+        records = []
+        for _data in self.train_db:
+            (struc, energy, force, energy_in, force_in, _, _) = _data
+            actual_energy = deepcopy(energy)
+            actual_forces = force.copy()
+            if self.base_potential is not None:
+                energy_off, force_off, _ = self.compute_base_potential(struc)
+                actual_energy += energy_off
+                actual_forces += force_off
+            data = {"energy": energy, "force": np.asarray(force, dtype=np.float64), "energy_in": bool(energy_in),
+                    "force_in": [int(i) for i in force_in]}
+            kvp = {"dft_energy": float(actual_energy / len(force)), "dft_fmax": float(np.max(np.abs(actual_forces.flatten())))}
+            if hasattr(struc, "set_constraint"):
+                struc.set_constraint()          # the reference drops constraints before writing (:722)
+            records.append((struc, data, kvp))
+        write_db(db_filename, records, append=(permission != "w"))
 
     def extract_db(self, db_filename, N_max=None):
-        """structures of an ASE db -> descriptors -> training points (gaussianprocess.py:726-821)"""
-        from ase.db import connect
+        """structures of an ASE db -> descriptors -> training points (gaussianprocess.py:726-821).  Every rank reads
+        the file and computes the descriptors itself (one batched device launch) where the reference scatters rows
+        over MPI ranks and gathers the points."""
+        from .asedb import read_db
         rows = []
-        with connect(db_filename, serial=True) as db:
-            for row in db.select():
-                rows.append((db.get_atoms(id=row.id), row.data.energy, row.data.force.copy(),
-                             row.data.energy_in, row.data.force_in))
-        if N_max is not None:
-            rows = rows[:N_max]
+        for row in read_db(db_filename, limit=N_max):
+            d = row["data"]
+            rows.append((row["atoms"], d["energy"], np.array(d["force"], dtype=np.float64), bool(d["energy_in"]),
+                         [int(i) for i in np.asarray(d["force_in"]).reshape(-1)]))
+        if self.rank == 0:
+            print(f"Rank 0: Loaded {len(rows)} structures")
         self.set_train_pts(self.points_from_structures(rows), "w")
 
     def points_from_structures(self, rows):
@@ -1197,7 +1204,12 @@ class GP():
         else:
             raise NotImplementedError("unknown descriptors {:s}".format(dict0["descriptor"]["_type"]))
         if "base_potential" in dict0.keys():
-            raise NotImplementedError("base potentials (LJ, calculator.py:183-292) are outside the hot path")
+            if dict0["base_potential"]["name"] == "LJ":
+                from .calculator import LJ
+                instance.base_potential = LJ()
+                instance.base_potential.load_from_dict(dict0["base_potential"])
+            else:
+                raise NotImplementedError("unknown base potential {:s}".format(dict0["base_potential"]["name"]))
         instance.kernel.device = device
         instance.noise_e = dict0["noise"]["energy"]
         instance.noise_f = dict0["noise"]["force"]

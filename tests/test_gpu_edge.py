@@ -267,3 +267,40 @@ def test_base_potential_is_subtracted_and_added_back():
     gp.device_single = False
     e1, f1, _ = gp.predict_structure(new, stress=False)
     assert abs(e1 - E0) < 1e-8 and np.abs(f1 - F0).max() < 1e-8
+
+
+@pytest.mark.parametrize("kind", ["Dot", "RBF"])
+def test_save_and_load_reproduce_the_model(kind, tmp_path):
+    """GP.save -> json + ASE sqlite db (gaussianprocess.py:632-724), GP.load -> descriptors recomputed from the
+    stored structures, same training set, same predictions after the same fit; with an LJ base potential in the
+    json as well"""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.calculator import LJ
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from gpr_calculator_amd import asedb
+    gp = _model(kind)
+    gp.base_potential = None
+    js, db = str(tmp_path / "m.json"), str(tmp_path / "m.db")
+    gp.save(js, db, verbose=False)
+    rows = asedb.read_db(db)
+    assert len(rows) == 3 and rows[0]["data"]["force_in"] == [0, 1, 3] and rows[0]["data"]["energy_in"] is True
+    assert set(rows[0]["key_value_pairs"]) == {"dft_energy", "dft_fmax"}
+    gp2 = GP.load(js)
+    assert type(gp2.kernel) is type(gp.kernel) and gp2.kernel.parameters() == gp.kernel.parameters()
+    assert (gp2.noise_e, gp2.noise_f, gp2.N_energy, gp2.N_forces) == (gp.noise_e, gp.noise_f, gp.N_energy, gp.N_forces)
+    assert np.array_equal(gp2.y_train, gp.y_train)
+    gp2.fit(show=False, opt=False)
+    new = [fcc_cell(seed=60 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(2)]
+    a, b = gp.predict_structures(new, return_std=True), gp2.predict_structures(new, return_std=True)
+    for k in range(2):
+        assert abs(a[0][k] - b[0][k]) < 1e-9 and np.abs(a[1][k] - b[1][k]).max() < 1e-9
+        assert abs(a[2][k] - b[2][k]) < 1e-8 and np.abs(a[3][k] - b[3][k]).max() < 1e-8
+    # N_max keeps the first structures only; a base potential travels through the json
+    assert GP.load(js, N_max=2).N_energy == 2
+    gp.base_potential = LJ(parameters={"rc": 5.0, "sigma": 2.3, "epsilon": 0.1})
+    gp.save(js, db, verbose=False)
+    gp3 = GP.load(js)
+    assert isinstance(gp3.base_potential, LJ) and gp3.base_potential.sigma == 2.3
+    e_lj = gp.base_potential.calculate(rows[0]["atoms"])[0]
+    got = asedb.read_db(db)[0]["key_value_pairs"]["dft_energy"]
+    assert abs(got - (rows[0]["data"]["energy"] + e_lj) / len(rows[0]["atoms"])) < 1e-12
