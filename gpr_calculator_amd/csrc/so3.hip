@@ -267,6 +267,8 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
     return o;
 }
 
+// LC: compile-time bound on lmax + 1 (5 serves the usual lmax <= 4; the R/S sums below are unrolled to it)
+template <int LC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) so3_centre_kernel(so3_args P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
@@ -288,8 +290,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
 
     // Tables of the pairs [c0, c0 + npc): lanes over pairs.  Stage 0: one thread per pair -- geometry and cutoff.
-    // Stage 1: four threads per pair -- three evaluate the radial Chebyshev sums (A_nl, B_nl), one runs the
-    // Legendre / azimuth recurrences (Y_l^m, l <= lmax+1).  Ends with a block barrier.
+    // Stage 1: wavefronts 0-2, four threads per pair, evaluate the radial Chebyshev sums (A_nl, B_nl); wavefront 3,
+    // one thread per pair, runs the Legendre / azimuth recurrences (Y_l^m, l <= lmax+1) -- two code paths of about
+    // equal length on different wavefronts instead of one after the other in the same one.  Ends with a block barrier.
     auto build_records = [&](int c0, int npc) {
         if (tid < npc) {
             const int p = c0 + tid;
@@ -302,42 +305,41 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             rec[5] = 0.5 * (carg + 1.0); rec[6] = -0.5 * M_PI / P.rcut * sarg; rec[7] = P.wj[p];
         }
         __syncthreads();
-        {
+        if (wave < 3) {
             const int pr = tid >> 2, part = tid & 3;
             if (pr < npc) {
                 double *rec = recs + pr * REC;
-                if (part < 3) {
-                    const double r = rec[4], fc = rec[5], dfc = rec[6], w = rec[7];
-                    for (int nl = part; nl < NL; nl += 3) {
-                        const double F0 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl);
-                        const double F1 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl + 1);
-                        const double norm = sNL[nl % L] * w;                 // SO3.py:206, 221
-                        rec[8 + nl] = norm * (fc * F1 + dfc * F0);
-                        rec[8 + SO3_NLP + nl] = norm * fc * F0;
-                    }
-                } else {
-                    const double ux = rec[0], uy = rec[1], ct = rec[2];
-                    const double rho = sqrt(ux * ux + uy * uy);
-                    const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
-                    cplx *Y = (cplx *)(rec + 8 + 2 * SO3_NLP);
-                    double cm = 1.0, sm = 0.0, pmm = 1.0;            // cos(m phi), sin(m phi), P_m^m (Condon-Shortley)
-                    for (int m = 0; m <= LT; m++) {
-                        if (m > 0) {
-                            const double c2 = cm * cphi - sm * sphi;
-                            sm = sm * cphi + cm * sphi; cm = c2;
-                            pmm *= -(2 * m - 1) * rho;
-                        }
-                        double plm2 = 0.0, plm1 = pmm;
-                        for (int l = m; l <= LT; l++) {
-                            double plm;
-                            if (l == m) plm = pmm;
-                            else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
-                            else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) * sRI[l * YW + m];
-                            if (l > m) { plm2 = plm1; plm1 = plm; }
-                            const double nrm = sNY[l * YW + m] * plm;
-                            Y[l * (l + 1) / 2 + m] = {nrm * cm, nrm * sm};
-                        }
-                    }
+                const double r = rec[4], fc = rec[5], dfc = rec[6], w = rec[7];
+                for (int nl = part; nl < NL; nl += 4) {
+                    const double F0 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl);
+                    const double F1 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl + 1);
+                    const double norm = sNL[nl % L] * w;                 // SO3.py:206, 221
+                    rec[8 + nl] = norm * (fc * F1 + dfc * F0);
+                    rec[8 + SO3_NLP + nl] = norm * fc * F0;
+                }
+            }
+        } else if (lane < npc) {
+            double *rec = recs + lane * REC;
+            const double ux = rec[0], uy = rec[1], ct = rec[2];
+            const double rho = sqrt(ux * ux + uy * uy);
+            const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
+            cplx *Y = (cplx *)(rec + 8 + 2 * SO3_NLP);
+            double cm = 1.0, sm = 0.0, pmm = 1.0;            // cos(m phi), sin(m phi), P_m^m (Condon-Shortley)
+            for (int m = 0; m <= LT; m++) {
+                if (m > 0) {
+                    const double c2 = cm * cphi - sm * sphi;
+                    sm = sm * cphi + cm * sphi; cm = c2;
+                    pmm *= -(2 * m - 1) * rho;
+                }
+                double plm2 = 0.0, plm1 = pmm;
+                for (int l = m; l <= LT; l++) {
+                    double plm;
+                    if (l == m) plm = pmm;
+                    else if (l == m + 1) plm = (2 * m + 1) * ct * pmm;
+                    else plm = ((2 * l - 1) * ct * plm1 - (l + m - 1) * plm2) * sRI[l * YW + m];
+                    if (l > m) { plm2 = plm1; plm1 = plm; }
+                    const double nrm = sNY[l * YW + m] * plm;
+                    Y[l * (l + 1) / 2 + m] = {nrm * cm, nrm * sm};
                 }
             }
         }
@@ -438,6 +440,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     else if (lane < 4 * NL) { t_nl = (lane - NL) / 3; t_k = (lane - NL) % 3; }
     const bool has_task = lane < 4 * NL;
     const int t_l = t_nl % L;
+    // R lane: Y_l . Rf (l + 1 terms).  S lane: Y_{l-1} . Tf (l terms, m' <= l - 1) then Y_{l+1} . Tf (l + 2 terms); the
+    // compact Tf block of (n, l, k) holds them back to back
+    const cplx *t_c1 = sRf + t_nl * L, *t_c2 = sRf;
+    int t_y1 = t_l * (t_l + 1) / 2, t_y2 = 0, t_n1 = t_l + 1, t_n2 = 0, t_dst = t_nl;
+    if (t_k >= 0) {
+        t_c1 = sTf + so3_tf_base(t_nl / L, t_l, L) + t_k * (2 * t_l + 2);
+        t_c2 = t_c1 + t_l;
+        t_y1 = t_l >= 2 ? (t_l - 1) * t_l / 2 : 0; t_y2 = (t_l + 1) * (t_l + 2) / 2;
+        t_n1 = t_l; t_n2 = t_l >= 1 ? t_l + 2 : 0;
+        t_dst = 16 + t_nl * 3 + t_k;
+    }
     int e_k[2], iA1[2], iA2[2];
 #pragma unroll
     for (int rnd = 0; rnd < 2; rnd++) {
@@ -471,27 +484,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 const double *rec = recs + (p - c0) * REC;
                 const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
                 if (has_task) {
-                    // fixed-length, predicated sums: every LDS load of the task is issued before the first add
+                    // one code path for R and S lanes: two fixed-length, predicated segments Re[Y conj(c)]; every LDS
+                    // load of the task is issued before the first add
+                    const cplx *y1 = Y + t_y1, *y2 = Y + t_y2;
                     double acc = 0.0;
-                    if (t_k < 0) {
-                        const cplx *rf = sRf + t_nl * L, *yl = Y + t_l * (t_l + 1) / 2;
 #pragma unroll
-                        for (int m = 0; m < SO3_LCAP; m++)
-                            if (m <= t_l) { const cplx y = yl[m], c = rf[m]; acc += y.re * c.re + y.im * c.im; }
-                        sR[t_nl] = acc;
-                    } else {
-                        // compact Tf: l entries for l' = l - 1 (m' <= l - 1), then l + 2 for l' = l + 1
-                        const cplx *tf = sTf + so3_tf_base(t_nl / L, t_l, L) + t_k * (2 * t_l + 2);
-                        const int lp = t_l - 1, lq = t_l + 1;
-                        const cplx *y0 = Y + (lp > 0 ? lp * (lp + 1) / 2 : 0), *y1 = Y + lq * (lq + 1) / 2;
+                    for (int m = 0; m < LC; m++)
+                        if (m < t_n1) { const cplx y = y1[m], c = t_c1[m]; acc += y.re * c.re + y.im * c.im; }
 #pragma unroll
-                        for (int m = 0; m < SO3_LCAP - 1; m++)
-                            if (m <= lp) { const cplx y = y0[m], c = tf[m]; acc += y.re * c.re + y.im * c.im; }
-#pragma unroll
-                        for (int m = 0; m < SO3_LCAP + 1; m++)
-                            if (m <= lq && t_l >= 1) { const cplx y = y1[m], c = tf[t_l + m]; acc += y.re * c.re + y.im * c.im; }
-                        sS[t_nl * 3 + t_k] = acc * rec[3];
-                    }
+                    for (int m = 0; m < LC + 1; m++)
+                        if (m < t_n2) { const cplx y = y2[m], c = t_c2[m]; acc += y.re * c.re + y.im * c.im; }
+                    sR[t_dst] = t_k < 0 ? acc : acc * rec[3];
                 }
                 so3_wave_lds_sync();
 #pragma unroll
@@ -661,11 +664,13 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     }
     static bool attr_set = false;
     if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
-    hipLaunchKernelGGL(so3_centre_kernel, dim3(ncentres), dim3(256), lds_bytes, st, A);
+    if (lmax + 1 <= 5) hipLaunchKernelGGL(so3_centre_kernel<5>, dim3(ncentres), dim3(256), lds_bytes, st, A);
+    else hipLaunchKernelGGL(so3_centre_kernel<SO3_LCAP>, dim3(ncentres), dim3(256), lds_bytes, st, A);
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("so3_centre_kernel launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
