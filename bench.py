@@ -193,13 +193,20 @@ def main():
         n_nbr = int(gp.descriptor.neighbor_index_batch(batch)["w"].shape[0])
         F = (30 * 31 // 2 + 1) * len(set(np.concatenate(desc["numbers"]).tolist()))
         per_step = {k: (ms / args.steps, n / args.steps) for k, (ms, n) in prof.items() if n}
+        # Dot at zeta = 2: the step is the native weight-space call (csrc/predict.hip), whose one GEMM is the variance product
+        ws_native = args.kernel == "Dot" and gp.native_batch and getattr(gp.kernel, "use_feature_map", False) \
+            and gp._weight_space() is not None
         work = {   # algorithmic FP64 operations of one step per kernel kind (SURVEY.md section 8d where it defines them)
             "ff": ("kblock_kernel<FF>: force-force block of K_trans", same_species_pairs(ele_rows, tE) * FLOP_PER_PAIR_FF,
                    "1.10 kflop per same-species row pair"),
             "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
                      "N^2 m (triangular-solve form of the variance)"),
-            "gemm": ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
-                     2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N"),
+            "gemm": (("gemm128_kernel via gpr_gemm_nt_lower: Q = Psi* C^-T, the weight-space predictive variance "
+                      "|psi|^2 - |C^-1 psi|^2 (C^-1 lower triangular: half of the m x F x F product)",
+                      float(m_rows) * F * (F + 1), "m F (F + 1) for the m = %d predicted rows and F = %d features" % (m_rows, F))
+                     if ws_native else
+                     ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
+                      2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N")),
             "gemv": ("gemv_t_partial_kernel: K_trans alpha", 2.0 * m_rows * N, "2 m N"),
             "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives (FP64 vector; no matrix shape)", n_nbr * 4.0e3,
                     "~4 kflop per neighbour pair (30 Clenshaw sums of 16 terms, Y_lm recurrences, c_tot, R/S "

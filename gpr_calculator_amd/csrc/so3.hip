@@ -197,6 +197,27 @@ __device__ __noinline__ double cheb_eval(const double *cheb, int nseg, int NF, d
     return cf[0] + t * b1 - b2;
 }
 
+// F0 and F1 of one (n, l) -- functions f and f + 1, f even -- in one pass: their coefficients are neighbours in the
+// table, one 16-byte load fetches both, and the two recurrences are independent chains
+__device__ __forceinline__ void cheb_eval2(const double *cheb, int nseg, int NF, double rcut, double r, int f, double &v0, double &v1) {
+    int seg = (int)(r * nseg / rcut);
+    seg = seg < 0 ? 0 : (seg > nseg - 1 ? nseg - 1 : seg);
+    const double inv_half = 2.0 * nseg / rcut, mid = (seg + 0.5) * rcut / nseg;
+    const double t = (r - mid) * inv_half, t2 = 2.0 * t;
+    const double2 *c = (const double2 *)(cheb + (size_t)seg * SO3_NCHEB * NF + f);
+    double2 cf[SO3_NCHEB];
+#pragma unroll
+    for (int k = 0; k < SO3_NCHEB; k++) cf[k] = c[k * (NF / 2)];    // all loads in flight before the recurrences
+    double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
+#pragma unroll
+    for (int k = SO3_NCHEB - 1; k >= 1; k--) {
+        const double a0 = cf[k].x + t2 * a1 - a2; a2 = a1; a1 = a0;
+        const double b0 = cf[k].y + t2 * b1 - b2; b2 = b1; b1 = b0;
+    }
+    v0 = cf[0].x + t * a1 - a2;
+    v1 = cf[0].y + t * b1 - b2;
+}
+
 __global__ void so3_radial_eval_kernel(const double *cheb, int nseg, int ncheb, int NF, double rcut, int nr, const double *rs,
                                        double *out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -240,87 +261,97 @@ constexpr int SO3_NLP = 16;      // padded nmax (lmax+1)
 // (c_tot folded onto m >= 0), Tf [NL][3][2][LT+1] cplx (gradient coefficients contracted with c_tot, folded onto
 // m' >= 0; compact: 2 l + 2 entries per (n, l, k)), per wavefront R [16] | S [48], with stress output the (i, i)
 // image sums [4][96]; then SO3_PC pair records of `rec` doubles (the self sums [4][96] reuse that area at the end):
-//   ux uy uz 1/r r fc fc' w | A [16] | B [16] | Y_l^m, 0 <= m <= l <= lmax+1, triangular, cplx
+//   ux uy uz 1/r r - - - | A [16] | B [16] | Y_l^m, 0 <= m <= l <= lmax+1, triangular, cplx
 // (sII: with stress output, dP and R (x) dP summed over the periodic images of the centre itself, [4][96])
-struct so3_lds { int oNY, oRI, oNL, oCtot, oRf, oTf, oSelf, oII, oRS, oRec, rec, tri, total; };
+struct so3_lds { int oNY, oRI, oNL, oCG, oPart, oCtot, oRf, oTf, oSelf, oII, oRS, oRec, rec, tri, pc, total; };
 // compact Tf index: per n the l-blocks hold 3 (2 l + 2) entries, l (l + 1) 3 entries precede block l
 __host__ __device__ inline int so3_tf_base(int n, int l, int L) { return (n * (L * L + L) + l * (l + 1)) * 3; }
+// Without stress rows pass 2 runs one lane per (pair, l): at most 256 / (lmax + 1) pairs per chunk, no per-wavefront
+// R/S exchange area, and the record area is reused as the staging area of the chunk's dP rows ([pc + 1][3 d]: the
+// rows of pc pairs plus the empty (i, i) row between them) with the pair -> row map behind the records.
 __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
     const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3, LT = lmax + 1, NLM = nmax * L * M, NL = nmax * L;
+    const int ne = nmax * (nmax + 1) / 2 * L * 3;
     so3_lds o;
     int off = 0;
     o.oNY = off; off += YW * YW;
     o.oRI = off; off += YW * YW;
     o.oNL = off; off += L;
+    o.oCG = off; off += L * M * 6;            // gradient coupling coefficients (SO3.py:682-707)
     off = (off + 1) & ~1;
+    o.oPart = off; off += 256 * 2;            // c_tot partial sums of the pair groups of pass 1
     o.oCtot = off; off += NLM * 2;
     o.oRf = off; off += NL * L * 2;
     o.oTf = off; off += nmax * (L * L + L) * 3 * 2;
     o.oII = off; if (stress) off += 96 * 4;   // stress only: dP sum and R (x) dP sum of the (i, i) image pairs
-    o.oRS = off; off += SO3_WAVES * 64;
+    o.oRS = off; if (stress) off += SO3_WAVES * 64;
     o.tri = (LT + 1) * (LT + 2) / 2;
     o.rec = 8 + 2 * SO3_NLP + 2 * o.tri;
-    o.oRec = off; off += SO3_PC * o.rec;
+    o.pc = stress ? SO3_PC : (SO3_PC < 256 / L ? SO3_PC : 256 / L);
+    o.oRec = off;
+    const int area_rec = o.pc * o.rec + o.pc, area_rows = (o.pc + 1) * ne;    // records + pair->row map | row staging
+    off += stress ? o.pc * o.rec : (area_rec > area_rows ? area_rec : area_rows);
     o.oSelf = o.oRec;                         // the records are dead when the self sums are formed
     o.total = off;
     (void)NL;
     return o;
 }
 
-// LC: compile-time bound on lmax + 1 (5 serves the usual lmax <= 4; the R/S sums below are unrolled to it)
-template <int LC>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) so3_centre_kernel(so3_args P) {
+// LC, NM: compile-time bounds on lmax + 1 and nmax (5, 3 serve the usual nmax <= 3, lmax <= 4; the R/S sums below are
+// unrolled to them)
+template <int LC, int NM, bool STRESS>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) so3_centre_kernel(so3_args P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
     const int YW = P.lmax + 3, LT = P.lmax + 1;
-    const so3_lds lay = so3_layout(P.nmax, P.lmax, P.rdxdr != nullptr);
+    const so3_lds lay = so3_layout(P.nmax, P.lmax, STRESS);
+    const int PC = lay.pc;                        // pairs per chunk
     const so3_tab tab = so3_table_layout(P.nmax, P.lmax, P.nseg, P.ncheb);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const double *sNY = smem + lay.oNY, *sRI = smem + lay.oRI, *sNL = smem + lay.oNL;
     cplx *ctot = (cplx *)(smem + lay.oCtot), *sRf = (cplx *)(smem + lay.oRf), *sTf = (cplx *)(smem + lay.oTf);
     double *sSelf = smem + lay.oSelf;
-    double *sR = smem + lay.oRS + wave * 64, *sS = sR + 16;
+    double *sR = smem + lay.oRS + wave * 64, *sS = sR + 16;      // stress variant only
     double *recs = smem + lay.oRec;
     const int REC = lay.rec;
     const int ic = blockIdx.x;
     const int p0 = P.centre_pair0[ic], p1 = P.centre_pair0[ic + 1];
-    const double *gCG = P.table + tab.oCG;
+    const double *sCG = smem + lay.oCG;
     for (int e = tid; e < YW * YW; e += 256) { smem[lay.oNY + e] = P.table[tab.oNY + e]; smem[lay.oRI + e] = P.table[tab.oRI + e]; }
     for (int e = tid; e < L; e += 256) smem[lay.oNL + e] = P.table[tab.oNL + e];
+    for (int e = tid; e < L * M * 6; e += 256) smem[lay.oCG + e] = P.table[tab.oCG + e];
     __syncthreads();
 
-    // Tables of the pairs [c0, c0 + npc): lanes over pairs.  Stage 0: one thread per pair -- geometry and cutoff.
-    // Stage 1: wavefronts 0-2, four threads per pair, evaluate the radial Chebyshev sums (A_nl, B_nl); wavefront 3,
-    // one thread per pair, runs the Legendre / azimuth recurrences (Y_l^m, l <= lmax+1) -- two code paths of about
-    // equal length on different wavefronts instead of one after the other in the same one.  Ends with a block barrier.
+    // Tables of the pairs [c0, c0 + npc): lanes over pairs.  Wavefronts 0-2, four threads per pair: distance, cutoff
+    // and the radial Chebyshev sums (A_nl, B_nl); wavefront 3, one thread per pair: unit vector and the Legendre /
+    // azimuth recurrences (Y_l^m, l <= lmax+1) -- two code paths of about equal length on different wavefronts, neither
+    // waiting for the other.  Ends with a block barrier.
     auto build_records = [&](int c0, int npc) {
-        if (tid < npc) {
-            const int p = c0 + tid;
-            double *rec = recs + tid * REC;
-            const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
-            const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
-            double sarg, carg;
-            sincospi(r / P.rcut, &sarg, &carg);             // cutoff 0.5 (cos(pi r / rcut) + 1) and its derivative
-            rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
-            rec[5] = 0.5 * (carg + 1.0); rec[6] = -0.5 * M_PI / P.rcut * sarg; rec[7] = P.wj[p];
-        }
-        __syncthreads();
         if (wave < 3) {
             const int pr = tid >> 2, part = tid & 3;
             if (pr < npc) {
+                const int p = c0 + pr;
                 double *rec = recs + pr * REC;
-                const double r = rec[4], fc = rec[5], dfc = rec[6], w = rec[7];
+                const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+                const double r = sqrt(vx * vx + vy * vy + vz * vz), w = P.wj[p];
+                double sarg, carg;
+                sincospi(r / P.rcut, &sarg, &carg);         // cutoff 0.5 (cos(pi r / rcut) + 1) and its derivative
+                const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI / P.rcut * sarg;
                 for (int nl = part; nl < NL; nl += 4) {
-                    const double F0 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl);
-                    const double F1 = cheb_eval(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl + 1);
+                    double F0, F1;
+                    cheb_eval2(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl, F0, F1);
                     const double norm = sNL[nl % L] * w;                 // SO3.py:206, 221
                     rec[8 + nl] = norm * (fc * F1 + dfc * F0);
                     rec[8 + SO3_NLP + nl] = norm * fc * F0;
                 }
             }
         } else if (lane < npc) {
+            const int p = c0 + lane;
             double *rec = recs + lane * REC;
-            const double ux = rec[0], uy = rec[1], ct = rec[2];
+            const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+            const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
+            const double ux = vx * inv_r, uy = vy * inv_r, ct = vz * inv_r;
+            rec[0] = ux; rec[1] = uy; rec[2] = ct; rec[3] = inv_r; rec[4] = r;
             const double rho = sqrt(ux * ux + uy * uy);
             const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
             cplx *Y = (cplx *)(rec + 8 + 2 * SO3_NLP);
@@ -346,18 +377,26 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         __syncthreads();
     };
 
-    // ---- pass 1: c_tot[nl][m >= 0] = sum over pairs of B_nl Y_l^m; thread e = (nl, m)
-    const int nchunks = (p1 - p0 + SO3_PC - 1) / SO3_PC;
+    // ---- pass 1: c_tot[nl][m >= 0] = sum over pairs of B_nl Y_l^m.  Task = one (n, l, m <= l); the block splits into
+    //      G groups of 256 / G threads, group g sums the pairs q = g, g + G, ... of a chunk, and the G partial sums are
+    //      added in group order.
+    const int nchunks = (p1 - p0 + PC - 1) / PC;
     {
-        const int nl = tid / L, m = tid % L, l = nl % L;
-        const bool mine = tid < NL * L && m <= l;
+        const int tri_l = L * (L + 1) / 2, ntask = P.nmax * tri_l;
+        const int G = ntask <= 64 ? 4 : (ntask <= 128 ? 2 : 1), slots = 256 / G;
+        const int task = tid % slots, grp = tid / slots;
+        int n = task / tri_l, l = 0;
+        const int rem = task - n * tri_l;
+        while ((l + 1) * (l + 2) / 2 <= rem) l++;
+        const int m = rem - l * (l + 1) / 2, nl = n * L + l;
+        const bool mine = task < ntask;
         cplx acc = {0.0, 0.0};
-        for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
-            const int npc = min(SO3_PC, p1 - c0);
+        for (int c0 = p0; c0 < p1; c0 += PC) {
+            const int npc = min(PC, p1 - c0);
             build_records(c0, npc);
             if (P.dbg == 1) return;
             if (mine)
-                for (int q = 0; q < npc; q++) {
+                for (int q = grp; q < npc; q += G) {
                     const double *rec = recs + q * REC;
                     const cplx y = ((const cplx *)(rec + 8 + 2 * SO3_NLP))[l * (l + 1) / 2 + m];
                     const double b = rec[8 + SO3_NLP + nl];
@@ -365,9 +404,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 }
             if (nchunks > 1) __syncthreads();            // records are rebuilt by the next chunk
         }
+        cplx *sPart = (cplx *)(smem + lay.oPart);
+        if (mine) sPart[grp * slots + task] = acc;
         for (int e = tid; e < NLM; e += 256) ctot[e] = {0.0, 0.0};
         __syncthreads();
-        if (mine) {
+        if (mine && grp == 0) {
+            for (int g = 1; g < G; g++) { const cplx o = sPart[g * slots + task]; acc.re += o.re; acc.im += o.im; }
             ctot[nl * M + P.lmax + m] = acc;
             if (m > 0) { const double sg = (m & 1) ? -1.0 : 1.0; ctot[nl * M + P.lmax - m] = {sg * acc.re, -sg * acc.im}; }
             sRf[nl * L + m] = (m == 0) ? acc : cplx{2.0 * acc.re, 2.0 * acc.im};
@@ -405,7 +447,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (lp >= 0 && mp <= lp && l >= 1) {
                 auto ctv = [&](int m) -> cplx { return (m >= -l && m <= l) ? ctot[nl * M + P.lmax + m] : cplx{0.0, 0.0}; };
                 auto cgv = [&](int m, int which) -> double {
-                    return (m >= -l && m <= l) ? gCG[((size_t)l * M + (m + P.lmax)) * 6 + which] : 0.0;
+                    return (m >= -l && m <= l) ? sCG[(l * M + (m + P.lmax)) * 6 + which] : 0.0;
                 };
                 auto Tval = [&](int m1) -> cplx {                      // coefficient of Y_{lp, m1}, any sign of m1
                     const double is2 = 0.70710678118654752440;
@@ -429,130 +471,261 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
 
     if (P.dbg == 2) return;
-    // ---- pass 2: dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
+    // ---- pass 2 (stress variant below): dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
     //      lanes e < 3 d then combine into the row's outputs.
     const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1];
     if (r0 == r1) return;                         // no rows at all: the emptied table of an overflowed capped build (nbr.hip)
     const int rself = P.self_row[ic];
     const int ne = P.d * 3;
-    int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
-    if (lane < NL) t_nl = lane;
-    else if (lane < 4 * NL) { t_nl = (lane - NL) / 3; t_k = (lane - NL) % 3; }
-    const bool has_task = lane < 4 * NL;
-    const int t_l = t_nl % L;
-    // R lane: Y_l . Rf (l + 1 terms).  S lane: Y_{l-1} . Tf (l terms, m' <= l - 1) then Y_{l+1} . Tf (l + 2 terms); the
-    // compact Tf block of (n, l, k) holds them back to back
-    const cplx *t_c1 = sRf + t_nl * L, *t_c2 = sRf;
-    int t_y1 = t_l * (t_l + 1) / 2, t_y2 = 0, t_n1 = t_l + 1, t_n2 = 0, t_dst = t_nl;
-    if (t_k >= 0) {
-        t_c1 = sTf + so3_tf_base(t_nl / L, t_l, L) + t_k * (2 * t_l + 2);
-        t_c2 = t_c1 + t_l;
-        t_y1 = t_l >= 2 ? (t_l - 1) * t_l / 2 : 0; t_y2 = (t_l + 1) * (t_l + 2) / 2;
-        t_n1 = t_l; t_n2 = t_l >= 1 ? t_l + 2 : 0;
-        t_dst = 16 + t_nl * 3 + t_k;
-    }
-    int e_k[2], iA1[2], iA2[2];
-#pragma unroll
-    for (int rnd = 0; rnd < 2; rnd++) {
-        const int e = lane + 64 * rnd;
-        int n1 = 0, n2 = 0, l = 0;
-        if (e < ne) decode(e / 3, n1, n2, l);
-        e_k[rnd] = e % 3; iA1[rnd] = n1 * L + l; iA2[rnd] = n2 * L + l;
-    }
-    double self0 = 0.0, self1 = 0.0;
-    const bool stress = P.rdxdr != nullptr;
-    double *sII = smem + lay.oII;
-    double Ri[3] = {0.0, 0.0, 0.0};
-    if (stress) {
-        Ri[0] = P.positions[3 * (size_t)ic]; Ri[1] = P.positions[3 * (size_t)ic + 1]; Ri[2] = P.positions[3 * (size_t)ic + 2];
-        for (int e = tid; e < 96 * 4; e += 256) sII[e] = 0.0;
-        __syncthreads();
-    }
-    const double ivol = stress ? P.inv_vol[ic] : 0.0;
-    for (int c0 = p0; c0 < p1; c0 += SO3_PC) {
-        const int npc = min(SO3_PC, p1 - c0), c1 = c0 + npc;
-        if (nchunks > 1) build_records(c0, npc);        // a single chunk is still resident from pass 1
-        for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
-            const bool is_self = row == rself;
-            if (is_self && !stress) continue;
-            const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
-            const int a = max(q0, c0), b = min(q1, c1);
-            if (a >= b) continue;
-            double s[2] = {0.0, 0.0};
-            double rs[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // sum over pairs of R_j[a] * dP[c, k]
-            for (int p = a; p < b; p++) {
-                const double *rec = recs + (p - c0) * REC;
+    if constexpr (!STRESS) {
+        // ---- pass 2 without stress rows: one lane per (pair q of the chunk, l).  The lane forms R_nl and S_nlk of its
+        // pair for every n from the pair's Y values and the per-centre tables (coefficient reads are broadcasts: all
+        // lanes with the same l read the same address), combines them into the nmax (nmax + 1) / 2 x 3 dP entries of
+        // that l, and the entries are summed over the pairs of a seq row (periodic images of one neighbour) in pair
+        // order in an LDS row buffer that takes the place of the dead pair records.  The buffer is the chunk's slab
+        // of dxdr: it is written out flat (coalesced), and its column sums give the (i, i) row (SO3.py:266-270).
+        constexpr int NPI = NM * (NM + 1) / 2;
+        int *sMap = (int *)(recs + PC * REC);                // [PC] row of the pair (centre-local), [PC] index in its row, max
+        double *rowOut = recs;
+        const int spart = tid / ne, scol = tid - spart * ne;  // (i, i) row: column sums in two interleaved halves
+        double selfacc = 0.0;
+        for (int c0 = p0; c0 < p1; c0 += PC) {
+            const int npc = min(PC, p1 - c0), c1 = c0 + npc;
+            if (nchunks > 1) build_records(c0, npc);          // a single chunk is still resident from pass 1
+            if (tid == 0) sMap[2 * PC] = 0;
+            __syncthreads();
+            for (int row = r0 + tid; row < r1; row += 256) {
+                const int a = max(P.row_pair0[row], c0), b = min(P.row_pair0[row + 1], c1);
+                for (int p = a; p < b; p++) { sMap[p - c0] = row - r0; sMap[PC + p - c0] = p - a; }
+                if (b > a) atomicMax(&sMap[2 * PC], b - a);
+            }
+            // lanes ordered by l, then pair: a wavefront sees one or two values of l, so its coefficient reads are
+            // (nearly) uniform and it skips the terms none of its lanes has (lw = the largest l in this wavefront)
+            const int l = tid / npc, q = tid - l * npc;
+            const bool active = l < L;
+            const int lw = __builtin_amdgcn_readfirstlane(min(L - 1, (64 * wave + 63) / npc));
+            double outv[NPI * 3];
+            if (active) {
+                const double *rec = recs + q * REC;
                 const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
-                if (has_task) {
-                    // one code path for R and S lanes: two fixed-length, predicated segments Re[Y conj(c)]; every LDS
-                    // load of the task is issued before the first add
-                    const cplx *y1 = Y + t_y1, *y2 = Y + t_y2;
-                    double acc = 0.0;
+                double Rn[NM], Sn[NM][3];
+#pragma unroll
+                for (int n = 0; n < NM; n++) { Rn[n] = 0.0; Sn[n][0] = 0.0; Sn[n][1] = 0.0; Sn[n][2] = 0.0; }
+                {
+                    const cplx *yl = Y + l * (l + 1) / 2, *rf = sRf + l * L;
 #pragma unroll
                     for (int m = 0; m < LC; m++)
-                        if (m < t_n1) { const cplx y = y1[m], c = t_c1[m]; acc += y.re * c.re + y.im * c.im; }
+                        if (m <= lw && m <= l) {
+                            const cplx y = yl[m];
+#pragma unroll
+                            for (int n = 0; n < NM; n++)
+                                if (n < P.nmax) { const cplx c = rf[n * L * L + m]; Rn[n] += y.re * c.re + y.im * c.im; }
+                        }
+                }
+                if (l >= 1) {
+                    const cplx *y0 = Y + (l - 1) * l / 2, *y1 = Y + (l + 1) * (l + 2) / 2;
+                    const cplx *tf = sTf + so3_tf_base(0, l, L);
+                    const int nstep = (L * L + L) * 3, kstep = 2 * l + 2;
+#pragma unroll
+                    for (int m = 0; m < LC - 1; m++)
+                        if (m < lw && m < l) {
+                            const cplx y = y0[m];
+#pragma unroll
+                            for (int n = 0; n < NM; n++)
+                                if (n < P.nmax)
+#pragma unroll
+                                    for (int k = 0; k < 3; k++) {
+                                        const cplx c = tf[n * nstep + k * kstep + m];
+                                        Sn[n][k] += y.re * c.re + y.im * c.im;
+                                    }
+                        }
 #pragma unroll
                     for (int m = 0; m < LC + 1; m++)
-                        if (m < t_n2) { const cplx y = y2[m], c = t_c2[m]; acc += y.re * c.re + y.im * c.im; }
-                    sR[t_dst] = t_k < 0 ? acc : acc * rec[3];
-                }
-                so3_wave_lds_sync();
+                        if (m < lw + 2 && m < l + 2) {
+                            const cplx y = y1[m];
 #pragma unroll
-                for (int rnd = 0; rnd < 2; rnd++) {
-                    if (lane + 64 * rnd < ne) {
-                        const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
-                        const double *A = rec + 8, *B = rec + 8 + SO3_NLP;
-                        const double term = rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
-                        s[rnd] += term;
-                        if (stress) {                       // R_j = R_i + r u (SO3.py:225-226, 254)
-                            const double rr = rec[4];
-                            rs[rnd][0] += (Ri[0] + rr * rec[0]) * term;
-                            rs[rnd][1] += (Ri[1] + rr * rec[1]) * term;
-                            rs[rnd][2] += (Ri[2] + rr * rec[2]) * term;
+                            for (int n = 0; n < NM; n++)
+                                if (n < P.nmax)
+#pragma unroll
+                                    for (int k = 0; k < 3; k++) {
+                                        const cplx c = tf[n * nstep + k * kstep + l + m];
+                                        Sn[n][k] += y.re * c.re + y.im * c.im;
+                                    }
                         }
-                    }
                 }
-                so3_wave_lds_sync();
+                const double inv_r = rec[3], u[3] = {rec[0], rec[1], rec[2]};
+                double An[NM], Bn[NM];
+#pragma unroll
+                for (int n = 0; n < NM; n++) {
+                    An[n] = n < P.nmax ? rec[8 + n * L + l] : 0.0;
+                    Bn[n] = n < P.nmax ? rec[8 + SO3_NLP + n * L + l] * inv_r : 0.0;
+                }
+#pragma unroll
+                for (int n1 = 0; n1 < NM; n1++)
+#pragma unroll
+                    for (int n2 = 0; n2 <= n1; n2++) {
+                        const double ar = An[n1] * Rn[n2] + An[n2] * Rn[n1];
+#pragma unroll
+                        for (int k = 0; k < 3; k++)
+                            outv[(n1 * (n1 + 1) / 2 + n2) * 3 + k] = u[k] * ar + Bn[n1] * Sn[n2][k] + Bn[n2] * Sn[n1][k];
+                    }
             }
+            __syncthreads();                                  // records read, pair -> row map complete
+            if (P.dbg == 3) { if (active && outv[0] == 1.234567e300) P.x[0] = 0.0; return; }   // ablation: keep outv alive
+            const int myrow = active ? sMap[q] : 0, myj = active ? sMap[PC + q] : -1;
+            const int rowb = sMap[0], nrows_c = sMap[npc - 1] - rowb + 1, maxj = sMap[2 * PC];
+            const bool cont = P.row_pair0[r0 + rowb] < c0;    // the chunk's first row began in the previous chunk
+            __syncthreads();                                  // map read: the row buffer may take its place
+            const bool mine = active && r0 + myrow != rself;  // periodic images of the centre itself cancel (SO3.py:266-273)
+            double *dst = rowOut + (myrow - rowb) * ne + l * 3;
+            for (int j = 0; j < maxj; j++) {
+                if (mine && myj == j) {
 #pragma unroll
-            for (int rnd = 0; rnd < 2; rnd++)
-                if (lane + 64 * rnd < ne) {
-                    const int e = lane + 64 * rnd;
-                    if (is_self) {      // periodic images of the centre itself: only the stress rows use them (SO3.py:264, 272-273)
-                        sII[e] += s[rnd];
-                        sII[96 + e] += rs[rnd][0]; sII[192 + e] += rs[rnd][1]; sII[288 + e] += rs[rnd][2];
-                        continue;
+                    for (int pi = 0; pi < NPI; pi++)
+                        if (pi < P.d / L)
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                double *o = dst + pi * L * 3 + k;
+                                *o = j == 0 ? outv[pi * 3 + k] : *o + outv[pi * 3 + k];
+                            }
+                }
+                __syncthreads();
+            }
+            if (P.dbg == 4) return;
+            for (int f = tid; f < nrows_c * ne; f += 256) {
+                const int rl = f / ne, row = r0 + rowb + rl;
+                if (row == rself) continue;
+                double *o = P.dxdr + (size_t)(r0 + rowb) * ne + f;
+                *o = (cont && rl == 0) ? *o + rowOut[f] : rowOut[f];
+            }
+            if (spart < 2)
+                for (int rl = spart; rl < nrows_c; rl += 2)
+                    if (r0 + rowb + rl != rself) selfacc += rowOut[rl * ne + scol];
+            __syncthreads();                                  // row buffer consumed (the next chunk rebuilds the records)
+        }
+        if (spart < 2) sSelf[spart * 96 + scol] = selfacc;
+        __syncthreads();
+        for (int e = tid; e < ne; e += 256) P.dxdr[(size_t)rself * ne + e] = -(sSelf[e] + sSelf[96 + e]);
+    } else {
+        int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
+        if (lane < NL) t_nl = lane;
+        else if (lane < 4 * NL) { t_nl = (lane - NL) / 3; t_k = (lane - NL) % 3; }
+        const bool has_task = lane < 4 * NL;
+        const int t_l = t_nl % L;
+        // R lane: Y_l . Rf (l + 1 terms).  S lane: Y_{l-1} . Tf (l terms, m' <= l - 1) then Y_{l+1} . Tf (l + 2 terms); the
+        // compact Tf block of (n, l, k) holds them back to back
+        const cplx *t_c1 = sRf + t_nl * L, *t_c2 = sRf;
+        int t_y1 = t_l * (t_l + 1) / 2, t_y2 = 0, t_n1 = t_l + 1, t_n2 = 0, t_dst = t_nl;
+        if (t_k >= 0) {
+            t_c1 = sTf + so3_tf_base(t_nl / L, t_l, L) + t_k * (2 * t_l + 2);
+            t_c2 = t_c1 + t_l;
+            t_y1 = t_l >= 2 ? (t_l - 1) * t_l / 2 : 0; t_y2 = (t_l + 1) * (t_l + 2) / 2;
+            t_n1 = t_l; t_n2 = t_l >= 1 ? t_l + 2 : 0;
+            t_dst = 16 + t_nl * 3 + t_k;
+        }
+        int e_k[2], iA1[2], iA2[2];
+    #pragma unroll
+        for (int rnd = 0; rnd < 2; rnd++) {
+            const int e = lane + 64 * rnd;
+            int n1 = 0, n2 = 0, l = 0;
+            if (e < ne) decode(e / 3, n1, n2, l);
+            e_k[rnd] = e % 3; iA1[rnd] = n1 * L + l; iA2[rnd] = n2 * L + l;
+        }
+        double self0 = 0.0, self1 = 0.0;
+        constexpr bool stress = true;
+        double *sII = smem + lay.oII;
+        double Ri[3] = {0.0, 0.0, 0.0};
+        if (stress) {
+            Ri[0] = P.positions[3 * (size_t)ic]; Ri[1] = P.positions[3 * (size_t)ic + 1]; Ri[2] = P.positions[3 * (size_t)ic + 2];
+            for (int e = tid; e < 96 * 4; e += 256) sII[e] = 0.0;
+            __syncthreads();
+        }
+        const double ivol = stress ? P.inv_vol[ic] : 0.0;
+        for (int c0 = p0; c0 < p1; c0 += PC) {
+            const int npc = min(PC, p1 - c0), c1 = c0 + npc;
+            if (nchunks > 1) build_records(c0, npc);        // a single chunk is still resident from pass 1
+            for (int row = r0 + wave; row < r1; row += SO3_WAVES) {
+                const bool is_self = row == rself;
+                if (is_self && !stress) continue;
+                const int q0 = P.row_pair0[row], q1 = P.row_pair0[row + 1];
+                const int a = max(q0, c0), b = min(q1, c1);
+                if (a >= b) continue;
+                double s[2] = {0.0, 0.0};
+                double rs[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // sum over pairs of R_j[a] * dP[c, k]
+                for (int p = a; p < b; p++) {
+                    const double *rec = recs + (p - c0) * REC;
+                    const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
+                    if (has_task) {
+                        // one code path for R and S lanes: two fixed-length, predicated segments Re[Y conj(c)]; every LDS
+                        // load of the task is issued before the first add
+                        const cplx *y1 = Y + t_y1, *y2 = Y + t_y2;
+                        double acc = 0.0;
+    #pragma unroll
+                        for (int m = 0; m < LC; m++)
+                            if (m < t_n1) { const cplx y = y1[m], c = t_c1[m]; acc += y.re * c.re + y.im * c.im; }
+    #pragma unroll
+                        for (int m = 0; m < LC + 1; m++)
+                            if (m < t_n2) { const cplx y = y2[m], c = t_c2[m]; acc += y.re * c.re + y.im * c.im; }
+                        sR[t_dst] = t_k < 0 ? acc : acc * rec[3];
                     }
-                    double *o = P.dxdr + (size_t)row * ne + e;
-                    // a row whose pairs straddle a chunk boundary: this lane wrote the earlier part itself
-                    *o = (q0 < c0) ? *o + s[rnd] : s[rnd];
-                    if (stress) {
-                        double *so = P.rdxdr + (size_t)row * ne * 3 + (e / 3) * 9 + (e % 3);
-#pragma unroll
-                        for (int a3 = 0; a3 < 3; a3++) {
-                            const double v = rs[rnd][a3] * ivol;        // rdxdr = -pstress / vol, pstress = -sum R_j (x) dP
-                            so[3 * a3] = (q0 < c0) ? so[3 * a3] + v : v;
+                    so3_wave_lds_sync();
+    #pragma unroll
+                    for (int rnd = 0; rnd < 2; rnd++) {
+                        if (lane + 64 * rnd < ne) {
+                            const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
+                            const double *A = rec + 8, *B = rec + 8 + SO3_NLP;
+                            const double term = rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
+                            s[rnd] += term;
+                            if (stress) {                       // R_j = R_i + r u (SO3.py:225-226, 254)
+                                const double rr = rec[4];
+                                rs[rnd][0] += (Ri[0] + rr * rec[0]) * term;
+                                rs[rnd][1] += (Ri[1] + rr * rec[1]) * term;
+                                rs[rnd][2] += (Ri[2] + rr * rec[2]) * term;
+                            }
                         }
                     }
+                    so3_wave_lds_sync();
                 }
-            if (!is_self) { self0 += s[0]; self1 += s[1]; }
+    #pragma unroll
+                for (int rnd = 0; rnd < 2; rnd++)
+                    if (lane + 64 * rnd < ne) {
+                        const int e = lane + 64 * rnd;
+                        if (is_self) {      // periodic images of the centre itself: only the stress rows use them (SO3.py:264, 272-273)
+                            sII[e] += s[rnd];
+                            sII[96 + e] += rs[rnd][0]; sII[192 + e] += rs[rnd][1]; sII[288 + e] += rs[rnd][2];
+                            continue;
+                        }
+                        double *o = P.dxdr + (size_t)row * ne + e;
+                        // a row whose pairs straddle a chunk boundary: this lane wrote the earlier part itself
+                        *o = (q0 < c0) ? *o + s[rnd] : s[rnd];
+                        if (stress) {
+                            double *so = P.rdxdr + (size_t)row * ne * 3 + (e / 3) * 9 + (e % 3);
+    #pragma unroll
+                            for (int a3 = 0; a3 < 3; a3++) {
+                                const double v = rs[rnd][a3] * ivol;        // rdxdr = -pstress / vol, pstress = -sum R_j (x) dP
+                                so[3 * a3] = (q0 < c0) ? so[3 * a3] + v : v;
+                            }
+                        }
+                    }
+                if (!is_self) { self0 += s[0]; self1 += s[1]; }
+            }
+            if (nchunks > 1) __syncthreads();
         }
-        if (nchunks > 1) __syncthreads();
-    }
-    __syncthreads();                                   // every wavefront is done with the records: their area takes the self sums
-    sSelf[wave * 96 + lane] = self0;
-    if (lane < 32) sSelf[wave * 96 + 64 + lane] = self1;
-    __syncthreads();
-    for (int e = tid; e < ne; e += 256) {
-        double s = 0.0;
-        for (int w2 = 0; w2 < SO3_WAVES; w2++) s += sSelf[w2 * 96 + e];
-        P.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
-        if (stress) {
-            // pstress(i, i) = -sum_{images of i} R_j (x) dP + R_i (x) sum_{all pairs} dP  (SO3.py:264, 272-273)
-            const double tot = s + sII[e];
-            double *so = P.rdxdr + (size_t)rself * ne * 3 + (e / 3) * 9 + (e % 3);
-#pragma unroll
-            for (int a3 = 0; a3 < 3; a3++) so[3 * a3] = (sII[96 * (a3 + 1) + e] - Ri[a3] * tot) * ivol;
+        __syncthreads();                                   // every wavefront is done with the records: their area takes the self sums
+        sSelf[wave * 96 + lane] = self0;
+        if (lane < 32) sSelf[wave * 96 + 64 + lane] = self1;
+        __syncthreads();
+        for (int e = tid; e < ne; e += 256) {
+            double s = 0.0;
+            for (int w2 = 0; w2 < SO3_WAVES; w2++) s += sSelf[w2 * 96 + e];
+            P.dxdr[(size_t)rself * ne + e] = -s;             // SO3.py:266-270
+            if (stress) {
+                // pstress(i, i) = -sum_{images of i} R_j (x) dP + R_i (x) sum_{all pairs} dP  (SO3.py:264, 272-273)
+                const double tot = s + sII[e];
+                double *so = P.rdxdr + (size_t)rself * ne * 3 + (e / 3) * 9 + (e % 3);
+    #pragma unroll
+                for (int a3 = 0; a3 < 3; a3++) so[3 * a3] = (sII[96 * (a3 + 1) + e] - Ri[a3] * tot) * ivol;
+            }
         }
     }
 }
@@ -664,13 +837,21 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     }
     static bool attr_set = false;
     if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
-    if (lmax + 1 <= 5) hipLaunchKernelGGL(so3_centre_kernel<5>, dim3(ncentres), dim3(256), lds_bytes, st, A);
-    else hipLaunchKernelGGL(so3_centre_kernel<SO3_LCAP>, dim3(ncentres), dim3(256), lds_bytes, st, A);
+    const bool small_l = lmax + 1 <= 5 && nmax <= 3;
+    if (rdxdr) {
+        if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+        else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+    } else {
+        if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+        else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+    }
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("so3_centre_kernel launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
