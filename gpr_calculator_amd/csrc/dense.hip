@@ -483,6 +483,136 @@ __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const doub
     }
 }
 
+// Weight-space prediction tail in one kernel, factored variance form: for the rows of P (feature rows psi of the
+// predicted quantities) mean = P w and var = max(diag - vsq (|p|^2 - |p C^-T|^2), 0) with C^-1 lower triangular
+// (G = C C^T).  The product Q = P C^-T is never stored: a workgroup owns WT_R rows, walks the column blocks of Q
+// (the k range of a block ends at its diagonal block), keeps the squares of its Q entries in registers and reduces
+// them per row in a fixed order; P w and |p|^2 are gathered from the A tiles of the last column block, whose k range
+// is the whole row.  FP64 MFMA 16x16x4, tiles two steps ahead in registers, every workgroup does the same work.
+#ifndef WT_ROWS
+#define WT_ROWS 32
+#endif
+constexpr int WT_C = 128, WT_K = 32, WT_LD = WT_K + 2;   // row stride 34: operand reads of a half-wave hit 32 distinct bank pairs
+template <int WT_R> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + 4 * WT_R) * sizeof(double); }
+
+template <int WT_R>
+__global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double *__restrict__ P, long long ldp,
+                                                       const double *__restrict__ Ci, long long ldc,
+                                                       const double *__restrict__ w, const double *__restrict__ diag,
+                                                       double *__restrict__ out, double vsq) {
+    constexpr int RT = WT_R / 16, AI = WT_R / 8;                 // 16-row MFMA tiles, A loads per thread and tile
+    extern __shared__ __attribute__((aligned(16))) double wt_smem[];
+    double *As0 = wt_smem, *As1 = As0 + WT_R * WT_LD, *Bs0 = As1 + WT_R * WT_LD, *Bs1 = Bs0 + WT_C * WT_LD;
+    double *red = Bs1 + WT_C * WT_LD;                            // [4 wavefronts][WT_R]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int bm0 = blockIdx.x * WT_R;
+    const int wj = wave * 32;                                    // this wavefront: all WT_R rows x columns wj .. wj + 31
+    const int lk = tid & 31, lr = tid >> 5;                      // tile loads: k offset, row / column offset (+ 8 i)
+    double sq[RT][4];                                            // sum over columns of Q^2, rows 16 i + (lane >> 4) + 4 r
+    double mean2[AI], norm2[AI];                                 // P w, |p|^2 partials of rows lr + 8 i
+#pragma unroll
+    for (int i = 0; i < RT; i++) { sq[i][0] = 0.0; sq[i][1] = 0.0; sq[i][2] = 0.0; sq[i][3] = 0.0; }
+#pragma unroll
+    for (int i = 0; i < AI; i++) { mean2[i] = 0.0; norm2[i] = 0.0; }
+    const int ncb = (n + WT_C - 1) / WT_C;
+    for (int cb = 0; cb < ncb; cb++) {
+        const int bn0 = cb * WT_C;
+        const int kend = min(n, bn0 + WT_C);                     // C^-1[j][k] = 0 for k > j
+        const bool last = cb == ncb - 1;
+        d4 acc[RT][2];                                           // independent accumulation chains
+#pragma unroll
+        for (int i = 0; i < RT; i++) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+        // two tiles ahead: the loads issued in step kt are stored at the end of step kt + 1; two register sets, the kt
+        // loop is unrolled by two
+        double ra0[AI], rb0[16], ra1[AI], rb1[16], wv0 = 0.0, wv1 = 0.0;
+        auto load_tile = [&](int k0, double *ra, double *rb, double &wv) {
+            const int gk = k0 + lk;
+            if (last) wv = gk < n ? w[gk] : 0.0;
+#pragma unroll
+            for (int i = 0; i < AI; i++) {
+                const int gm = bm0 + lr + 8 * i;
+                ra[i] = (gm < m && gk < kend) ? P[(long long)gm * ldp + gk] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const int gn = bn0 + lr + 8 * i;
+                rb[i] = (gn < n && gk < kend) ? Ci[(long long)gn * ldc + gk] : 0.0;
+            }
+        };
+        auto store_tile = [&](double *As, double *Bs, const double *ra, const double *rb, double wv) {
+#pragma unroll
+            for (int i = 0; i < AI; i++) As[(lr + 8 * i) * WT_LD + lk] = ra[i];
+#pragma unroll
+            for (int i = 0; i < 16; i++) Bs[(lr + 8 * i) * WT_LD + lk] = rb[i];
+            if (last) {
+#pragma unroll
+                for (int i = 0; i < AI; i++) { mean2[i] += ra[i] * wv; norm2[i] += ra[i] * ra[i]; }
+            }
+        };
+        auto mma_tile = [&](const double *As, const double *Bs) {
+#pragma unroll
+            for (int ks = 0; ks < WT_K / 4; ks++) {
+                const int kr = ks * 4 + (lane >> 4);
+                const double b0 = Bs[(wj + (lane & 15)) * WT_LD + kr], b1 = Bs[(wj + 16 + (lane & 15)) * WT_LD + kr];
+#pragma unroll
+                for (int i = 0; i < RT; i++) {
+                    const double a = As[(16 * i + (lane & 15)) * WT_LD + kr];
+                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[i][1], 0, 0, 0);
+                }
+            }
+        };
+        const int nkt = (kend + WT_K - 1) / WT_K;
+        load_tile(0, ra0, rb0, wv0);
+        if (nkt > 1) load_tile(WT_K, ra1, rb1, wv1);
+        store_tile(As0, Bs0, ra0, rb0, wv0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt += 2) {
+            // even step: LDS buffer 0 holds tile kt, set 1 holds tile kt + 1, set 0 is free for tile kt + 2
+            if (kt + 2 < nkt) load_tile((kt + 2) * WT_K, ra0, rb0, wv0);
+            mma_tile(As0, Bs0);
+            if (kt + 1 < nkt) store_tile(As1, Bs1, ra1, rb1, wv1);
+            __syncthreads();
+            if (kt + 1 >= nkt) break;
+            // odd step: buffer 1 holds tile kt + 1, set 0 holds tile kt + 2, set 1 is free for tile kt + 3
+            if (kt + 3 < nkt) load_tile((kt + 3) * WT_K, ra1, rb1, wv1);
+            mma_tile(As1, Bs1);
+            if (kt + 2 < nkt) store_tile(As0, Bs0, ra0, rb0, wv0);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sq[i][r] += acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r];
+    }
+    // rows of sq: 16 lanes (columns) share a row -> butterfly inside the 16-lane group; the four wavefronts hold
+    // different columns of the same rows and are added in wavefront order
+#pragma unroll
+    for (int i = 0; i < RT; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            for (int o = 8; o > 0; o >>= 1) sq[i][r] += __shfl_xor(sq[i][r], o, 64);
+#pragma unroll
+    for (int i = 0; i < AI; i++)
+        for (int o = 16; o > 0; o >>= 1) { mean2[i] += __shfl_xor(mean2[i], o, 64); norm2[i] += __shfl_xor(norm2[i], o, 64); }
+    if ((lane & 15) == 0)
+#pragma unroll
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave * WT_R + 16 * i + (lane >> 4) + 4 * r] = sq[i][r];
+    __syncthreads();
+    if (lk == 0)
+#pragma unroll
+        for (int i = 0; i < AI; i++) {
+            const int rl = lr + 8 * i, row = bm0 + rl;
+            if (row < m) {
+                out[row] = mean2[i];
+                const double q2 = ((red[rl] + red[WT_R + rl]) + red[2 * WT_R + rl]) + red[3 * WT_R + rl];
+                out[m + row] = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0);
+            }
+        }
+}
+
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
 __global__ void gemv_t_partial_kernel(int n, int ncols, const double *a, long long lda, const double *x, double *part,
                                       int rows_per) {
@@ -791,6 +921,25 @@ extern "C" int gpr_ws_finish(void *stream, int m, int n, const double *P, long l
     GPR_REQUIRE(out && P && w && ldp >= n && (!Q || (diag && ldq >= n)), "gpr_ws_finish: bad arguments");
     hipLaunchKernelGGL(ws_finish_kernel, dim3((m + 3) / 4), dim3(256), 0, (hipStream_t)stream, m, n, P, ldp, Q, ldq, w, diag, out, vsq);
     LAUNCH_CHECK("ws_finish");
+    return GPR_OK;
+}
+
+// out = [mean (m) | var (m)] of the weight-space prediction with the factored variance, one launch, Q never stored
+extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                           const double *w, const double *diag, double *out, double vsq) {
+    if (m <= 0) return GPR_OK;
+    GPR_REQUIRE(n > 0 && out && P && Cinv && w && diag && ldp >= n && ldc >= n && vsq > 0.0, "gpr_ws_tail: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    constexpr int R = WT_ROWS;
+    static bool attr_set = false;
+    if (!attr_set) {
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
+        attr_set = true;
+    }
+    const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
+    hipLaunchKernelGGL(ws_tail_kernel<R>, dim3((m + R - 1) / R), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq);
+    gpr_prof_end(st, pid);
+    LAUNCH_CHECK("ws_tail");
     return GPR_OK;
 }
 

@@ -98,17 +98,17 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         (rc = gpr_dot2_features_direct(stream, d, 3, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr, d_num,
                                        ns, species_host, (int)extra.size(), extra.data(), sigma, 0.0, d_psi + (size_t)nstruct * F, F,
                                        d_diag ? d_diag + nstruct : nullptr))) return cleanup(rc);
-    // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0)
-    if (want_std) {
-        if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
-        d_q = (double *)p;
-        // factored form when C^-1 is at hand: Q = Psi C^-T touches only the lower triangle of C^-1
-        if (Cinv_dev) rc = gpr_gemm_nt_lower(stream, (int)m, F, 1.0, d_psi, F, Cinv_dev, F, d_q, F);
-        else rc = gpr_gemm(stream, 0, 0, (int)m, F, F, 1.0, d_psi, F, M_dev, F, 0.0, d_q, F);
-        if (rc) return cleanup(rc);
+    // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0); with C^-1 at hand the factored form in one launch
+    if (want_std && Cinv_dev) {
+        if ((rc = gpr_ws_tail(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma))) return cleanup(rc);
+    } else {
+        if (want_std) {
+            if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
+            d_q = (double *)p;
+            if ((rc = gpr_gemm(stream, 0, 0, (int)m, F, F, 1.0, d_psi, F, M_dev, F, 0.0, d_q, F))) return cleanup(rc);
+        }
+        if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev, 0.0))) return cleanup(rc);
     }
-    if ((rc = gpr_ws_finish(stream, (int)m, F, d_psi, F, d_q, F, w_dev, d_diag, out_dev,
-                            (want_std && Cinv_dev) ? sigma * sigma : 0.0))) return cleanup(rc);
     if ((rc = gpr_nbr_info_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
     return cleanup(GPR_OK);
 }

@@ -318,6 +318,11 @@ int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, co
 /* (vsq > 0 selects the factored form of the same variance: Q = P C^-T with I + Psi'^T D^-1 Psi' = C C^T, and
  * out[m+i] = max(diag[i] - vsq (|P[i,:]|^2 - |Q[i,:]|^2), 0), vsq = sigma^2; vsq = 0: the form above)
  * C[m, n] = alpha A[m, n] B^T with B n x n lower triangular (zero blocks of B^T are skipped) */
+/* The same tail with the product fused in: out = [P w | max(diag - vsq (|p|^2 - |p C^-T|^2), 0)] from P[m, n], the lower
+ * triangular C^-1[n, n], w[n], diag[m]; Q = P C^-T is formed tile by tile on the matrix cores and only its row sums of
+ * squares are kept (no m x n intermediate). */
+int gpr_ws_tail(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                const double *w, const double *diag, double *out, double vsq);
 int gpr_gemm_nt_lower(void *stream, int m, int n, double alpha, const double *a, long long lda, const double *b_lower,
                       long long ldb, double *c, long long ldc);
 /* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
