@@ -201,9 +201,11 @@ def main():
                    "1.10 kflop per same-species row pair"),
             "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
                      "N^2 m (triangular-solve form of the variance)"),
-            "gemm": (("gemm128_kernel via gpr_gemm_nt_lower: Q = Psi* C^-T, the weight-space predictive variance "
-                      "|psi|^2 - |C^-1 psi|^2 (C^-1 lower triangular: half of the m x F x F product)",
-                      float(m_rows) * F * (F + 1), "m F (F + 1) for the m = %d predicted rows and F = %d features" % (m_rows, F))
+            "gemm": (("ws_tail_kernel (gpr_ws_tail): mean = Psi* w and the weight-space variance |psi|^2 - |C^-1 psi|^2 from "
+                      "FP64 MFMA tiles of Psi* C^-T (C^-1 lower triangular: half of the m x F x F product; the product "
+                      "itself is never stored)",
+                      float(m_rows) * F * (F + 1) + 4.0 * m_rows * F,
+                      "m F (F + 1) + 4 m F for the m = %d predicted rows and F = %d features" % (m_rows, F))
                      if ws_native else
                      ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
                       2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N")),
