@@ -128,8 +128,8 @@ def _cpu_job(job):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--kernel", default="Dot", choices=["Dot", "RBF"])
     ap.add_argument("--n-train", type=int, default=N_TRAIN)
     ap.add_argument("--batch", type=int, default=BATCH)

@@ -429,10 +429,22 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
 }
 
 // HIP events around one launch (or launch sequence) on its stream; no-ops unless profiling is enabled
+// Events come from a pool that is only ever grown: creating a pair per launch put ~10 us of host time into every
+// profiled step.
+static thread_local std::vector<hipEvent_t> g_event_pool;
+static thread_local size_t g_event_next = 0;
+static hipEvent_t prof_event() {
+    if (g_event_next == g_event_pool.size()) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) return nullptr;
+        g_event_pool.push_back(e);
+    }
+    return g_event_pool[g_event_next++];
+}
 int gpr_prof_begin(hipStream_t st, int kind) {
     if (!g_prof_on) return -1;
-    prof_rec r{kind, nullptr, nullptr};
-    if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return -1;
+    prof_rec r{kind, prof_event(), prof_event()};
+    if (!r.start || !r.stop) return -1;
     (void)hipEventRecord(r.start, st);
     g_prof.push_back(r);
     return (int)g_prof.size() - 1;
@@ -443,8 +455,16 @@ void gpr_prof_end(hipStream_t st, int id) {
 
 extern "C" int gpr_profile_enable(int on) {
     g_prof_on = on != 0;
-    for (auto &r : g_prof) { (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop); }
     g_prof.clear();
+    g_event_next = 0;
+    if (on && g_event_pool.size() < 4096) {          // enough for a long timed region without a create inside it
+        g_event_pool.reserve(4096);
+        while (g_event_pool.size() < 4096) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            g_event_pool.push_back(e);
+        }
+    }
     return GPR_OK;
 }
 
@@ -457,8 +477,8 @@ extern "C" int gpr_profile_fetch(double *ms_by_mode, int *launches_by_mode) {
         float ms = 0.f;
         GPR_HIP_TRY(hipEventElapsedTime(&ms, r.start, r.stop));
         ms_by_mode[r.mode] += ms; launches_by_mode[r.mode] += 1;
-        (void)hipEventDestroy(r.start); (void)hipEventDestroy(r.stop);
     }
     g_prof.clear();
+    g_event_next = 0;
     return GPR_OK;
 }

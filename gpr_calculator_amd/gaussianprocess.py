@@ -814,7 +814,8 @@ class GP():
         atom0, numbers, pos, cells, pbc = batch_arrays(mine_strucs)
         natoms = int(atom0[-1])
         mask, frees = None, []
-        for k, s in enumerate(mine_strucs):
+        any_fixed = any(has_fixed_atoms(s) for s in mine_strucs)
+        for k, s in enumerate(mine_strucs if any_fixed else ()):
             fix = self._get_fixed_atoms(s) if has_fixed_atoms(s) else ()
             if len(fix):
                 if mask is None:
@@ -824,6 +825,8 @@ class GP():
                 frees.append([i for i in range(int(atom0[k + 1] - atom0[k])) if i not in fixset])
             else:
                 frees.append(None)
+        if not any_fixed:
+            frees = [None] * len(mine_strucs)
         nfree = natoms if mask is None else int(mask.sum())
         m = len(mine_strucs) + 3 * nfree
         table, nseg, ncheb = des._device_tables()[:3]
@@ -887,6 +890,10 @@ class GP():
                 n = ns_atoms[0]
                 Eb = mean[:nS] * n
                 Fb = mean[nS:].reshape(nS, n, 3)
+                if size == 1:                    # one rank owns the whole batch: the slices are the answer
+                    if return_std:
+                        return list(Eb), list(Fb), list(std[:nS]), list(std[nS:].reshape(nS, n, 3))
+                    return list(Eb), list(Fb), [None] * nS, [None] * nS
                 if return_std:
                     Sb = std[nS:].reshape(nS, n, 3)
                     for s, k in enumerate(mine):
