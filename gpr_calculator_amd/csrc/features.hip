@@ -181,9 +181,8 @@ __global__ void __launch_bounds__(THREADS) dot2_features_direct_kernel(dfeat_arg
 
 // prior variance of energy points, numpy-helper convention (Dot_mb.py:177-202): rows of one point against each
 // other, same species only, cosine = x.x' / (1e-8 + (|x| + 1e-8)(|x'| + 1e-8)), mean of sigma^2 (cos^2 + sigma0^2)
-__global__ void __launch_bounds__(256) dot2_diag_ee_direct_kernel(dfeat_args A) {
-    __shared__ double sRed[4];
-    const int p = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void dot2_diag_ee_body(const dfeat_args &A, int p, double *sRed) {
+    const int tid = threadIdx.x;
     const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1], n = r1 - r0;
     double part = 0.0;
     for (long long t = tid; t < (long long)n * n; t += blockDim.x) {
@@ -204,6 +203,11 @@ __global__ void __launch_bounds__(256) dot2_diag_ee_direct_kernel(dfeat_args A) 
         const double tot = sRed[0] + sRed[1] + sRed[2] + sRed[3];
         A.diag[p] = n > 0 ? A.sigma2 * tot / ((double)n * (double)n) : 0.0;
     }
+}
+
+__global__ void __launch_bounds__(256) dot2_diag_ee_direct_kernel(dfeat_args A) {
+    __shared__ double sRed[4];
+    dot2_diag_ee_body(A, blockIdx.x, sRed);
 }
 
 
@@ -239,10 +243,9 @@ __device__ __forceinline__ void fm_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_args A) {
-    __shared__ double smem[4][32 * FM_LD];                     // per wavefront: operands of one step / transpose buffer
+__device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &A, int blk, double (*smem)[32 * FM_LD]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + wave;
+    const int p = blk * 4 + wave;
     if (p >= A.npts) return;                                    // wavefront-uniform; no block barriers below
     double *sm = smem[wave];
     double *opA = sm, *opB = sm + 4 * FM_LD;                    // opA[row][k], opB[q][row][k]
@@ -394,6 +397,97 @@ __global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_arg
     }
 }
 
+__global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_args A) {
+    __shared__ double smem[4][32 * FM_LD];                     // per wavefront: operands of one step / transpose buffer
+    dot2_force_features_mfma_body(A, blockIdx.x, smem);
+}
+
+// energy-point feature rows with 256 threads (thread t owns monomials t, t + 256, t + 512): the block role of the
+// fused launch below; same arithmetic as dot2_features_direct_kernel, 16 rows staged per pass
+template <int NS>
+__device__ __forceinline__ void dot2_features_direct256_body(const dfeat_args &A, int p, double *sA, int *sE) {
+    constexpr int ROWS = 16, MPT = 3;
+    const int tid = threadIdx.x;
+    int kk[MPT], mm[MPT];
+    double wgt[MPT];
+    bool act[MPT];
+#pragma unroll
+    for (int u = 0; u < MPT; u++) {
+        const int e = tid + 256 * u;
+        act[u] = e < A.npair;
+        int k = 0;
+        if (act[u]) { k = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5); while ((k + 1) * (k + 2) / 2 <= e) k++; while (k * (k + 1) / 2 > e) k--; }
+        kk[u] = k; mm[u] = act[u] ? e - k * (k + 1) / 2 : 0;
+        wgt[u] = (kk[u] == mm[u]) ? 1.0 : 1.4142135623730951;
+    }
+    double acc[NS][MPT], cnt[NS];
+#pragma unroll
+    for (int s = 0; s < NS; s++) { cnt[s] = 0.0; for (int u = 0; u < MPT; u++) acc[s][u] = 0.0; }
+    const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
+    const int slot = tid >> 4, g = tid & 15;          // staging: 16 lanes per row, 16 rows per pass
+    for (int rb = r0; rb < r1; rb += ROWS) {
+        __syncthreads();
+        {
+            const int r = rb + slot;
+            const bool have = r < r1;
+            const int xs = have ? (A.x_index ? A.x_index[r] : r) : -1;
+            const bool ok = have && xs >= 0;
+            double x0 = 0.0, x1 = 0.0;
+            if (ok) {
+                const double *xr = A.x + (size_t)xs * A.d;
+                if (g < A.d) x0 = xr[g];
+                if (g + 16 < A.d) x1 = xr[g + 16];
+            }
+            double ss = x0 * x0 + x1 * x1;
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 16);
+            const double n = sqrt(ss);
+            const bool live = ok && n > 1e-8;          // dot_kernel.cpp:28-44 skip
+            const double inv = live ? 1.0 / n : 0.0;
+            sA[slot * DF_LD + g] = x0 * inv;
+            sA[slot * DF_LD + g + 16] = x1 * inv;
+            if (g == 0) sE[slot] = live ? A.ele[xs] : INT_MIN;
+        }
+        __syncthreads();
+        const int nr = min(ROWS, r1 - rb);
+        for (int r = 0; r < nr; r++) {
+            const int el = sE[r];
+            if (el == INT_MIN) continue;
+#pragma unroll
+            for (int s = 0; s < NS; s++)
+                if (el == A.species[s]) {
+                    cnt[s] += 1.0;
+#pragma unroll
+                    for (int u = 0; u < MPT; u++)
+                        if (act[u]) acc[s][u] += wgt[u] * sA[r * DF_LD + kk[u]] * sA[r * DF_LD + mm[u]];
+                }
+        }
+    }
+    const int npt_rows = r1 - r0;
+    const double inv_cnt = npt_rows > 0 ? 1.0 / npt_rows : 0.0;
+    double *o = A.out + (long long)p * A.ld;
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+#pragma unroll
+        for (int u = 0; u < MPT; u++)
+            if (act[u]) o[s * A.npair + tid + 256 * u] = inv_cnt * acc[s][u];
+        if (tid == 0) o[A.ns * A.npair + s] = A.sigma0 * cnt[s] * inv_cnt;
+    }
+}
+
+// One launch for all feature rows of a prediction batch: blocks [0, nblkF) take four force points each (matrix
+// cores), the next AE.npts blocks one energy point each, the last AE.npts blocks the prior variance of one energy
+// point.  The three roles have nothing in common but their inputs; side by side they fill the chip where three
+// launches in a row each left most of it idle (64 energy points = 64 workgroups).
+template <int NS>
+__global__ void __launch_bounds__(256) dot2_features_ef_kernel(dfeat_args AF, dfeat_args AE, int nblkF) {
+    __shared__ double smem[4][32 * FM_LD];
+    const int b = blockIdx.x;
+    if (b < nblkF) dot2_force_features_mfma_body(AF, b, smem);
+    else if (b < nblkF + AE.npts) dot2_features_direct256_body<NS>(AE, b - nblkF, &smem[0][0], (int *)&smem[1][0]);
+    else dot2_diag_ee_body(AE, b - nblkF - AE.npts, &smem[0][0]);
+}
+
 }  // namespace
 
 // Psi rows of the points of a STREAM-packed set: energy set -> out[npts, F]; force set -> out[3*npts, F]
@@ -475,5 +569,49 @@ extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("dot2_features_direct launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}
+
+// Energy and force feature rows (and prior variances) of a prediction batch in one launch: psi = [nE energy rows |
+// 3 nF force rows], diag likewise (may be NULL).  Energy point s = the x rows [e_row0[s], e_row0[s+1]); force point a =
+// rows f_row0[a] .. f_row0[a+1] of the index arrays (gpr_nbr_force_rows).  Same arithmetic as two calls of
+// gpr_dot2_features_direct (width 0, then width 3).
+extern "C" int gpr_dot2_features_ef(void *stream, int d, int nE, const int *e_row0_dev, int nF, const int *f_row0_dev,
+                                    const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev,
+                                    const double *dxdr_dev, const int *ele_dev, int ns, const int *species_host,
+                                    int nsx, const int *species_extra_host, double sigma, double sigma0, double *psi,
+                                    long long ld, double *diag) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(d >= 1 && d <= GPR_KPAD, "gpr_dot2_features_ef: d=%d unsupported (1..%d)", d, GPR_KPAD);
+    GPR_REQUIRE(ns >= 1 && ns <= FEAT_MAX_SPECIES, "gpr_dot2_features_ef: 1..%d species supported (got %d)", FEAT_MAX_SPECIES, ns);
+    GPR_REQUIRE(nsx >= 0 && nsx <= FEAT_MAX_EXTRA && (nsx == 0 || species_extra_host),
+                "gpr_dot2_features_ef: 0..%d extra species supported (got %d)", FEAT_MAX_EXTRA, nsx);
+    const int npair = d * (d + 1) / 2, F = ns * (npair + 1);
+    GPR_REQUIRE(psi && ld >= F, "gpr_dot2_features_ef: output leading dimension %lld < %d", ld, F);
+    GPR_REQUIRE(nE >= 0 && nF >= 0, "gpr_dot2_features_ef: negative sizes");
+    if (nE == 0 && nF == 0) return GPR_OK;
+    GPR_REQUIRE(x_dev && ele_dev && (nE == 0 || e_row0_dev) && (nF == 0 || (f_row0_dev && dxdr_dev)),
+                "gpr_dot2_features_ef: null device pointer");
+    dfeat_args AE, AF;
+    AE.x = x_dev; AE.dxdr = nullptr; AE.ele = ele_dev; AE.pt_row0 = e_row0_dev; AE.x_index = nullptr; AE.d_index = nullptr;
+    AE.npts = nE; AE.nc = 1; AE.d = d; AE.npair = npair; AE.ns = ns;
+    for (int s = 0; s < FEAT_MAX_SPECIES; s++) AE.species[s] = s < ns ? species_host[s] : 0;
+    AE.nsx = nsx;
+    for (int s = 0; s < FEAT_MAX_EXTRA; s++) AE.species_x[s] = s < nsx ? species_extra_host[s] : 0;
+    AE.sigma0 = sigma0; AE.sigma2 = sigma * sigma; AE.out = psi; AE.ld = ld; AE.diag = diag;
+    AF = AE;
+    AF.dxdr = dxdr_dev; AF.pt_row0 = f_row0_dev; AF.x_index = x_index_dev; AF.d_index = dxdr_index_dev;
+    AF.npts = nF; AF.nc = 4; AF.sigma0 = 0.0; AF.out = psi + (size_t)nE * ld; AF.diag = diag ? diag + nE : nullptr;
+    const int nblkF = (nF + 3) / 4, nblk = nblkF + nE * (diag ? 2 : 1);
+    const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
+    switch (ns) {
+        case 1: hipLaunchKernelGGL((dot2_features_ef_kernel<1>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
+        case 2: hipLaunchKernelGGL((dot2_features_ef_kernel<2>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
+        case 3: hipLaunchKernelGGL((dot2_features_ef_kernel<3>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
+        default: hipLaunchKernelGGL((dot2_features_ef_kernel<4>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
+    }
+    gpr_prof_end(st, pid);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("dot2_features_ef launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
     return GPR_OK;
 }

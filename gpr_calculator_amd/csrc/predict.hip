@@ -92,12 +92,9 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         if ((rc = dalloc((size_t)m * sizeof(double), &p))) return cleanup(rc);
         d_diag = (double *)p;
     }
-    if ((rc = gpr_dot2_features_direct(stream, d, 0, nstruct, d_atom0, nullptr, nullptr, d_x, nullptr, d_num, ns, species_host,
-                                       (int)extra.size(), extra.data(), sigma, sigma0, d_psi, F, d_diag))) return cleanup(rc);
-    if (nfree > 0 &&
-        (rc = gpr_dot2_features_direct(stream, d, 3, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr, d_num,
-                                       ns, species_host, (int)extra.size(), extra.data(), sigma, 0.0, d_psi + (size_t)nstruct * F, F,
-                                       d_diag ? d_diag + nstruct : nullptr))) return cleanup(rc);
+    if ((rc = gpr_dot2_features_ef(stream, d, nstruct, d_atom0, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr,
+                                   d_num, ns, species_host, (int)extra.size(), extra.data(), sigma, sigma0, d_psi, F, d_diag)))
+        return cleanup(rc);
     // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0); with C^-1 at hand the factored form in one launch
     if (want_std && Cinv_dev) {
         if ((rc = gpr_ws_tail(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma))) return cleanup(rc);

@@ -151,6 +151,14 @@ int gpr_dot2_features_direct(void *stream, int d, int width, int npts, const int
 /* (species_extra_host[nsx]: atomic numbers that occur in the predicted points but not among the model's ns species;
  * they get no feature block -- the kernel is zero across species -- but their own row pairs are part of k(x*, x*)) */
 
+/* Both calls of gpr_dot2_features_direct that a prediction batch needs (width 0 for its nE energy points, rows
+ * [e_row0[s], e_row0[s+1]) of x; width 3 for its nF force points, rows f_row0[a] .. f_row0[a+1] of the index arrays) as
+ * ONE launch: psi[nE + 3 nF, F] = [energy rows | force rows], diag[nE + 3 nF] likewise (may be NULL). */
+int gpr_dot2_features_ef(void *stream, int d, int nE, const int *e_row0_dev, int nF, const int *f_row0_dev,
+                         const int *x_index_dev, const int *dxdr_index_dev, const double *x_dev, const double *dxdr_dev,
+                         const int *ele_dev, int ns, const int *species_host, int nsx, const int *species_extra_host,
+                         double sigma, double sigma0, double *psi, long long ld, double *diag);
+
 /* Batched prediction of the Dot kernel at zeta = 2 in one call (what GP.predict_structures does for that kernel;
  * reference: one GP.predict_structure per structure, gaussianprocess.py:834-918): host arrays of the structures in
  * (layout of gpr_nbr_build), device-resident model in (so3_table from gpr_so3_tables; w[F] and M[F, F] of the
