@@ -47,6 +47,7 @@ struct nbr_geom {
 
 static void nbr_geometry(int n, const double *positions, const double *cell, const int *pb, double rcut, nbr_geom &g) {
     const bool any = pb[0] || pb[1] || pb[2];
+    g.shifts.clear(); g.nimg = 0; g.zero_img = 0; g.singular = false;     // `g` may be reused across structures
     g.wrapped.assign(positions, positions + 3 * (size_t)n);
     int nimg[3] = {0, 0, 0};
     if (any) {
@@ -325,6 +326,12 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 
 }  // namespace
 
+namespace {
+struct stage_buf { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+thread_local stage_buf g_stage[2];
+thread_local int g_stage_next = 0;
+}
+
 static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                  const double *cells, const int *pbc, const int *numbers, double rcut,
                                  int weight_on, int cap_pairs, int cap_rows) {
@@ -337,10 +344,10 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     std::vector<double> wpos, shifts;
     wpos.reserve(3 * (size_t)natoms);
     std::vector<int> sid(natoms);
+    nbr_geom g;
     for (int s = 0; s < nstruct; s++) {
         const int n = atom0[s + 1] - atom0[s];
         GPR_REQUIRE(n >= 0, "gpr_nbr_build_device: atom0 not ascending at structure %d", s);
-        nbr_geom g;
         nbr_geometry(n, positions + 3 * (size_t)atom0[s], cells + 9 * s, pbc + 3 * s, rcut, g);
         if (g.singular) { gpr_set_error("gpr_nbr_build_device: periodic structure %d has a singular cell", s); return GPR_ERR_ARG; }
         sinfo[s] = nbr_sinfo{atom0[s], n, (int)(shifts.size() / 3), g.nimg, g.zero_img, 0};
@@ -351,8 +358,27 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     const size_t b_wpos = wpos.size() * 8, b_shift = shifts.size() * 8, b_sinfo = sinfo.size() * sizeof(nbr_sinfo),
                  b_num = (size_t)natoms * 4;
     const size_t b_a0 = (size_t)(nstruct + 1) * 4;
-    std::vector<char> blob(b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0);
-    char *bp = blob.data();
+    const size_t b_total = b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0;
+    // the blob is assembled in page-locked memory (two buffers used in turn, each guarded by the event of its last
+    // copy): the upload is then a real asynchronous copy instead of a staged one
+    stage_buf &sb = g_stage[g_stage_next];
+    g_stage_next ^= 1;
+    if (sb.pending) { (void)hipEventSynchronize(sb.ev); sb.pending = false; }
+    if (sb.cap < b_total) {
+        if (sb.p) (void)hipHostFree(sb.p);
+        sb.p = nullptr; sb.cap = 0;
+        const size_t want = std::max(b_total * 2, (size_t)1 << 16);
+        if (hipHostMalloc(&sb.p, want, hipHostMallocDefault) != hipSuccess) {
+            gpr_set_error("gpr_nbr_build_device: cannot allocate %zu bytes of page-locked memory", want);
+            return GPR_ERR_HIP;
+        }
+        sb.cap = want;
+    }
+    if (!sb.ev && hipEventCreateWithFlags(&sb.ev, hipEventDisableTiming) != hipSuccess) {
+        gpr_set_error("gpr_nbr_build_device: cannot create an event");
+        return GPR_ERR_HIP;
+    }
+    char *bp = (char *)sb.p;
     if (b_wpos) memcpy(bp, wpos.data(), b_wpos);
     if (b_shift) memcpy(bp + b_wpos, shifts.data(), b_shift);
     if (b_sinfo) memcpy(bp + b_wpos + b_shift, sinfo.data(), b_sinfo);
@@ -364,11 +390,11 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     auto fail = [&](int code) { gpr_nbr_destroy(nb); return code; };
     int rc;
     void *p;
-    if ((rc = gpr_dev_alloc(&p, blob.size() + 16, st))) return fail(rc);
+    if ((rc = gpr_dev_alloc(&p, b_total + 16, st))) return fail(rc);
     nb->d_in = (char *)p;
-    if (!blob.empty()) {
-        // pageable source: the runtime stages it before returning, `blob` may die afterwards
-        hipError_t e = hipMemcpyAsync(nb->d_in, blob.data(), blob.size(), hipMemcpyHostToDevice, st);
+    if (b_total) {
+        hipError_t e = hipMemcpyAsync(nb->d_in, bp, b_total, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: upload failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
     }
     nb->d_wpos = (const double *)nb->d_in;
