@@ -167,3 +167,36 @@ def test_dense_linear_algebra(gpu):
     assert int(dev.potrf_lower_(t).item()) == 0 and rel(t.cpu().numpy(), cholesky(spd, lower=True)) < 1e-12
     bad = torch.tensor(np.array([[1.0, 2.0], [2.0, 1.0]]), device="cuda")
     assert int(dev.potrf_lower_(bad).item()) == 2          # not positive definite: pivot 2
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 3), (33, 130), (100, 257), (70, 466), (200, 932)])
+def test_ws_tail_matches_numpy(m, n):
+    """gpr_ws_tail (fused weight-space tail: P w and diag - vsq (|p|^2 - |p C^-T|^2) from MFMA tiles that are never
+    stored) against numpy, at sizes that are not multiples of its 32 x 128 x 32 tiles, and against the two-call route
+    gpr_gemm_nt_lower + gpr_ws_finish"""
+    import torch
+    from gpr_calculator_amd import _lib, device as dev
+    rng = np.random.default_rng(m * 1000 + n)
+    P = rng.normal(size=(m, n))
+    Ci = np.tril(rng.normal(size=(n, n))) / np.sqrt(n)
+    w = rng.normal(size=n)
+    vsq = 1.7
+    Q = P @ Ci.T
+    core = (P * P).sum(1) - (Q * Q).sum(1)
+    diag = vsq * core + rng.uniform(-0.5, 2.0, size=m)              # some rows clamp at zero
+    want_mean, want_var = P @ w, np.maximum(diag - vsq * core, 0.0)
+    dP, dC, dw, dd = dev.to_dev(P), dev.to_dev(Ci), dev.to_dev(w), dev.to_dev(diag)
+    out = torch.full((2 * m,), np.nan, dtype=torch.float64, device="cuda")
+    dev.check(_lib.lib().gpr_ws_tail(dev.stream_ptr(), m, n, dev.ptr(dP), n, dev.ptr(dC), n, dev.ptr(dw), dev.ptr(dd),
+                                     dev.ptr(out), vsq), "gpr_ws_tail")
+    got = out.cpu().numpy()
+    scale = max(1.0, np.abs(core).max() * vsq)
+    assert np.abs(got[:m] - want_mean).max() < 1e-12 * max(1.0, np.abs(want_mean).max())
+    assert np.abs(got[m:] - want_var).max() < 1e-12 * scale
+    # the two-call route computes the same numbers
+    dQ = torch.empty((m, n), dtype=torch.float64, device="cuda")
+    dev.check(_lib.lib().gpr_gemm_nt_lower(dev.stream_ptr(), m, n, 1.0, dev.ptr(dP), n, dev.ptr(dC), n, dev.ptr(dQ), n), "gemm")
+    out2 = torch.empty(2 * m, dtype=torch.float64, device="cuda")
+    dev.check(_lib.lib().gpr_ws_finish(dev.stream_ptr(), m, n, dev.ptr(dP), n, dev.ptr(dQ), n, dev.ptr(dw), dev.ptr(dd),
+                                       dev.ptr(out2), vsq), "finish")
+    assert np.abs(out2.cpu().numpy() - got).max() < 1e-12 * scale
