@@ -148,9 +148,36 @@ def test_so3_dense_small_cell_matches_oracle(scale):
     des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
     nb = des.neighbor_index_batch([s])
     assert np.diff(nb["centre_pair0"]).min() > (48 if scale == 1.0 else 96) and np.diff(nb["row_pair0"]).max() > 20
+    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, 3, 4, 5.0, 2.0, stress=True)
+    # without stress rows: pass 2 by (pair, l) lanes, rows summed over their ~30 / ~60 pairs round by round in the LDS
+    # row buffer, rows continued across chunk boundaries through global memory
+    out = des.calculate(s)
+    assert np.array_equal(out["seq"], ref["seq"])
+    assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
     des.stress = True           # the centre's own periodic images enter the (i, i) stress row only
     out = des.calculate(s)
-    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, 3, 4, 5.0, 2.0, stress=True)
     assert np.array_equal(out["seq"], ref["seq"])
     assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
     assert rel(out["rdxdr"], ref["rdxdr"]) < REL
+
+
+@pytest.mark.parametrize("cfg", [(2, 6, 4.2, 1.5), (4, 2, 4.0, 2.0), (1, 0, 3.0, 1.0), (3, 4, 6.5, 2.0)],
+                         ids=["n2l6", "n4l2", "n1l0", "n3l4_rcut6.5"])
+def test_so3_other_configurations_match_oracle(cfg):
+    """descriptor sizes off the default: lmax = 6 and nmax = 4 take the generically sized kernel instance (l loops to 7,
+    four radial channels), nmax = 1 / lmax = 0 the smallest tables, rcut = 6.5 gives ~90 pairs per centre (three chunks,
+    more Chebyshev segments); with and without stress rows"""
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from oracle.so3_numpy import so3_calculate
+    nmax, lmax, rcut, alpha = cfg
+    s = fcc_cell(seed=4, reps=1 if rcut < 6 else 2, species=(46, 78), sigma=0.1)
+    for stress in (False, True):
+        des = SO3(nmax=nmax, lmax=lmax, rcut=rcut, alpha=alpha)
+        des.stress = stress
+        out = des.calculate(s)
+        ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, nmax, lmax, rcut, alpha, stress=stress)
+        assert np.array_equal(out["seq"], ref["seq"])
+        assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
+        if stress:
+            assert rel(out["rdxdr"], ref["rdxdr"]) < REL
