@@ -495,17 +495,23 @@ __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const doub
 constexpr int WT_C = 128, WT_K = 32, WT_LD = WT_K + 2;   // row stride 34: operand reads of a half-wave hit 32 distinct bank pairs
 template <int WT_R> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + 4 * WT_R) * sizeof(double); }
 
-template <int WT_R>
+// SPLIT (few rows, e.g. one structure): grid (column blocks, row blocks), a workgroup takes ONE column block so that the
+// k chains of a row block run side by side; it leaves its sums of Q^2 in part[cb][row] (the owner of the last column
+// block also P w and |p|^2 in mn), and whichever workgroup of the row block finishes last (cnt) adds the parts in
+// column-block order and writes mean and variance.
+template <int WT_R, bool SPLIT>
 __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double *__restrict__ P, long long ldp,
                                                        const double *__restrict__ Ci, long long ldc,
                                                        const double *__restrict__ w, const double *__restrict__ diag,
-                                                       double *__restrict__ out, double vsq) {
+                                                       double *__restrict__ out, double vsq, double *__restrict__ part,
+                                                       double *__restrict__ mn, int *__restrict__ cnt) {
     constexpr int RT = WT_R / 16, AI = WT_R / 8;                 // 16-row MFMA tiles, A loads per thread and tile
+    __shared__ int s_last;
     extern __shared__ __attribute__((aligned(16))) double wt_smem[];
     double *As0 = wt_smem, *As1 = As0 + WT_R * WT_LD, *Bs0 = As1 + WT_R * WT_LD, *Bs1 = Bs0 + WT_C * WT_LD;
     double *red = Bs1 + WT_C * WT_LD;                            // [4 wavefronts][WT_R]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bm0 = blockIdx.x * WT_R;
+    const int bm0 = (SPLIT ? blockIdx.y : blockIdx.x) * WT_R;
     const int wj = wave * 32;                                    // this wavefront: all WT_R rows x columns wj .. wj + 31
     const int lk = tid & 31, lr = tid >> 5;                      // tile loads: k offset, row / column offset (+ 8 i)
     double sq[RT][4];                                            // sum over columns of Q^2, rows 16 i + (lane >> 4) + 4 r
@@ -515,7 +521,7 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
 #pragma unroll
     for (int i = 0; i < AI; i++) { mean2[i] = 0.0; norm2[i] = 0.0; }
     const int ncb = (n + WT_C - 1) / WT_C;
-    for (int cb = 0; cb < ncb; cb++) {
+    for (int cb = SPLIT ? (int)blockIdx.x : 0; cb < (SPLIT ? (int)blockIdx.x + 1 : ncb); cb++) {
         const int bn0 = cb * WT_C;
         const int kend = min(n, bn0 + WT_C);                     // C^-1[j][k] = 0 for k > j
         const bool last = cb == ncb - 1;
@@ -601,16 +607,41 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
 #pragma unroll
             for (int r = 0; r < 4; r++) red[wave * WT_R + 16 * i + (lane >> 4) + 4 * r] = sq[i][r];
     __syncthreads();
-    if (lk == 0)
+    if (!SPLIT) {
+        if (lk == 0)
+#pragma unroll
+            for (int i = 0; i < AI; i++) {
+                const int rl = lr + 8 * i, row = bm0 + rl;
+                if (row < m) {
+                    out[row] = mean2[i];
+                    const double q2 = ((red[rl] + red[WT_R + rl]) + red[2 * WT_R + rl]) + red[3 * WT_R + rl];
+                    out[m + row] = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0);
+                }
+            }
+        return;
+    }
+    if (tid < WT_R && bm0 + tid < m)
+        part[(size_t)blockIdx.x * m + bm0 + tid] = ((red[tid] + red[WT_R + tid]) + red[2 * WT_R + tid]) + red[3 * WT_R + tid];
+    if ((int)blockIdx.x == ncb - 1 && lk == 0)                   // owner of the last column block: full k range seen
 #pragma unroll
         for (int i = 0; i < AI; i++) {
-            const int rl = lr + 8 * i, row = bm0 + rl;
-            if (row < m) {
-                out[row] = mean2[i];
-                const double q2 = ((red[rl] + red[WT_R + rl]) + red[2 * WT_R + rl]) + red[3 * WT_R + rl];
-                out[m + row] = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0);
-            }
+            const int row = bm0 + lr + 8 * i;
+            if (row < m) { mn[row] = mean2[i]; mn[(size_t)m + row] = norm2[i]; }
         }
+    // last workgroup of this row block: what the others wrote is visible after the fence / counter handshake
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(&cnt[blockIdx.y], 1) == ncb - 1;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    if (tid < WT_R && bm0 + tid < m) {
+        const int row = bm0 + tid;
+        double q2 = 0.0;
+        for (int x = 0; x < ncb; x++) q2 += __builtin_nontemporal_load(&part[(size_t)x * m + row]);
+        out[row] = __builtin_nontemporal_load(&mn[row]);
+        out[m + row] = fmax(diag[row] - vsq * (__builtin_nontemporal_load(&mn[(size_t)m + row]) - q2), 0.0);
+    }
 }
 
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
@@ -933,11 +964,33 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
     constexpr int R = WT_ROWS;
     static bool attr_set = false;
     if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
         attr_set = true;
     }
+    const int nrb = (m + R - 1) / R, ncb = (n + WT_C - 1) / WT_C;
+    if (nrb * 2 <= 128 && ncb > 1) {
+        // few rows (a single structure): one workgroup per (column block, row block) and a last-arriver reduction
+        void *wsp;
+        const size_t ws_bytes = (size_t)(ncb + 2) * m * sizeof(double) + (size_t)nrb * sizeof(int);
+        int rc = gpr_dev_alloc(&wsp, ws_bytes, st);
+        if (rc) return rc;
+        double *part = (double *)wsp, *mn = part + (size_t)ncb * m;
+        int *cnt = (int *)(mn + 2 * (size_t)m);
+        const hipError_t me = hipMemsetAsync(cnt, 0, (size_t)nrb * sizeof(int), st);
+        if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
+        const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
+        hipLaunchKernelGGL((ws_tail_kernel<R, true>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
+                           out, vsq, part, mn, cnt);
+        gpr_prof_end(st, pid);
+        const hipError_t le = hipGetLastError();
+        gpr_dev_free(wsp, st);
+        if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
     const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
-    hipLaunchKernelGGL(ws_tail_kernel<R>, dim3((m + R - 1) / R), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq);
+    hipLaunchKernelGGL((ws_tail_kernel<R, false>), dim3(nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq,
+                       (double *)nullptr, (double *)nullptr, (int *)nullptr);
     gpr_prof_end(st, pid);
     LAUNCH_CHECK("ws_tail");
     return GPR_OK;
