@@ -57,6 +57,7 @@ _L1_SIGNATURES = {
     "gpr_nbr_device_arrays": ([_vp] + [C.POINTER(_vp)] * 9, _i),
     "gpr_nbr_force_rows": ([_vp, _i, _vp, _vp, _i, _vp, _vp], _i),
     "gpr_nbr_check": ([_vp, c_int_p], _i),
+    "gpr_nbr_point_rows": ([_vp, _i, _vp, _vp], _i),
     "gpr_nbr_status_to": ([_vp, _vp], _i),
     "gpr_nbr_info_to": ([_vp, _vp], _i),
     "gpr_nbr_build_device_capped": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i, _i, _i], _i),

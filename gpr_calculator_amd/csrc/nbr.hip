@@ -292,6 +292,31 @@ __global__ void __launch_bounds__(1024) nbr_scan_kernel(int n, const int *cnt_ro
     if (tid == 0) { info[0] = over ? 1 : 0; info[1] = P; info[2] = S; }
 }
 
+// row offsets of a list of moving atoms: out[k] = sum_{k' < k} rows(atoms[k']), out[npts] = total; one workgroup
+__global__ void __launch_bounds__(1024) nbr_point_rows_kernel(int npts, const int *atoms, const int *cr0, int *out) {
+    __shared__ int wsum[16];
+    __shared__ int carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < npts; base += 1024) {
+        const int k = base + tid;
+        int v = 0;
+        if (k < npts) { const int a = atoms[k]; v = cr0[a + 1] - cr0[a]; }
+        const int incl = wave_incl_scan(v, lane);
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        int w0 = 0;
+        for (int q = 0; q < wave; q++) w0 += wsum[q];
+        const int c = carry;
+        if (k < npts) out[k] = c + w0 + incl - v;
+        __syncthreads();
+        if (tid == 1023) carry = c + w0 + incl;
+        __syncthreads();
+    }
+    if (tid == 0) out[npts] = carry;
+}
+
 struct frow_args {
     const int *atoms, *pt_row0;      // [npts], [npts+1]
     const int *cr0, *seq, *sid;
@@ -513,6 +538,17 @@ extern "C" int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_
     frow_args f{atoms_dev, pt_row0_dev, nb->d_off, nb->d_seq, nb->d_sid, nb->d_sinfo, row_index_dev, x_index_dev, nb->d_err,
                 npts, nrows};
     hipLaunchKernelGGL(nbr_force_rows_kernel, dim3((nrows + 255) / 256), dim3(256), 0, nb->st, f);
+    GPR_HIP_TRY(hipGetLastError());
+    return GPR_OK;
+}
+
+// pt_row0_out_dev[npts + 1]: exclusive row offsets of the force points of the moving atoms atoms_dev[npts] (device),
+// the input gpr_nbr_force_rows wants next to that list -- computed on the device so that nobody needs centre_row0 on
+// the host
+extern "C" int gpr_nbr_point_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, int *pt_row0_out_dev) {
+    GPR_REQUIRE(nb && nb->on_device, "gpr_nbr_point_rows: handle was not built by gpr_nbr_build_device");
+    GPR_REQUIRE(npts >= 0 && pt_row0_out_dev && (npts == 0 || atoms_dev), "gpr_nbr_point_rows: bad arguments");
+    hipLaunchKernelGGL(nbr_point_rows_kernel, dim3(1), dim3(1024), 0, nb->st, npts, atoms_dev, nb->d_off, pt_row0_out_dev);
     GPR_HIP_TRY(hipGetLastError());
     return GPR_OK;
 }

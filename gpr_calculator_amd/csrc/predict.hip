@@ -35,7 +35,7 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
 
     // capacities guessed by the caller (from the sizes an earlier call reported): nothing below waits for the device
     gpr_nbr *nb = nullptr;
-    const bool capped = cap_pairs > 0 && cap_rows > 0 && !free_mask && natoms > 0;
+    const bool capped = cap_pairs > 0 && cap_rows > 0 && natoms > 0;
     int rc = capped ? gpr_nbr_build_device_capped(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
                                                   cap_pairs, cap_rows)
                     : gpr_nbr_build_device(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on);
@@ -58,17 +58,20 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     int frows = S;
     const int *d_fatoms = nullptr, *d_frow0 = nullptr;
     if (free_mask) {
-        std::vector<int> cr0(natoms + 1), meta(2 * (size_t)nfree + 1);
-        if ((rc = gpr_nbr_export(nb, nullptr, nullptr, nullptr, cr0.data(), nullptr, nullptr, nullptr, nullptr))) return cleanup(rc);
-        int k = 0, acc = 0;
+        // list of moving atoms up, their row offsets by a device scan (frows stays the bound S: the regrouping kernel
+        // stops at the true total)
+        std::vector<int> fatoms((size_t)std::max(nfree, 1));
+        int k = 0;
         for (int a = 0; a < natoms; a++)
-            if (free_mask[a]) { meta[k] = a; meta[nfree + k] = acc; acc += cr0[a + 1] - cr0[a]; k++; }
-        meta[2 * (size_t)nfree] = acc;
-        frows = acc;
-        if ((rc = dalloc(meta.size() * sizeof(int), &p))) return cleanup(rc);
-        hipError_t e = hipMemcpyAsync(p, meta.data(), meta.size() * sizeof(int), hipMemcpyHostToDevice, st);   // pageable: staged before return
-        if (e != hipSuccess) { gpr_set_error("gpr_predict_dot2_batch: upload failed: %s", hipGetErrorString(e)); return cleanup(GPR_ERR_HIP); }
-        d_fatoms = (const int *)p; d_frow0 = d_fatoms + nfree;
+            if (free_mask[a]) fatoms[k++] = a;
+        if ((rc = dalloc((2 * (size_t)nfree + 2) * sizeof(int), &p))) return cleanup(rc);
+        int *d_meta = (int *)p;
+        if (nfree > 0) {
+            hipError_t e = hipMemcpyAsync(d_meta, fatoms.data(), (size_t)nfree * sizeof(int), hipMemcpyHostToDevice, st);   // pageable: staged before return
+            if (e != hipSuccess) { gpr_set_error("gpr_predict_dot2_batch: upload failed: %s", hipGetErrorString(e)); return cleanup(GPR_ERR_HIP); }
+        }
+        if ((rc = gpr_nbr_point_rows(nb, nfree, d_meta, d_meta + nfree))) return cleanup(rc);
+        d_fatoms = d_meta; d_frow0 = d_meta + nfree;
     }
     int *d_rowidx = nullptr, *d_xidx = nullptr;
     if ((rc = dalloc((size_t)std::max(frows, 1) * 2 * sizeof(int), &p))) return cleanup(rc);

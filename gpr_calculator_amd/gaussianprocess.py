@@ -849,7 +849,7 @@ class GP():
         # neighbour-table capacities guessed from the densest batch seen so far (pairs and seq rows per atom, 12 % spare):
         # with them the call queues everything without waiting for the device; too small a guess comes back flagged
         # and the batch is repeated with exact sizes
-        hint = self._nbr_hint if mask is None else None
+        hint = self._nbr_hint
         caps = (0, 0) if hint is None else (int(hint[0] * natoms * 1.125) + 64, int(hint[1] * natoms * 1.125) + 64)
         for attempt in range(2):
             tailw[:] = np.nan

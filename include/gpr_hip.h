@@ -167,7 +167,7 @@ int gpr_dot2_features_ef(void *stream, int d, int nE, const int *e_row0_dev, int
  * m = nstruct + 3 nfree rows ordered energies (per atom) then (fx, fy, fz) of every free atom; free_mask[natoms]
  * (host, may be NULL = every atom free) marks the atoms that get force rows (FixAtoms, gaussianprocess.py:823-832);
  * status = [force rows the neighbour symmetry check could not find (0), overflow, neighbour pairs, seq rows].
- * cap_pairs / cap_rows > 0 (and no free_mask): sizes guessed from what an earlier call reported in status[2..3]; the
+ * cap_pairs / cap_rows > 0: sizes guessed from what an earlier call reported in status[2..3]; the
  * neighbour build then runs capped (gpr_nbr_build_device_capped) and the call queues everything without waiting for
  * the device.  overflow = 1 means the guess was too small and mean / var are meaningless: call again with 0, 0.
  * Queues neighbour search, descriptor, regrouping, features, GEMM and the tail kernel on `stream`; the caller
@@ -233,6 +233,8 @@ int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **
  * (npts = natoms, nrows = S): point a is atom a and its row range is centre_row0 -- nothing to upload. */
 int gpr_nbr_force_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, const int *pt_row0_dev, int nrows,
                        int *row_index_dev, int *x_index_dev);
+/* pt_row0_out_dev[npts + 1] for gpr_nbr_force_rows from the list of moving atoms alone (device scan of their row counts) */
+int gpr_nbr_point_rows(const gpr_nbr *nb, int npts, const int *atoms_dev, int *pt_row0_out_dev);
 /* number of (i, a) rows gpr_nbr_force_rows could not find (0 unless the symmetry above is broken); synchronises */
 int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
 /* same count written as a double to dst_dev[0] in stream order (rides along with the caller's result download) */
