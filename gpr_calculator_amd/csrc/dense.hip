@@ -102,10 +102,17 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
                                                        const double *__restrict__ A, long long lda,
                                                        const double *__restrict__ B, long long ldb,
                                                        double beta, double *__restrict__ C, long long ldc,
-                                                       int lower_only) {
+                                                       int lower_only, int ksplit, double *__restrict__ ws) {
     __shared__ double As[2][GBUF];
     __shared__ double Bs[2][GBUF];
     const int bm0 = blockIdx.y * GM, bn0 = blockIdx.x * GN;
+    if (ksplit > 0) {            // split-K slice blockIdx.z: rows [k0, k0 + ksplit) of op(A), op(B); plain sums into ws[z]
+        const int k0 = blockIdx.z * ksplit;
+        A += TA ? (long long)k0 * lda : (long long)k0;
+        B += TB ? (long long)k0 : (long long)k0 * ldb;
+        k = min(k - k0, ksplit);
+        C = ws + (size_t)blockIdx.z * m * n; ldc = n; alpha = 1.0; beta = 0.0;
+    }
     if ((lower_only & 1) && bn0 > bm0 + GM - 1) return;
     if (lower_only & 2) k = min(k, bm0 + GM);
     if (lower_only & 4) k = min(k, bn0 + GN);
@@ -655,15 +662,45 @@ __global__ void gemv_t_partial_kernel(int n, int ncols, const double *a, long lo
     part[(long long)blockIdx.y * ncols + j] = acc;
 }
 
+// C = alpha sum_z ws[z] + beta C, slices added in z order
+__global__ void gemm_splitk_reduce_kernel(int m, int n, int nz, const double *__restrict__ ws, double alpha, double beta,
+                                          double *__restrict__ C, long long ldc) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)m * n) return;
+    double s = 0.0;
+    for (int z = 0; z < nz; z++) s += ws[(size_t)z * m * n + e];
+    double *c = C + (e / n) * ldc + (e % n);
+    *c = (beta == 0.0) ? alpha * s : alpha * s + beta * *c;
+}
+
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
     if (m >= 256 && n >= 256) {      // enough tiles to fill the chip with the 128x128 kernel
         dim3 g2((n + GN - 1) / GN, (m + GM - 1) / GM), b2(256);
-        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
-        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
-        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
+        // tall-skinny A^T B (the F x F Gram matrices of the weight-space fit: a handful of tiles, k in the thousands):
+        // slices of k on blockIdx.z, partial tiles to a workspace, summed in slice order
+        const int tiles = (int)(g2.x * g2.y);
+        if (ta && !tb && !lower_only && tiles <= 64 && k >= 2048) {
+            int nz = std::min(256 / tiles, k / 512);
+            const int ksplit = ((k + nz - 1) / nz + GK - 1) / GK * GK;
+            nz = (k + ksplit - 1) / ksplit;
+            void *wsp;
+            int rc = gpr_dev_alloc(&wsp, (size_t)nz * m * n * sizeof(double), st);
+            if (rc) return rc;
+            g2.z = nz;
+            hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp);
+            hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, nz,
+                               (const double *)wsp, alpha, beta, c, ldc);
+            const hipError_t e3 = hipGetLastError();
+            gpr_dev_free(wsp, st);
+            if (e3 != hipSuccess) { gpr_set_error("split-K gemm launch failed: %s", hipGetErrorString(e3)); return GPR_ERR_HIP; }
+            return GPR_OK;
+        }
+        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
+        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
+        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
+        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { gpr_set_error("gemm128 launch failed: %s", hipGetErrorString(e2)); return GPR_ERR_HIP; }
         return GPR_OK;

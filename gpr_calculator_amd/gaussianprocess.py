@@ -407,7 +407,7 @@ class GP():
         y = dev.to_dev(self.y_train).reshape(-1) * rs
         G = dev.gemm(S, S, transa=True)
         G.diagonal().add_(1.0)
-        b = dev.gemm(S, y.reshape(-1, 1), transa=True)                            # Psi'^T D^-1 y
+        b = dev.gemv_t(S, y).reshape(-1, 1)                                       # Psi'^T D^-1 y
         info, dinv = dev.potrf_lower_(G, want_dinv=True)
         if int(info.item()) != 0:
             return False
@@ -415,10 +415,18 @@ class GP():
         dev.trsm_lower_(G, b, trans=True, dinv=dinv)                              # G^-1 b
         Ci = torch.eye(F, dtype=dev.F64, device=Psi.device)
         dev.trsm_lower_(G, Ci, dinv=dinv)                                         # C^-1, G = C C^T
-        M = dev.gemm(Ci, Ci, transa=True, alpha=-sig * sig)                       # -sigma^2 G^-1
-        M.diagonal().add_(sig * sig)
-        self._ws_cache = (species, M, b * sig, Ci)                        # Ci = C^-1 feeds the factored variance form
+        # M = sigma^2 (I - G^-1) is formed from C^-1 only when the unfactored variance form asks for it (_ws_M)
+        self._ws_cache = [species, None, b * sig, Ci]                     # Ci = C^-1 feeds the factored variance form
         return True
+
+    def _ws_M(self, ws):
+        """M = sigma^2 (I - G^-1) of the weight-space model; a weight-space fit leaves it to the first caller"""
+        if ws[1] is None:
+            sig, Ci = float(self.kernel.sigma), ws[3]
+            M = dev.gemm(Ci, Ci, transa=True, alpha=-sig * sig)                   # -sigma^2 G^-1
+            M.diagonal().add_(sig * sig)
+            ws[1] = M
+        return ws[1]
 
     # ------------------------------------------------------------------ prediction
     def _predict_dev(self, X, train_x, f_tol, return_std, want_flat=False):
@@ -432,7 +440,7 @@ class GP():
             pd = self.kernel.psi_diag_dev(X, ws[0], want_diag=return_std)
             if pd is not None:
                 P, diag = pd
-                out, flat = dev.ws_finish(P, ws[2], dev.gemm(P, ws[1]) if return_std else None, diag, tail=1)
+                out, flat = dev.ws_finish(P, ws[2], dev.gemm(P, self._ws_M(ws)) if return_std else None, diag, tail=1)
                 res = (out[0], out[1] if return_std else None)
                 return res + (flat,) if want_flat else res
         if ws is not None and self.weight_space_mean:
@@ -450,7 +458,7 @@ class GP():
         if ws is not None:
             # Dot kernel at zeta = 2: k = sigma^2 Psi psi, so |L^-1 k|^2 = psi^T M psi with the F x F matrix
             # M = (L^-1 sigma^2 Psi)^T (L^-1 sigma^2 Psi) built once per fit: no N-sized work per prediction
-            species, M = ws[0], ws[1]
+            species, M = ws[0], self._ws_M(ws)
             P = self.kernel._psi(X, species)
             var = var - dev.rowdot(dev.gemm(P, M), P)
         else:
@@ -830,8 +838,9 @@ class GP():
         nfree = natoms if mask is None else int(mask.sum())
         m = len(mine_strucs) + 3 * nfree
         table, nseg, ncheb = des._device_tables()[:3]
-        species, M, w = ws[:3]
+        species, w = ws[0], ws[2]
         Cinv = ws[3] if len(ws) > 3 else None
+        M = None if (Cinv is not None or not return_std) else self._ws_M(ws)
         sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
         a0 = atom0.astype(np.int32)
         num = numbers.astype(np.int32)
