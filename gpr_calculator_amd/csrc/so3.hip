@@ -22,8 +22,11 @@
 //     dP[(n1,n2,l), k] = u_k (A_n1l R_n2l + A_n2l R_n1l) + B_n1l S_n2lk + B_n2l S_n1lk
 // and dC itself is never formed; S is evaluated without grad Y either, from Y_{l+-1} and per-centre tables that
 // contract the gradient coefficients (SO3.py:682-707) with c_tot once.  One 256-thread workgroup per centre atom:
-// the per-pair tables (geometry, A, B, Y) are built with lanes over pairs into LDS records, pass 1 sums c_tot
-// from them, pass 2 walks the seq rows (one row per wavefront).  No atomics; the summation order is fixed.
+// the per-pair tables (geometry, A, B, Y) are built with lanes over pairs into LDS records (radial sums on three
+// wavefronts, angular recurrences on the fourth), pass 1 sums c_tot from them, pass 2 forms the dP entries with one
+// lane per (pair, l) and adds them over the pairs of a seq row in an LDS row buffer that is written out as the
+// centre's slab of dxdr (the stress variant walks the seq rows instead, one row per wavefront).  No floating-point
+// atomics; the summation order is fixed.
 #include "gpr_internal.h"
 
 namespace {
