@@ -136,3 +136,53 @@ def test_dot_weight_space_fit_matches_dense_route_at_full_size():
     gp.fit(show=False, opt=False)
     a_lazy = gp.alpha_
     assert not gp._dense_pending and a_lazy.shape == (6063, 1)
+
+
+def test_symmetries_of_the_native_prediction_at_full_size():
+    """cfg3 Dot model, native batch call: size-independent properties of the whole device path (neighbour search ->
+    descriptor -> features -> tail).  Batch order only permutes the results (bit for bit); a rigid translation (atoms
+    re-wrapped into other periodic images) and a rigid rotation of cell and atoms leave E and sigma unchanged and
+    rotate the forces."""
+    import bench
+    from gpr_calculator_amd.parallel import Comm
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    from gpr_calculator_amd.synthetic import neb_images
+    gp = bench.build_model("Dot", 2000, Comm())
+    gp.fit(show=False, opt=False)
+    batch = neb_images(12, seed=700)
+    E, F, Es, Fs = gp.predict_structures(batch, return_std=True)
+    perm = np.random.default_rng(0).permutation(len(batch))
+    Ep, Fp, Esp, Fsp = gp.predict_structures([batch[k] for k in perm], return_std=True)
+    for a, k in enumerate(perm):
+        assert Ep[a] == E[k] and Esp[a] == Es[k] and np.array_equal(Fp[a], F[k]) and np.array_equal(Fsp[a], Fs[k])
+    # translation by a vector that moves atoms across cell boundaries
+    s = batch[3]
+    t = SimpleAtoms(s.numbers, s.positions + np.array([3.3, -7.9, 11.2]), s.cell, s.pbc)
+    # rotation about an oblique axis (Rodrigues), applied to cell rows and positions alike
+    ax = np.array([1.0, 2.0, -0.5]); ax /= np.linalg.norm(ax); th = 0.83
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    r = SimpleAtoms(s.numbers, s.positions @ R.T, s.cell @ R.T, s.pbc)
+    (Et, Er), (Ft, Fr), (Est, Esr), (Fst, Fsr) = gp.predict_structures([t, r], return_std=True)
+    n = len(s)
+    assert abs(Et - E[3]) / n < 1e-9 and np.abs(Ft - F[3]).max() < 1e-8 and abs(Est - Es[3]) < 1e-8 and np.abs(Fst - Fs[3]).max() < 1e-7
+    assert abs(Er - E[3]) / n < 1e-9 and np.abs(Fr - F[3] @ R.T).max() < 1e-8 and abs(Esr - Es[3]) < 1e-8
+    # the force variances are those of the rotated components: compare the rotation-invariant trace per atom
+    assert np.abs((Fsr ** 2).sum(1) - (Fs[3] ** 2).sum(1)).max() < 1e-6 * max(1.0, (Fs[3] ** 2).sum(1).max())
+
+
+def test_translation_and_rotation_invariance_rbf(model):
+    """the same physics through the pair-kernel route (RBF, K_trans + triangular product)"""
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    from gpr_calculator_amd.synthetic import neb_images
+    gp = model
+    s = neb_images(2, seed=710)[1]
+    ax = np.array([-0.3, 1.0, 0.7]); ax /= np.linalg.norm(ax); th = 2.1
+    Kx = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+    R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+    t = SimpleAtoms(s.numbers, s.positions + np.array([-5.1, 2.2, 9.7]), s.cell, s.pbc)
+    r = SimpleAtoms(s.numbers, s.positions @ R.T, s.cell @ R.T, s.pbc)
+    E, F, Es, Fs = gp.predict_structures([s, t, r], return_std=True)
+    n = len(s)
+    assert abs(E[1] - E[0]) / n < 1e-9 and np.abs(F[1] - F[0]).max() < 1e-8 and abs(Es[1] - Es[0]) < 1e-7
+    assert abs(E[2] - E[0]) / n < 1e-9 and np.abs(F[2] - F[0] @ R.T).max() < 1e-8 and abs(Es[2] - Es[0]) < 1e-7
