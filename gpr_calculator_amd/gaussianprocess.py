@@ -872,11 +872,12 @@ class GP():
             # synchronisation sleeps and wakes tens of microseconds late); everything queued before that kernel has
             # completed, in stream order, when they appear
             spins = 0
-            while np.isnan(tailw).any():
+            while self._poll_results and np.isnan(tailw).any():
                 spins += 1
-                if spins > 200000:                    # ~0.1 s without an answer: let the runtime report what happened
-                    torch.cuda.current_stream().synchronize()
-                    break
+                if spins > 200000:                    # ~0.3 s without an answer: let the runtime report what happened,
+                    self._poll_results = False        # and stop polling (host memory that is not coherent with the device)
+            if not self._poll_results:
+                torch.cuda.current_stream().synchronize()
             host = view.copy()                        # the pinned buffer is reused by the next call
             if host[nout + 1] == 0.0:
                 break
@@ -890,6 +891,7 @@ class GP():
 
     _nbr_hint = None
     _pinned_out = None
+    _poll_results = True
 
     native_batch = True
     device_single = True
