@@ -205,9 +205,9 @@ def main():
                    "1.10 kflop per same-species row pair"),
             "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
                      "N^2 m (triangular-solve form of the variance)"),
-            "gemm": (("ws_tail_kernel (gpr_ws_tail): mean = Psi* w and the weight-space variance |psi|^2 - |C^-1 psi|^2 from "
-                      "FP64 MFMA tiles of Psi* C^-T (C^-1 lower triangular: half of the m x F x F product; the product "
-                      "itself is never stored)",
+            "gemm": (("ws_tail_kernel (+ ws_tail_combine_kernel; gpr_ws_tail): mean = Psi* w and the weight-space variance "
+                      "|psi|^2 - |C^-1 psi|^2 from FP64 MFMA tiles of Psi* C^-T (C^-1 lower triangular: half of the m x F x F "
+                      "product; the product itself is never stored)",
                       float(m_rows) * F * (F + 1) + 4.0 * m_rows * F,
                       "m F (F + 1) + 4 m F for the m = %d predicted rows and F = %d features" % (m_rows, F))
                      if ws_native else
@@ -238,7 +238,13 @@ def main():
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
                     "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "flop_per_step": flops,
                     "work_unit": unit_note,
-                    "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])}}
+                    "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
+                    # the same figures for every profiled kernel kind of the step (the top two are often within a few
+                    # per cent of each other, so which one is "dominant" can change from run to run)
+                    "per_kernel": {k: {"ms_per_step": round(per_step[k][0], 4), "flop_per_step": work[k][1],
+                                       "achieved": work[k][1] / (per_step[k][0] * 1e-3) / 1e12 if per_step[k][0] > 0 else 0.0,
+                                       "frac": work[k][1] / (per_step[k][0] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if per_step[k][0] > 0 else 0.0}
+                                   for k in per_step if k in work}}
         # the same step through the row-pair route (what every other kernel / zeta takes): the Dot kernel object with its
         # feature map switched off builds K_trans with kblock_kernel<FF> -- the FP64-MFMA kernel of SURVEY section 8d --
         # measured live here so that its roofline point sits next to the headline's

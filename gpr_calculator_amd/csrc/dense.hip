@@ -502,11 +502,14 @@ __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const doub
 constexpr int WT_C = 128, WT_K = 32, WT_LD = WT_K + 2;   // row stride 34: operand reads of a half-wave hit 32 distinct bank pairs
 template <int WT_R> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + 4 * WT_R) * sizeof(double); }
 
-// SPLIT (few rows, e.g. one structure): grid (column blocks, row blocks), a workgroup takes ONE column block so that the
-// k chains of a row block run side by side; it leaves its sums of Q^2 in part[cb][row] (the owner of the last column
-// block also P w and |p|^2 in mn), and whichever workgroup of the row block finishes last (cnt) adds the parts in
-// column-block order and writes mean and variance.
-template <int WT_R, bool SPLIT>
+// SPLIT = 1 (few rows, e.g. one structure): grid (column blocks, row blocks), a workgroup takes ONE column block so that
+// the k chains of a row block run side by side; it leaves its sums of Q^2 in part[cb][row] (the owner of the last
+// column block also P w and |p|^2 in mn), and whichever workgroup of the row block finishes last (cnt) adds the parts in
+// column-block order and writes mean and variance.  SPLIT = 2 (many rows): grid (ceil(ncb / 2), row blocks), a
+// workgroup takes column blocks x and ncb - 1 - x; ws_tail_combine_kernel adds the parts (a device-scope fence per
+// workgroup, as the last-arriver scheme needs, costs more than that launch when there are hundreds of workgroups).
+// SPLIT = 0: one workgroup walks all column blocks (a single column block, or as a reference).
+template <int WT_R, int SPLIT>
 __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double *__restrict__ P, long long ldp,
                                                        const double *__restrict__ Ci, long long ldc,
                                                        const double *__restrict__ w, const double *__restrict__ diag,
@@ -528,7 +531,11 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
 #pragma unroll
     for (int i = 0; i < AI; i++) { mean2[i] = 0.0; norm2[i] = 0.0; }
     const int ncb = (n + WT_C - 1) / WT_C;
-    for (int cb = SPLIT ? (int)blockIdx.x : 0; cb < (SPLIT ? (int)blockIdx.x + 1 : ncb); cb++) {
+    // SPLIT 0: all column blocks; 1: column block blockIdx.x; 2: blocks blockIdx.x and ncb - 1 - blockIdx.x (a short k
+    // range with a long one)
+    const int nturn = SPLIT == 0 ? ncb : (SPLIT == 1 ? 1 : ((int)blockIdx.x * 2 + 1 == ncb ? 1 : 2));
+    for (int turn = 0; turn < nturn; turn++) {
+        const int cb = SPLIT == 0 ? turn : (turn == 0 ? (int)blockIdx.x : ncb - 1 - (int)blockIdx.x);
         const int bn0 = cb * WT_C;
         const int kend = min(n, bn0 + WT_C);                     // C^-1[j][k] = 0 for k > j
         const bool last = cb == ncb - 1;
@@ -629,12 +636,13 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
     }
     if (tid < WT_R && bm0 + tid < m)
         part[(size_t)blockIdx.x * m + bm0 + tid] = ((red[tid] + red[WT_R + tid]) + red[2 * WT_R + tid]) + red[3 * WT_R + tid];
-    if ((int)blockIdx.x == ncb - 1 && lk == 0)                   // owner of the last column block: full k range seen
+    if ((SPLIT == 2 ? (int)blockIdx.x == 0 : (int)blockIdx.x == ncb - 1) && lk == 0)     // owner of the last column block: full k range seen
 #pragma unroll
         for (int i = 0; i < AI; i++) {
             const int row = bm0 + lr + 8 * i;
             if (row < m) { mn[row] = mean2[i]; mn[(size_t)m + row] = norm2[i]; }
         }
+    if (SPLIT == 2) return;                                      // ws_tail_combine_kernel adds the parts
     // last workgroup of this row block: what the others wrote is visible after the fence / counter handshake
     __threadfence();
     __syncthreads();
@@ -649,6 +657,17 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
         out[row] = __builtin_nontemporal_load(&mn[row]);
         out[m + row] = fmax(diag[row] - vsq * (__builtin_nontemporal_load(&mn[(size_t)m + row]) - q2), 0.0);
     }
+}
+
+// second launch of the paired scheme: parts added in order, mean and variance written
+__global__ void ws_tail_combine_kernel(int m, int npart, const double *__restrict__ part, const double *__restrict__ mn,
+                                       const double *__restrict__ diag, double *__restrict__ out, double vsq) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    double q2 = 0.0;
+    for (int x = 0; x < npart; x++) q2 += part[(size_t)x * m + row];
+    out[row] = mn[row];
+    out[m + row] = fmax(diag[row] - vsq * (mn[(size_t)m + row] - q2), 0.0);
 }
 
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
@@ -1001,8 +1020,8 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
     constexpr int R = WT_ROWS;
     static bool attr_set = false;
     if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
         attr_set = true;
     }
     const int nrb = (m + R - 1) / R, ncb = (n + WT_C - 1) / WT_C;
@@ -1017,7 +1036,7 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
         const hipError_t me = hipMemsetAsync(cnt, 0, (size_t)nrb * sizeof(int), st);
         if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
-        hipLaunchKernelGGL((ws_tail_kernel<R, true>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
+        hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
                            out, vsq, part, mn, cnt);
         gpr_prof_end(st, pid);
         const hipError_t le = hipGetLastError();
@@ -1025,8 +1044,33 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
         if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
         return GPR_OK;
     }
+    if (ncb >= 2) {
+        // many rows: 64-row workgroups take column blocks x and ncb - 1 - x (equal work for every workgroup, half the
+        // C^-1 bytes per flop of the 32-row form), their sums are combined by a second small launch
+        constexpr int R2 = 64;
+        static bool attr2 = false;
+        if (!attr2) {
+            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R2>()));
+            attr2 = true;
+        }
+        const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
+        void *wsp;
+        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double), st);
+        if (rc) return rc;
+        double *part = (double *)wsp, *mn = part + (size_t)npart * m;
+        const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
+        hipLaunchKernelGGL((ws_tail_kernel<R2, 2>), dim3(npart, nrb2), dim3(256), wt_lds_bytes<R2>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
+                           out, vsq, part, mn, (int *)nullptr);
+        hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
+                           (const double *)mn, diag, out, vsq);
+        gpr_prof_end(st, pid2);
+        const hipError_t le = hipGetLastError();
+        gpr_dev_free(wsp, st);
+        if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
     const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
-    hipLaunchKernelGGL((ws_tail_kernel<R, false>), dim3(nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq,
+    hipLaunchKernelGGL((ws_tail_kernel<R, 0>), dim3(nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq,
                        (double *)nullptr, (double *)nullptr, (int *)nullptr);
     gpr_prof_end(st, pid);
     LAUNCH_CHECK("ws_tail");
