@@ -5,15 +5,18 @@ Metric (BASELINE.json): GPR predict E+F+sigma structures/sec (+ fit ms) at N_tra
 Workload (BASELINE.json configs[2], SURVEY.md section 8d "cfg3"): 2000 training force environments
 (+ 63 energy points) of seeded synthetic 32-atom fcc Pd cells, SO3(nmax=3, lmax=4, rcut=5), Dot-product
 kernel with force derivatives; one step = predict energy, forces and both standard deviations for a
-batch of 64 synthetic NEB images (descriptor -> K_trans -> K_trans alpha -> L^-1 K_trans^T -> variance),
-inputs resident on the host as ASE-like structures, model resident in HBM.
+batch of 64 synthetic NEB images: neighbour search -> descriptor -> feature rows -> weight-space mean and
+variance for the Dot kernel at zeta = 2 (descriptor -> K_trans -> K_trans alpha -> L^-1 K_trans^T -> variance
+with --kernel RBF), inputs resident on the host as ASE-like structures, model resident in HBM, results
+back on the host.
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
-One JSON line on stdout (rank 0).  Extra objects: "roofline" for the dominant kernel (the force-force
-covariance block, FP64 MFMA bound) and "cpu_baseline" (the reference's CPU natives -- oracle/_ref if
-present, else the oracle's C port -- timed on a bounded sample of the same predict workload on the
-host cores).
+One JSON line on stdout (rank 0).  Extra objects: "roofline" for the kernel with the largest summed HIP-event
+time of the timed region (plus the same figures for every profiled kernel of the step under "per_kernel" and,
+for the Dot run, the same step through the row-pair kernels under "pair_route") and "cpu_baseline" (the
+reference's CPU natives -- oracle/_ref if present, else the oracle's C port -- timed on a bounded sample of
+the same predict workload on the host cores).
 """
 import argparse
 import json
