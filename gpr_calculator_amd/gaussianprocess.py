@@ -32,6 +32,10 @@ from .kernels.Dot_mb import Dot_mb
 from .kernels.RBF_mb import RBF_mb
 from .kernels._common import n_points
 from .neighbors import fixed_indices, has_fixed_atoms
+try:                                     # host-side marshalling helper (CPython extension built next to libgprhip.so)
+    from . import _pygather
+except ImportError:
+    _pygather = None
 from .parallel import Comm
 from .utilities import (convert_train_data, list_to_tuple, metric_values, new_pt, species_numbers,
                         tuple_to_list)
@@ -819,10 +823,22 @@ class GP():
         des = self.descriptor
         if not des.derivative:
             return None
-        atom0, numbers, pos, cells, pbc = batch_arrays(mine_strucs)
+        # one pass over the structures in C when they expose plain arrays (csrc/pygather.c), the numpy route otherwise
+        got = _pygather.gather(mine_strucs) if _pygather is not None else None
+        if got is not None:
+            a0 = np.frombuffer(got[0], dtype=np.int32)
+            num = np.frombuffer(got[1], dtype=np.int32)
+            pos = np.frombuffer(got[2], dtype=np.float64)
+            cells = np.frombuffer(got[3], dtype=np.float64)
+            pbc = np.frombuffer(got[4], dtype=np.int32)
+            atom0, any_fixed = a0, got[5]
+        else:
+            atom0, numbers, pos, cells, pbc = batch_arrays(mine_strucs)
+            a0 = atom0.astype(np.int32)
+            num = numbers.astype(np.int32)
+            any_fixed = any(has_fixed_atoms(s) for s in mine_strucs)
         natoms = int(atom0[-1])
         mask, frees = None, []
-        any_fixed = any(has_fixed_atoms(s) for s in mine_strucs)
         for k, s in enumerate(mine_strucs if any_fixed else ()):
             fix = self._get_fixed_atoms(s) if has_fixed_atoms(s) else ()
             if len(fix):
@@ -842,8 +858,6 @@ class GP():
         Cinv = ws[3] if len(ws) > 3 else None
         M = None if (Cinv is not None or not return_std) else self._ws_M(ws)
         sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
-        a0 = atom0.astype(np.int32)
-        num = numbers.astype(np.int32)
         ip = lambda a: a.ctypes.data_as(_lib.c_int_p)
         dp = lambda a: a.ctypes.data_as(_lib.c_double_p)
         nout = (2 if return_std else 1) * m

@@ -112,3 +112,39 @@ def test_lj_base_potential_energy_forces_stress():
         assert abs(S[:, v].sum() - dE / V) < 1e-6 * max(1.0, abs(dE / V))
     cluster = SimpleAtoms([46, 46, 46], [[0, 0, 0], [2.7, 0, 0], [0, 2.8, 0.1]], np.eye(3) * 20.0, [False] * 3)
     assert lj.calculate(cluster)[2] is None and str(lj).startswith("LJ(") and LJ().save_dict()["rc"] == 5.0
+
+
+def test_c_gather_matches_numpy_batch_arrays():
+    """csrc/pygather.c against neighbors.batch_arrays: same concatenated arrays, fixed-atom detection, and None for
+    structures that do not expose plain buffers (the caller then takes the numpy route)"""
+    import subprocess, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        from gpr_calculator_amd import _pygather
+    except ImportError:
+        subprocess.check_call(["make", "-C", os.path.join(root, "gpr_calculator_amd", "csrc"), os.path.join(root, "gpr_calculator_amd", "_pygather.so")])
+        from gpr_calculator_amd import _pygather
+    from gpr_calculator_amd.neighbors import SimpleAtoms, batch_arrays
+    rng = np.random.default_rng(5)
+    strucs = []
+    for k in range(5):
+        n = 3 + 2 * k
+        strucs.append(SimpleAtoms(numbers=rng.choice([8, 46, 78], n), positions=rng.normal(size=(n, 3)),
+                                  cell=rng.normal(size=(3, 3)) + 5 * np.eye(3), pbc=[True, k % 2 == 0, False]))
+    a0, num, pos, cel, pbc, fixed = _pygather.gather(strucs)
+    ref = batch_arrays(strucs)
+    assert np.array_equal(np.frombuffer(a0, np.int32), ref[0]) and np.array_equal(np.frombuffer(num, np.int32), ref[1])
+    assert np.array_equal(np.frombuffer(pos, np.float64).reshape(-1, 3), ref[2])
+    assert np.array_equal(np.frombuffer(cel, np.float64).reshape(-1, 9), ref[3])
+    assert np.array_equal(np.frombuffer(pbc, np.int32).reshape(-1, 3), ref[4]) and fixed is False
+    strucs[2].fixed = np.array([1])
+    assert _pygather.gather(strucs)[5] is True
+    assert _pygather.gather([]) is not None and len(_pygather.gather([])[1]) == 0
+
+    class Listy:                                  # attributes that are not array buffers
+        numbers, positions, cell, pbc = [1, 1], [[0, 0, 0], [1, 0, 0]], np.eye(3).tolist(), [False] * 3
+    assert _pygather.gather([strucs[0], Listy()]) is None
+
+    class NonContiguous:
+        numbers = np.array([1, 1]); positions = np.zeros((3, 2)).T; cell = np.eye(3); pbc = np.zeros(3, bool)
+    assert _pygather.gather([NonContiguous()]) is None
