@@ -901,10 +901,13 @@ class GP():
             self._nbr_hint = per_atom if self._nbr_hint is None else (max(per_atom[0], self._nbr_hint[0]), max(per_atom[1], self._nbr_hint[1]))
         if host[nout] != 0.0:
             raise RuntimeError(f"neighbour table is not symmetric: {int(host[nout])} force rows missing")
+        self._last_counts = (nfree == natoms, int(atom0[1] - atom0[0]) if len(mine_strucs) and natoms == len(mine_strucs) * int(atom0[1] - atom0[0])
+                             and bool((np.diff(atom0) == atom0[1] - atom0[0]).all()) else -1)
         return host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
 
     _nbr_hint = None
     _pinned_out = None
+    _last_counts = None
     _poll_results = True
 
     native_batch = True
@@ -920,14 +923,21 @@ class GP():
         mine = list(range(rank, nb, size)) if size > 1 else list(range(nb))
         results = {}
         if mine:
-            fast = self._predict_batch_native([strucs[k] for k in mine], return_std)
+            mine_strucs = strucs if size == 1 else [strucs[k] for k in mine]
+            self._last_counts = None
+            fast = self._predict_batch_native(mine_strucs, return_std)
             if fast is not None:
                 mean, std, frees = fast
             else:
-                mean, std, frees = self._predict_batch_generic([strucs[k] for k in mine], return_std, f_tol)
+                mean, std, frees = self._predict_batch_generic(mine_strucs, return_std, f_tol)
             nS = len(mine)
-            ns_atoms = [len(strucs[k]) for k in mine]
-            uniform = all(f is None for f in frees) and len(set(ns_atoms)) == 1 and self.base_potential is None
+            if self._last_counts is not None:       # the native call has already seen whether the batch is uniform
+                all_free, n_uni = self._last_counts
+                ns_atoms = [n_uni] * nS if n_uni >= 0 else [len(strucs[k]) for k in mine]
+                uniform = all_free and n_uni >= 0 and self.base_potential is None
+            else:
+                ns_atoms = [len(strucs[k]) for k in mine]
+                uniform = all(f is None for f in frees) and len(set(ns_atoms)) == 1 and self.base_potential is None
             if uniform:
                 # same composition, nothing fixed, no base potential (an NEB band): slice the result block once
                 n = ns_atoms[0]
