@@ -38,48 +38,59 @@ static void cross3(const double *a, const double *b, double *c) {
     c[0] = a[1] * b[2] - a[2] * b[1]; c[1] = a[2] * b[0] - a[0] * b[2]; c[2] = a[0] * b[1] - a[1] * b[0];
 }
 
-// wrapped positions and the periodic image table of one structure (shared by both builders)
+// wrapped positions and the periodic image table of one structure (shared by both builders).  The cell analysis
+// (normals, volume, image counts, shift table) is kept when the next structure has the same cell and pbc -- the usual
+// case in a band of images -- and only the positions are wrapped again.
 struct nbr_geom {
     std::vector<double> wrapped, shifts;
     int nimg = 0, zero_img = 0;
     bool singular = false;
+    // cell analysis of the last call
+    bool have_cell = false, any = false;
+    double cell[9], perp[3][3], det = 0.0;
+    int pb[3] = {0, 0, 0};
 };
 
 static void nbr_geometry(int n, const double *positions, const double *cell, const int *pb, double rcut, nbr_geom &g) {
-    const bool any = pb[0] || pb[1] || pb[2];
-    g.shifts.clear(); g.nimg = 0; g.zero_img = 0; g.singular = false;     // `g` may be reused across structures
+    const bool same = g.have_cell && !g.singular && memcmp(g.cell, cell, sizeof(g.cell)) == 0 && g.pb[0] == pb[0] &&
+                      g.pb[1] == pb[1] && g.pb[2] == pb[2];
     g.wrapped.assign(positions, positions + 3 * (size_t)n);
-    int nimg[3] = {0, 0, 0};
-    if (any) {
-        double c01[3], c12[3], c20[3];
-        cross3(cell, cell + 3, c01); cross3(cell + 3, cell + 6, c12); cross3(cell + 6, cell, c20);
-        const double det = cell[0] * c12[0] + cell[1] * c12[1] + cell[2] * c12[2];
-        const double vol = std::fabs(det);
-        if (vol < 1e-12) { g.singular = true; return; }
-        const double *perp[3] = {c12, c20, c01};     // normal of the plane spanned by the other two
-        for (int k = 0; k < 3; k++)
-            if (pb[k]) {
-                const double area = std::sqrt(perp[k][0] * perp[k][0] + perp[k][1] * perp[k][1] + perp[k][2] * perp[k][2]);
-                nimg[k] = (int)std::ceil(rcut / (vol / area));
-            }
+    if (!same) {
+        g.shifts.clear(); g.nimg = 0; g.zero_img = 0; g.singular = false;
+        memcpy(g.cell, cell, sizeof(g.cell)); g.pb[0] = pb[0]; g.pb[1] = pb[1]; g.pb[2] = pb[2];
+        g.have_cell = true;
+        g.any = pb[0] || pb[1] || pb[2];
+        int nimg[3] = {0, 0, 0};
+        if (g.any) {
+            cross3(cell + 3, cell + 6, g.perp[0]); cross3(cell + 6, cell, g.perp[1]); cross3(cell, cell + 3, g.perp[2]);
+            g.det = cell[0] * g.perp[0][0] + cell[1] * g.perp[0][1] + cell[2] * g.perp[0][2];
+            const double vol = std::fabs(g.det);
+            if (vol < 1e-12) { g.singular = true; return; }
+            for (int k = 0; k < 3; k++)          // perp[k]: normal of the plane spanned by the other two cell vectors
+                if (pb[k]) {
+                    const double area = std::sqrt(g.perp[k][0] * g.perp[k][0] + g.perp[k][1] * g.perp[k][1] + g.perp[k][2] * g.perp[k][2]);
+                    nimg[k] = (int)std::ceil(rcut / (vol / area));
+                }
+        }
+        for (int a = -nimg[0]; a <= nimg[0]; a++)
+            for (int b = -nimg[1]; b <= nimg[1]; b++)
+                for (int c = -nimg[2]; c <= nimg[2]; c++) {
+                    if (a == 0 && b == 0 && c == 0) g.zero_img = g.nimg;
+                    for (int k = 0; k < 3; k++) g.shifts.push_back(a * cell[k] + b * cell[3 + k] + c * cell[6 + k]);
+                    g.nimg++;
+                }
+    }
+    if (g.any)
         for (int i = 0; i < n; i++) {
             double *p = &g.wrapped[3 * i];
             double f[3];
-            for (int k = 0; k < 3; k++) f[k] = (p[0] * perp[k][0] + p[1] * perp[k][1] + p[2] * perp[k][2]) / det;
+            for (int k = 0; k < 3; k++) f[k] = (p[0] * g.perp[k][0] + p[1] * g.perp[k][1] + p[2] * g.perp[k][2]) / g.det;
             for (int k = 0; k < 3; k++)
                 if (pb[k]) {
                     const double fl = std::floor(f[k]);
                     for (int c = 0; c < 3; c++) p[c] -= fl * cell[3 * k + c];
                 }
         }
-    }
-    for (int a = -nimg[0]; a <= nimg[0]; a++)
-        for (int b = -nimg[1]; b <= nimg[1]; b++)
-            for (int c = -nimg[2]; c <= nimg[2]; c++) {
-                if (a == 0 && b == 0 && c == 0) g.zero_img = g.nimg;
-                for (int k = 0; k < 3; k++) g.shifts.push_back(a * cell[k] + b * cell[3 + k] + c * cell[6 + k]);
-                g.nimg++;
-            }
 }
 
 // per-structure result (structure-local pair / row numbering), merged afterwards
