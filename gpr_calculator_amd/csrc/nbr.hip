@@ -32,6 +32,7 @@ struct gpr_nbr {
     double *d_vec = nullptr, *d_w = nullptr;
     int *d_rp0 = nullptr, *d_self = nullptr, *d_seq = nullptr, *d_err = nullptr;
     bool capped = false;                        // P, S are capacities; the true sizes live in d_err[1..3] only
+    bool seq_in_vec = false;                    // d_seq shares d_vec's allocation (capped build)
 };
 
 static void cross3(const double *a, const double *b, double *c) {
@@ -267,6 +268,14 @@ __global__ void __launch_bounds__(64) nbr_centre_kernel(nbrk_args a) {
     if (!FILL && lane == 0) { a.cnt_pairs[i] = pair_run; a.cnt_rows[i] = row_run; }
 }
 
+// geometry blob from page-locked host memory to the device by a kernel (a copy-engine transfer costs ~20 us of queue
+// hand-over before the first compute kernel may start); also clears the missing-row counter
+__global__ void __launch_bounds__(256) nbr_upload_kernel(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16, int *err) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n16) dst[i] = src[i];
+    if (i == 0) err[0] = 0;
+}
+
 // exclusive scans of the per-centre counts: off = [cr0 (n+1) | cp0 (n+1)]; one workgroup.
 // info = [overflow, pairs, rows] (true totals).  Capped build (cap_rows > 0): the arrays downstream were sized from a
 // guess; when the totals exceed it every offset is zeroed -- each centre then has no pairs and no rows, so whatever is
@@ -426,10 +435,23 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     auto fail = [&](int code) { gpr_nbr_destroy(nb); return code; };
     int rc;
     void *p;
-    if ((rc = gpr_dev_alloc(&p, b_total + 16, st))) return fail(rc);
+    // one allocation for [geometry blob | offsets and counters | self rows]
+    const size_t sz_in = (b_total + 16 + 255) / 256 * 256, sz_off = ((size_t)(4 * natoms + 8) * sizeof(int) + 255) / 256 * 256;
+    if ((rc = gpr_dev_alloc(&p, sz_in + sz_off + (size_t)std::max(natoms, 1) * sizeof(int), st))) return fail(rc);
     nb->d_in = (char *)p;
-    if (b_total) {
-        hipError_t e = hipMemcpyAsync(nb->d_in, bp, b_total, hipMemcpyHostToDevice, st);
+    nb->d_off = (int *)(nb->d_in + sz_in);      // [cr0 | cp0 | cnt_rows | cnt_pairs | err | overflow, pairs, rows]
+    nb->d_self = (int *)(nb->d_in + sz_in + sz_off);
+    int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
+    nb->d_err = cnt_pairs + natoms;
+    {
+        void *src_dev = nullptr;
+        hipError_t e = hipHostGetDevicePointer(&src_dev, sb.p, 0);
+        if (e == hipSuccess) {
+            const size_t n16 = (b_total + 15) / 16;
+            hipLaunchKernelGGL(nbr_upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint4 *)src_dev,
+                               (uint4 *)nb->d_in, n16, nb->d_err);
+            e = hipGetLastError();
+        }
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: upload failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
     }
@@ -439,12 +461,6 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
     nb->d_sid = nb->d_numbers + natoms;
     nb->d_atom0 = nb->d_sid + natoms;
-    if ((rc = gpr_dev_alloc(&p, (size_t)(4 * natoms + 8) * sizeof(int), st))) return fail(rc);
-    nb->d_off = (int *)p;                       // [cr0 | cp0 | cnt_rows | cnt_pairs | err | overflow, pairs, rows]
-    int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
-    nb->d_err = cnt_pairs + natoms;
-    if ((rc = gpr_dev_alloc(&p, (size_t)std::max(natoms, 1) * sizeof(int), st))) return fail(rc);
-    nb->d_self = (int *)p;
 
     nbrk_args a{};
     a.wpos = nb->d_wpos; a.shift = nb->d_shift; a.numbers = nb->d_numbers; a.sid = nb->d_sid; a.sinfo = nb->d_sinfo;
@@ -454,12 +470,11 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         // sizes guessed by the caller: everything is queued without waiting for the count pass; the true sizes and the
         // overflow flag stay on the device (gpr_nbr_info_to)
         nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;
-        if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double), st))) return fail(rc);
+        if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double) + ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
         nb->d_vec = (double *)p; nb->d_w = nb->d_vec + 3 * (size_t)cap_pairs;
-        if ((rc = gpr_dev_alloc(&p, ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
-        nb->d_seq = (int *)p; nb->d_rp0 = nb->d_seq + 2 * (size_t)cap_rows;
-        hipError_t e = hipMemsetAsync(nb->d_err, 0, sizeof(int), st);
-        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: memset failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+        nb->d_seq = (int *)(nb->d_vec + 4 * (size_t)cap_pairs); nb->d_rp0 = nb->d_seq + 2 * (size_t)cap_rows;
+        nb->seq_in_vec = true;
+        hipError_t e;
         hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
         hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
                            cap_pairs, cap_rows, nb->d_rp0);
@@ -474,8 +489,8 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     nb->centre_row0.assign(natoms + 1, 0);
     std::vector<int> h_off(2 * (size_t)natoms + 2, 0);
     {
-        hipError_t e = hipMemsetAsync(nb->d_err, 0, sizeof(int), st);
-        if (e == hipSuccess && natoms > 0) {
+        hipError_t e = hipSuccess;
+        if (natoms > 0) {
             hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
             hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
                                0, 0, (int *)nullptr);
@@ -632,8 +647,9 @@ extern "C" int gpr_nbr_export(const gpr_nbr *nb, double *vec, double *w, int *ce
 extern "C" int gpr_nbr_destroy(gpr_nbr *nb) {
     if (!nb) return GPR_OK;
     if (nb->on_device) {      // stream-ordered frees: kernels already queued on the stream still see the arrays
-        gpr_dev_free(nb->d_in, nb->st); gpr_dev_free(nb->d_off, nb->st); gpr_dev_free(nb->d_self, nb->st);
-        gpr_dev_free(nb->d_vec, nb->st); gpr_dev_free(nb->d_seq, nb->st);
+        gpr_dev_free(nb->d_in, nb->st);               // d_off and d_self live in the same block
+        gpr_dev_free(nb->d_vec, nb->st);
+        if (!nb->seq_in_vec) gpr_dev_free(nb->d_seq, nb->st);
     }
     delete nb;
     return GPR_OK;

@@ -53,19 +53,29 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     const double *d_vec, *d_w; const int *d_cp0, *d_cr0, *d_rp0, *d_self, *d_seq, *d_num, *d_atom0;
     if ((rc = gpr_nbr_device_arrays(nb, &d_vec, &d_w, &d_cp0, &d_cr0, &d_rp0, &d_self, &d_seq, &d_num, &d_atom0))) return cleanup(rc);
 
-    // force points: every free atom; its rows are found on the device (gpr_nbr_force_rows)
+    // one arena for everything this call needs besides the neighbour table: [psi | diag | x | dxdr | row indices | moving
+    // atoms and their row offsets] -- a single stream-ordered allocation, so the launches below go out back to back
     void *p;
-    int frows = S;
+    const int frows = S;                        // bound on the force rows (the regrouping kernel stops at the true total)
+    auto up = [](size_t bytes) { return (bytes + 255) / 256 * 256; };
+    const size_t sz_psi = up((size_t)m * F * sizeof(double)), sz_diag = up(want_std ? (size_t)m * sizeof(double) : 0),
+                 sz_x = up((size_t)std::max(natoms, 1) * d * sizeof(double)), sz_dxdr = up((size_t)std::max(S, 1) * d * 3 * sizeof(double)),
+                 sz_idx = up((size_t)std::max(frows, 1) * 2 * sizeof(int)), sz_meta = up(free_mask ? (2 * (size_t)nfree + 2) * sizeof(int) : 0);
+    if ((rc = dalloc(sz_psi + sz_diag + sz_x + sz_dxdr + sz_idx + sz_meta, &p))) return cleanup(rc);
+    char *arena = (char *)p;
+    double *d_psi = (double *)arena, *d_diag = want_std ? (double *)(arena + sz_psi) : nullptr, *d_q = nullptr;
+    double *d_x = (double *)(arena + sz_psi + sz_diag), *d_dxdr = (double *)(arena + sz_psi + sz_diag + sz_x);
+    int *d_rowidx = (int *)(arena + sz_psi + sz_diag + sz_x + sz_dxdr), *d_xidx = d_rowidx + std::max(frows, 1);
+    int *d_meta = (int *)(arena + sz_psi + sz_diag + sz_x + sz_dxdr + sz_idx);
+
+    // force points: every free atom; its rows are found on the device (gpr_nbr_force_rows)
     const int *d_fatoms = nullptr, *d_frow0 = nullptr;
     if (free_mask) {
-        // list of moving atoms up, their row offsets by a device scan (frows stays the bound S: the regrouping kernel
-        // stops at the true total)
+        // list of moving atoms up, their row offsets by a device scan
         std::vector<int> fatoms((size_t)std::max(nfree, 1));
         int k = 0;
         for (int a = 0; a < natoms; a++)
             if (free_mask[a]) fatoms[k++] = a;
-        if ((rc = dalloc((2 * (size_t)nfree + 2) * sizeof(int), &p))) return cleanup(rc);
-        int *d_meta = (int *)p;
         if (nfree > 0) {
             hipError_t e = hipMemcpyAsync(d_meta, fatoms.data(), (size_t)nfree * sizeof(int), hipMemcpyHostToDevice, st);   // pageable: staged before return
             if (e != hipSuccess) { gpr_set_error("gpr_predict_dot2_batch: upload failed: %s", hipGetErrorString(e)); return cleanup(GPR_ERR_HIP); }
@@ -73,28 +83,13 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         if ((rc = gpr_nbr_point_rows(nb, nfree, d_meta, d_meta + nfree))) return cleanup(rc);
         d_fatoms = d_meta; d_frow0 = d_meta + nfree;
     }
-    int *d_rowidx = nullptr, *d_xidx = nullptr;
-    if ((rc = dalloc((size_t)std::max(frows, 1) * 2 * sizeof(int), &p))) return cleanup(rc);
-    d_rowidx = (int *)p; d_xidx = d_rowidx + std::max(frows, 1);
     if ((rc = gpr_nbr_force_rows(nb, nfree, d_fatoms, d_frow0, frows, d_rowidx, d_xidx))) return cleanup(rc);
 
     // descriptor
-    double *d_x = nullptr, *d_dxdr = nullptr;
-    if ((rc = dalloc((size_t)std::max(natoms, 1) * d * sizeof(double), &p))) return cleanup(rc);
-    d_x = (double *)p;
-    if ((rc = dalloc((size_t)std::max(S, 1) * d * 3 * sizeof(double), &p))) return cleanup(rc);
-    d_dxdr = (double *)p;
     if ((rc = gpr_so3_power_spectrum(stream, nmax, lmax, rcut, alpha, nseg, ncheb, so3_table, natoms, P, S, d_vec, d_w,
                                      d_cp0, d_cr0, d_rp0, d_self, d_x, d_dxdr))) return cleanup(rc);
 
     // feature rows [energies ; forces] and prior variances
-    double *d_psi = nullptr, *d_diag = nullptr, *d_q = nullptr;
-    if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);
-    d_psi = (double *)p;
-    if (want_std) {
-        if ((rc = dalloc((size_t)m * sizeof(double), &p))) return cleanup(rc);
-        d_diag = (double *)p;
-    }
     if ((rc = gpr_dot2_features_ef(stream, d, nstruct, d_atom0, nfree, free_mask ? d_frow0 : d_cr0, d_xidx, d_rowidx, d_x, d_dxdr,
                                    d_num, ns, species_host, (int)extra.size(), extra.data(), sigma, sigma0, d_psi, F, d_diag)))
         return cleanup(rc);
