@@ -81,6 +81,8 @@ _L1_SIGNATURES = {
     "gpr_gemm_nt_lower": ([_vp, _i, _i, _d, _vp, _ll, _vp, _ll, _vp, _ll], _i),
     "gpr_dot2_features_ef": ([_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, c_int_p, _i, c_int_p, _d, _d, _vp, _ll, _vp], _i),
     "gpr_ws_tail": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _d], _i),
+    "gpr_ws_tail_status": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _vp, _vp, _d, _vp, _vp], _i),
+    "gpr_nbr_info_ptr": ([_vp], _vp),
     "gpr_rowdot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
     "gpr_frob_dot": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
 }

@@ -659,16 +659,31 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
     }
 }
 
-// second launch of the paired scheme: parts added in order, mean and variance written
-__global__ void ws_tail_combine_kernel(int m, int npart, const double *__restrict__ part, const double *__restrict__ mn,
-                                       const double *__restrict__ diag, double *__restrict__ out, double vsq) {
+// second launch of the paired scheme: parts added in order, mean and variance written.  With status_dst the workgroup
+// that finishes last (counter) also delivers the caller's four status words (ints -> doubles behind the results) after
+// every workgroup has made its results visible system-wide: a host polling those words in page-locked memory may read
+// the results as soon as it sees them, and no separate launch is needed for them
+__global__ void __launch_bounds__(256) ws_tail_combine_kernel(int m, int npart, const double *__restrict__ part,
+                                                              const double *__restrict__ mn, const double *__restrict__ diag,
+                                                              double *__restrict__ out, double vsq, const int *status_src,
+                                                              double *status_dst, int *done) {
+    __shared__ int s_last;
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
-    if (row >= m) return;
-    double q2 = 0.0;
-    for (int x = 0; x < npart; x++) q2 += part[(size_t)x * m + row];
-    out[row] = mn[row];
-    out[m + row] = fmax(diag[row] - vsq * (mn[(size_t)m + row] - q2), 0.0);
+    if (row < m) {
+        double q2 = 0.0;
+        for (int x = 0; x < npart; x++) q2 += part[(size_t)x * m + row];
+        out[row] = mn[row];
+        out[m + row] = fmax(diag[row] - vsq * (mn[(size_t)m + row] - q2), 0.0);
+    }
+    if (!status_dst) return;
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last && threadIdx.x < 4) status_dst[threadIdx.x] = (double)status_src[threadIdx.x];
 }
+
+__global__ void ws_status_kernel(const int *src, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)src[threadIdx.x]; }
 
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
 __global__ void gemv_t_partial_kernel(int n, int ncols, const double *a, long long lda, const double *x, double *part,
@@ -1014,9 +1029,24 @@ extern "C" int gpr_ws_finish(void *stream, int m, int n, const double *P, long l
 // out = [mean (m) | var (m)] of the weight-space prediction with the factored variance, one launch, Q never stored
 extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
                            const double *w, const double *diag, double *out, double vsq) {
-    if (m <= 0) return GPR_OK;
-    GPR_REQUIRE(n > 0 && out && P && Cinv && w && diag && ldp >= n && ldc >= n && vsq > 0.0, "gpr_ws_tail: bad arguments");
+    return gpr_ws_tail_status(stream, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq, nullptr, nullptr);
+}
+
+// same, and afterwards status_dst[0..3] = (double)status_src[0..3] (device ints, e.g. the counters of a neighbour table):
+// written strictly after the results, by the kernel that wrote them last where that is possible
+extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                                  const double *w, const double *diag, double *out, double vsq, const int *status_src,
+                                  double *status_dst) {
     hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE((status_src == nullptr) == (status_dst == nullptr), "gpr_ws_tail_status: status source and destination go together");
+    auto status_only = [&]() {
+        if (!status_dst) return GPR_OK;
+        hipLaunchKernelGGL(ws_status_kernel, dim3(1), dim3(64), 0, st, status_src, status_dst);
+        LAUNCH_CHECK("ws_status");
+        return GPR_OK;
+    };
+    if (m <= 0) return status_only();
+    GPR_REQUIRE(n > 0 && out && P && Cinv && w && diag && ldp >= n && ldc >= n && vsq > 0.0, "gpr_ws_tail: bad arguments");
     constexpr int R = WT_ROWS;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1042,7 +1072,7 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
         if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
-        return GPR_OK;
+        return status_only();
     }
     if (ncb >= 2) {
         // many rows: 64-row workgroups take column blocks x and ncb - 1 - x (equal work for every workgroup, half the
@@ -1055,14 +1085,19 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
         }
         const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
         void *wsp;
-        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double), st);
+        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double) + 16, st);
         if (rc) return rc;
         double *part = (double *)wsp, *mn = part + (size_t)npart * m;
+        int *done = (int *)(mn + 2 * (size_t)m);
+        if (status_dst) {
+            const hipError_t me = hipMemsetAsync(done, 0, sizeof(int), st);
+            if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
+        }
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R2, 2>), dim3(npart, nrb2), dim3(256), wt_lds_bytes<R2>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
                            out, vsq, part, mn, (int *)nullptr);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
-                           (const double *)mn, diag, out, vsq);
+                           (const double *)mn, diag, out, vsq, status_src, status_dst, done);
         gpr_prof_end(st, pid2);
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
@@ -1074,7 +1109,7 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
                        (double *)nullptr, (double *)nullptr, (int *)nullptr);
     gpr_prof_end(st, pid);
     LAUNCH_CHECK("ws_tail");
-    return GPR_OK;
+    return status_only();
 }
 
 // C[m, n] = alpha A[m, n] B^T with B n x n lower triangular: the k range of every column block stops at its diagonal block

@@ -584,6 +584,8 @@ __global__ void nbr_status_kernel(const int *err, double *dst) { dst[0] = (doubl
 __global__ void nbr_info_kernel(const int *err, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)err[threadIdx.x]; }
 }
 
+extern "C" const int *gpr_nbr_info_ptr(const gpr_nbr *nb) { return (nb && nb->on_device) ? nb->d_err : nullptr; }
+
 // [missing force rows, overflow, pairs, rows] as doubles into dst[0..3] on the handle's stream (see gpr_nbr_status_to)
 extern "C" int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev) {
     GPR_REQUIRE(nb && nb->on_device && dst_dev, "gpr_nbr_info_to: needs a device-built handle and a device pointer");

@@ -95,7 +95,10 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         return cleanup(rc);
     // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0); with C^-1 at hand the factored form in one launch
     if (want_std && Cinv_dev) {
-        if ((rc = gpr_ws_tail(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma))) return cleanup(rc);
+        // the tail delivers the status words behind the results itself (no separate launch)
+        if ((rc = gpr_ws_tail_status(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma,
+                                     gpr_nbr_info_ptr(nb), out_dev + 2 * m))) return cleanup(rc);
+        return cleanup(GPR_OK);
     } else {
         if (want_std) {
             if ((rc = dalloc((size_t)m * F * sizeof(double), &p))) return cleanup(rc);

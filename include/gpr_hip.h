@@ -248,6 +248,8 @@ int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstruct, const 
                                 int cap_pairs, int cap_rows);
 /* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
 int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
+/* the four device ints gpr_nbr_info_to converts (for kernels that deliver them themselves, gpr_ws_tail_status) */
+const int *gpr_nbr_info_ptr(const gpr_nbr *nb);
 
 /* ------------------------------------------------------------------ SO(3) power-spectrum descriptor */
 /* Tables of one descriptor configuration, built on the device once: piecewise Chebyshev coefficients (nseg
@@ -333,6 +335,11 @@ int gpr_ws_finish(void *stream, int m, int n, const double *P, long long ldp, co
  * squares are kept (no m x n intermediate). */
 int gpr_ws_tail(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
                 const double *w, const double *diag, double *out, double vsq);
+/* gpr_ws_tail followed by status_dst[0..3] = (double)status_src[0..3] (device ints, e.g. gpr_nbr_info_ptr): the words are
+ * written strictly after the results -- by the kernel that writes the results last where the launch shape allows it --
+ * so a host that polls them in page-locked memory may read the results as soon as it sees them */
+int gpr_ws_tail_status(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                       const double *w, const double *diag, double *out, double vsq, const int *status_src, double *status_dst);
 int gpr_gemm_nt_lower(void *stream, int m, int n, double alpha, const double *a, long long lda, const double *b_lower,
                       long long ldb, double *c, long long ldc);
 /* out[0] = sum_ij a[i*lda+j] * b[i*ldb+j] over an m x n window (trace terms of the LML gradient,
