@@ -172,7 +172,10 @@ def main():
         step()
     comm.barrier()
     torch.cuda.synchronize()
-    dev.profile_enable(True)
+    # HIP events on the launch stream around every 4th launch of each kernel kind of the timed region (around every one
+    # costs 6 % of a 0.35 ms step in event records alone); RBF steps are 67 ms, every launch carries events there
+    sample = 4 if (args.kernel == "Dot" and args.steps >= 16) else 1
+    dev.profile_enable(sample)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
@@ -239,7 +242,7 @@ def main():
                 traffic = None
         roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
-                    "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "flop_per_step": flops,
+                    "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "event_sampling": sample, "flop_per_step": flops,
                     "work_unit": unit_note,
                     "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
                     # the same figures for every profiled kernel kind of the step (the top two are often within a few

@@ -69,6 +69,7 @@ _L1_SIGNATURES = {
     "gpr_set_shard": ([_i, _i], _i),
     "gpr_profile_enable": ([_i], _i),
     "gpr_profile_fetch": ([c_double_p, c_int_p], _i),
+    "gpr_profile_counts": ([c_int_p], _i),
     "gpr_so3_power_spectrum": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _i] + [_vp] * 8, _i),
     "gpr_so3_power_spectrum_stress": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, _i] + [_vp] * 11, _i),
     "gpr_predict_dot2_batch": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _i,

@@ -441,8 +441,11 @@ static hipEvent_t prof_event() {
     }
     return g_event_pool[g_event_next++];
 }
+static thread_local int g_prof_period = 1;
+static thread_local int g_prof_seen[GPR_PROF_NKINDS];
 int gpr_prof_begin(hipStream_t st, int kind) {
     if (!g_prof_on) return -1;
+    if ((g_prof_seen[kind]++) % g_prof_period != 0) return -1;          // sampled: every period-th launch of a kind
     prof_rec r{kind, prof_event(), prof_event()};
     if (!r.start || !r.stop) return -1;
     (void)hipEventRecord(r.start, st);
@@ -455,6 +458,8 @@ void gpr_prof_end(hipStream_t st, int id) {
 
 extern "C" int gpr_profile_enable(int on) {
     g_prof_on = on != 0;
+    g_prof_period = on > 1 ? on : 1;
+    for (int k = 0; k < GPR_PROF_NKINDS; k++) g_prof_seen[k] = 0;
     g_prof.clear();
     g_event_next = 0;
     if (on && g_event_pool.size() < 4096) {          // enough for a long timed region without a create inside it
@@ -480,5 +485,11 @@ extern "C" int gpr_profile_fetch(double *ms_by_mode, int *launches_by_mode) {
     }
     g_prof.clear();
     g_event_next = 0;
+    return GPR_OK;
+}
+
+// launches of every kind seen since gpr_profile_enable, recorded or not (with sampling the two differ)
+extern "C" int gpr_profile_counts(int *launches_seen_by_kind) {
+    for (int k = 0; k < GPR_PROF_NKINDS; k++) launches_seen_by_kind[k] = g_prof_seen[k];
     return GPR_OK;
 }

@@ -346,13 +346,19 @@ def profile_enable(on=True):
     check(_lib.lib().gpr_profile_enable(int(on)), "gpr_profile_enable")
 
 
-def profile_fetch():
-    """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable()"""
+def profile_fetch(scaled=True):
+    """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable().  With a
+    sampling period (profile_enable(n), n > 1) only every n-th launch of a kind carries events; scaled=True returns
+    the recorded time scaled to all launches seen (mean recorded launch x launches seen) and the launches seen."""
     names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack", "gemv")
+    seen = (C.c_int * len(names))()
+    check(_lib.lib().gpr_profile_counts(seen), "gpr_profile_counts")
     ms = (C.c_double * len(names))()
     n = (C.c_int * len(names))()
     check(_lib.lib().gpr_profile_fetch(ms, n), "gpr_profile_fetch")
-    return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+    if not scaled:
+        return {k: (ms[i], n[i]) for i, k in enumerate(names)}
+    return {k: ((ms[i] / n[i] * seen[i]) if n[i] else 0.0, seen[i]) for i, k in enumerate(names)}
 
 
 def dot2_features(pset, species, sigma0, out=None):

@@ -187,6 +187,9 @@ int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double
  * records. */
 int gpr_profile_enable(int on);
 int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
+/* gpr_profile_enable(n) with n > 1 records every n-th launch of a kind only (events cost host time inside the region
+ * they measure); gpr_profile_counts gives the launches seen since then, recorded or not */
+int gpr_profile_counts(int *launches_seen_by_kind);
 
 /* Multi-GPU sharding of the block calls issued from this host thread: with (nshards, shard) set, a
  * gpr_block_* call evaluates only the point-pair tasks t with t % nshards == shard and leaves every

@@ -22,6 +22,7 @@ def declared_functions():
 def built_lib():
     if not os.path.exists(LIB):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "gpr_calculator_amd", "csrc"), "-j4"])
+    import torch  # noqa: F401  -- like the package: torch's HIP runtime is resolved first, the library binds to the same one
     return ctypes.CDLL(LIB)
 
 
