@@ -60,6 +60,8 @@ _L1_SIGNATURES = {
     "gpr_nbr_point_rows": ([_vp, _i, _vp, _vp], _i),
     "gpr_nbr_status_to": ([_vp, _vp], _i),
     "gpr_nbr_info_to": ([_vp, _vp], _i),
+    "gpr_nbr_build_device_extra": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i, _i, _i, _i, c_int_p], _i),
+    "gpr_nbr_extra_ptr": ([_vp], _vp),
     "gpr_nbr_build_device_capped": ([C.POINTER(_vp), _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i, _i, _i], _i),
     "gpr_nbr_build": ([C.POINTER(_vp), _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _d, _i], _i),
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),

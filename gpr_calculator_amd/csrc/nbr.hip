@@ -33,6 +33,7 @@ struct gpr_nbr {
     int *d_rp0 = nullptr, *d_self = nullptr, *d_seq = nullptr, *d_err = nullptr;
     bool capped = false;                        // P, S are capacities; the true sizes live in d_err[1..3] only
     bool seq_in_vec = false;                    // d_seq shares d_vec's allocation (capped build)
+    const int *d_extra = nullptr;               // caller's extra ints uploaded with the geometry (or NULL)
 };
 
 static void cross3(const double *a, const double *b, double *c) {
@@ -379,7 +380,7 @@ thread_local int g_stage_next = 0;
 
 static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                  const double *cells, const int *pbc, const int *numbers, double rcut,
-                                 int weight_on, int cap_pairs, int cap_rows) {
+                                 int weight_on, int cap_pairs, int cap_rows, int n_extra = 0, const int *extra = nullptr) {
     GPR_REQUIRE(out && atom0 && (nstruct == 0 || (positions && cells && pbc && numbers)), "gpr_nbr_build_device: null pointer");
     GPR_REQUIRE(rcut > 0.0, "gpr_nbr_build_device: rcut must be positive");
     hipStream_t st = (hipStream_t)stream;
@@ -403,7 +404,8 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     const size_t b_wpos = wpos.size() * 8, b_shift = shifts.size() * 8, b_sinfo = sinfo.size() * sizeof(nbr_sinfo),
                  b_num = (size_t)natoms * 4;
     const size_t b_a0 = (size_t)(nstruct + 1) * 4;
-    const size_t b_total = b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0;
+    const size_t b_extra = (size_t)n_extra * 4;         // caller's ints riding along with the blob (gpr_nbr_extra_ptr)
+    const size_t b_total = b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0 + b_extra;
     // the blob is assembled in page-locked memory (two buffers used in turn, each guarded by the event of its last
     // copy): the upload is then a real asynchronous copy instead of a staged one
     stage_buf &sb = g_stage[g_stage_next];
@@ -429,6 +431,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     if (b_sinfo) memcpy(bp + b_wpos + b_shift, sinfo.data(), b_sinfo);
     if (b_num) { memcpy(bp + b_wpos + b_shift + b_sinfo, numbers, b_num); memcpy(bp + b_wpos + b_shift + b_sinfo + b_num, sid.data(), b_num); }
     memcpy(bp + b_wpos + b_shift + b_sinfo + 2 * b_num, atom0, b_a0);
+    if (b_extra) memcpy(bp + b_wpos + b_shift + b_sinfo + 2 * b_num + b_a0, extra, b_extra);
 
     gpr_nbr *nb = new gpr_nbr();
     nb->on_device = true; nb->st = st; nb->nstruct = nstruct; nb->natoms = natoms;
@@ -461,6 +464,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
     nb->d_sid = nb->d_numbers + natoms;
     nb->d_atom0 = nb->d_sid + natoms;
+    nb->d_extra = n_extra ? nb->d_atom0 + nstruct + 1 : nullptr;
 
     nbrk_args a{};
     a.wpos = nb->d_wpos; a.shift = nb->d_shift; a.numbers = nb->d_numbers; a.sid = nb->d_sid; a.sinfo = nb->d_sinfo;
@@ -535,6 +539,18 @@ extern "C" int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstr
     GPR_REQUIRE(cap_pairs > 0 && cap_rows > 0, "gpr_nbr_build_device_capped: capacities must be positive");
     return nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows);
 }
+
+// builders with n_extra caller ints appended to the geometry upload (they reach the device with it, no copy of their own);
+// cap_pairs = cap_rows = 0 selects the exact, synchronising build
+extern "C" int gpr_nbr_build_device_extra(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                          const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
+                                          int cap_pairs, int cap_rows, int n_extra, const int *extra_host) {
+    GPR_REQUIRE(n_extra >= 0 && (n_extra == 0 || extra_host), "gpr_nbr_build_device_extra: bad extra payload");
+    GPR_REQUIRE((cap_pairs > 0) == (cap_rows > 0), "gpr_nbr_build_device_extra: capacities go together");
+    return nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows,
+                                 n_extra, extra_host);
+}
+extern "C" const int *gpr_nbr_extra_ptr(const gpr_nbr *nb) { return (nb && nb->on_device) ? nb->d_extra : nullptr; }
 
 extern "C" int gpr_nbr_device_arrays(const gpr_nbr *nb, const double **vec, const double **w, const int **centre_pair0,
                                      const int **centre_row0, const int **row_pair0, const int **self_row,

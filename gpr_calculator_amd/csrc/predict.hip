@@ -36,9 +36,15 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     // capacities guessed by the caller (from the sizes an earlier call reported): nothing below waits for the device
     gpr_nbr *nb = nullptr;
     const bool capped = cap_pairs > 0 && cap_rows > 0 && natoms > 0;
-    int rc = capped ? gpr_nbr_build_device_capped(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
-                                                  cap_pairs, cap_rows)
-                    : gpr_nbr_build_device(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on);
+    // the list of moving atoms (fixed atoms present) travels with the geometry upload
+    std::vector<int> fatoms;
+    if (free_mask) {
+        fatoms.reserve((size_t)nfree);
+        for (int a = 0; a < natoms; a++)
+            if (free_mask[a]) fatoms.push_back(a);
+    }
+    int rc = gpr_nbr_build_device_extra(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
+                                        capped ? cap_pairs : 0, capped ? cap_rows : 0, (int)fatoms.size(), fatoms.data());
     if (rc) return rc;
     std::vector<void *> temps;
     auto cleanup = [&](int code) {
@@ -60,7 +66,7 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     auto up = [](size_t bytes) { return (bytes + 255) / 256 * 256; };
     const size_t sz_psi = up((size_t)m * F * sizeof(double)), sz_diag = up(want_std ? (size_t)m * sizeof(double) : 0),
                  sz_x = up((size_t)std::max(natoms, 1) * d * sizeof(double)), sz_dxdr = up((size_t)std::max(S, 1) * d * 3 * sizeof(double)),
-                 sz_idx = up((size_t)std::max(frows, 1) * 2 * sizeof(int)), sz_meta = up(free_mask ? (2 * (size_t)nfree + 2) * sizeof(int) : 0);
+                 sz_idx = up((size_t)std::max(frows, 1) * 2 * sizeof(int)), sz_meta = up(free_mask ? ((size_t)nfree + 2) * sizeof(int) : 0);
     if ((rc = dalloc(sz_psi + sz_diag + sz_x + sz_dxdr + sz_idx + sz_meta, &p))) return cleanup(rc);
     char *arena = (char *)p;
     double *d_psi = (double *)arena, *d_diag = want_std ? (double *)(arena + sz_psi) : nullptr, *d_q = nullptr;
@@ -71,17 +77,10 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     // force points: every free atom; its rows are found on the device (gpr_nbr_force_rows)
     const int *d_fatoms = nullptr, *d_frow0 = nullptr;
     if (free_mask) {
-        // list of moving atoms up, their row offsets by a device scan
-        std::vector<int> fatoms((size_t)std::max(nfree, 1));
-        int k = 0;
-        for (int a = 0; a < natoms; a++)
-            if (free_mask[a]) fatoms[k++] = a;
-        if (nfree > 0) {
-            hipError_t e = hipMemcpyAsync(d_meta, fatoms.data(), (size_t)nfree * sizeof(int), hipMemcpyHostToDevice, st);   // pageable: staged before return
-            if (e != hipSuccess) { gpr_set_error("gpr_predict_dot2_batch: upload failed: %s", hipGetErrorString(e)); return cleanup(GPR_ERR_HIP); }
-        }
-        if ((rc = gpr_nbr_point_rows(nb, nfree, d_meta, d_meta + nfree))) return cleanup(rc);
-        d_fatoms = d_meta; d_frow0 = d_meta + nfree;
+        // row offsets of the moving atoms by a device scan
+        d_fatoms = nfree > 0 ? gpr_nbr_extra_ptr(nb) : d_meta;
+        if ((rc = gpr_nbr_point_rows(nb, nfree, d_fatoms, d_meta))) return cleanup(rc);
+        d_frow0 = d_meta;
     }
     if ((rc = gpr_nbr_force_rows(nb, nfree, d_fatoms, d_frow0, frows, d_rowidx, d_xidx))) return cleanup(rc);
 

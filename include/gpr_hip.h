@@ -249,6 +249,13 @@ int gpr_nbr_status_to(const gpr_nbr *nb, double *dst_dev);
 int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                 const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
                                 int cap_pairs, int cap_rows);
+/* gpr_nbr_build_device(_capped) with n_extra caller ints appended to the geometry upload (e.g. the list of moving atoms
+ * gpr_nbr_point_rows / gpr_nbr_force_rows want on the device): they arrive with it instead of through a copy of their
+ * own; cap_pairs = cap_rows = 0 selects the exact build.  gpr_nbr_extra_ptr: where they are (device), NULL if none. */
+int gpr_nbr_build_device_extra(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                               const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
+                               int cap_pairs, int cap_rows, int n_extra, const int *extra_host);
+const int *gpr_nbr_extra_ptr(const gpr_nbr *nb);
 /* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
 int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
 /* the four device ints gpr_nbr_info_to converts (for kernels that deliver them themselves, gpr_ws_tail_status) */
