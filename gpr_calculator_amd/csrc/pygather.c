@@ -1,7 +1,9 @@
 /* _pygather -- marshalling helper of the batched prediction (host side only, no model arithmetic): walks a list of
  * ase.Atoms-like objects once and concatenates numbers / positions / cell / pbc into flat buffers, the job
  * neighbors.batch_arrays does with a dozen numpy calls.  gather(strucs) returns
- *     (atom0 int32[ns+1], numbers int32[N], positions f64[3N], cells f64[9 ns], pbc int32[3 ns], any_fixed)
+ *     (atom0 int32[ns+1], numbers int32[N], positions f64[3N], cells f64[9 ns], pbc int32[3 ns], any_fixed, mask)
+ * mask: uint8[N], 0 for the atoms listed in a structure's `fixed` array, or None when nothing is fixed or the fixed
+ * atoms come as ase constraints (the caller resolves those)
  * as bytearrays (np.frombuffer views them without a copy), or None when some structure does not expose plain
  * C-contiguous array buffers (ase.Cell objects, lists, ...): the caller then takes the numpy path. */
 #define PY_SSIZE_T_CLEAN
@@ -34,8 +36,8 @@ static PyObject *gather(PyObject *self, PyObject *arg) {
     const Py_ssize_t ns = PySequence_Fast_GET_SIZE(seq);
     PyObject **items = PySequence_Fast_ITEMS(seq);
     PyObject *b_atom0 = PyByteArray_FromStringAndSize(NULL, (ns + 1) * 4), *b_cells = PyByteArray_FromStringAndSize(NULL, ns * 72),
-             *b_pbc = PyByteArray_FromStringAndSize(NULL, ns * 12), *b_num = NULL, *b_pos = NULL, *result = NULL;
-    int any_fixed = 0, plain = 1;
+             *b_pbc = PyByteArray_FromStringAndSize(NULL, ns * 12), *b_num = NULL, *b_pos = NULL, *b_mask = NULL, *result = NULL;
+    int any_fixed = 0, plain = 1, unresolved = 0;
     if (!b_atom0 || !b_cells || !b_pbc) goto done;
     int32_t *atom0 = (int32_t *)PyByteArray_AS_STRING(b_atom0);
     /* pass 1: atom counts */
@@ -75,19 +77,46 @@ static PyObject *gather(PyObject *self, PyObject *arg) {
         /* fixed atoms: SimpleAtoms.fixed (array) or a non-empty ase constraints list */
         PyObject *fx = PyObject_GetAttr(items[s], s_fixed);
         if (fx) {
-            if (fx != Py_None && PyObject_Length(fx) > 0) any_fixed = 1;
+            const Py_ssize_t nfx = fx != Py_None ? PyObject_Length(fx) : 0;
             if (PyErr_Occurred()) PyErr_Clear();
+            if (nfx > 0) {
+                any_fixed = 1;
+                Py_buffer fv;
+                int ok = 0;
+                if (PyObject_GetBuffer(fx, &fv, PyBUF_C_CONTIGUOUS | PyBUF_FORMAT) == 0) {
+                    const char c = fmt_char(&fv);
+                    if (!b_mask) {
+                        b_mask = PyByteArray_FromStringAndSize(NULL, N);
+                        if (b_mask) memset(PyByteArray_AS_STRING(b_mask), 1, (size_t)N);
+                    }
+                    if (b_mask && fv.len == nfx * fv.itemsize) {
+                        unsigned char *mk = (unsigned char *)PyByteArray_AS_STRING(b_mask) + atom0[s];
+                        ok = 1;
+                        for (Py_ssize_t i = 0; i < nfx; i++) {
+                            long long idx;
+                            if (fv.itemsize == 8 && (c == 'l' || c == 'q' || c == 'n')) idx = ((const int64_t *)fv.buf)[i];
+                            else if (fv.itemsize == 4 && (c == 'i' || c == 'l')) idx = ((const int32_t *)fv.buf)[i];
+                            else { ok = 0; break; }
+                            if (idx < 0 || idx >= n) { ok = 0; break; }
+                            mk[idx] = 0;
+                        }
+                    }
+                    PyBuffer_Release(&fv);
+                } else PyErr_Clear();
+                if (!ok) unresolved = 1;
+            }
             Py_DECREF(fx);
         } else {
             PyErr_Clear();
             PyObject *cs = PyObject_GetAttr(items[s], s_constraints);
-            if (cs) { const int t = PyObject_IsTrue(cs); if (t > 0) any_fixed = 1; if (t < 0) PyErr_Clear(); Py_DECREF(cs); }
+            if (cs) { const int t = PyObject_IsTrue(cs); if (t > 0) { any_fixed = 1; unresolved = 1; } if (t < 0) PyErr_Clear(); Py_DECREF(cs); }
             else PyErr_Clear();
         }
     }
-    if (plain) result = Py_BuildValue("(OOOOOO)", b_atom0, b_num, b_pos, b_cells, b_pbc, any_fixed ? Py_True : Py_False);
+    if (plain) result = Py_BuildValue("(OOOOOOO)", b_atom0, b_num, b_pos, b_cells, b_pbc, any_fixed ? Py_True : Py_False,
+                                      (b_mask && !unresolved) ? b_mask : Py_None);
 done:
-    Py_XDECREF(b_atom0); Py_XDECREF(b_cells); Py_XDECREF(b_pbc); Py_XDECREF(b_num); Py_XDECREF(b_pos);
+    Py_XDECREF(b_atom0); Py_XDECREF(b_cells); Py_XDECREF(b_pbc); Py_XDECREF(b_num); Py_XDECREF(b_pos); Py_XDECREF(b_mask);
     Py_DECREF(seq);
     if (!result && !PyErr_Occurred()) Py_RETURN_NONE;
     return result;

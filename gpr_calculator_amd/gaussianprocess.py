@@ -832,24 +832,29 @@ class GP():
             cells = np.frombuffer(got[3], dtype=np.float64)
             pbc = np.frombuffer(got[4], dtype=np.int32)
             atom0, any_fixed = a0, got[5]
+            cmask = got[6]
         else:
             atom0, numbers, pos, cells, pbc = batch_arrays(mine_strucs)
             a0 = atom0.astype(np.int32)
             num = numbers.astype(np.int32)
             any_fixed = any(has_fixed_atoms(s) for s in mine_strucs)
+            cmask = None
         natoms = int(atom0[-1])
-        mask, frees = None, []
-        for k, s in enumerate(mine_strucs if any_fixed else ()):
-            fix = self._get_fixed_atoms(s) if has_fixed_atoms(s) else ()
-            if len(fix):
-                if mask is None:
-                    mask = np.ones(natoms, dtype=np.uint8)
-                mask[atom0[k] + np.asarray(fix, dtype=np.int64)] = 0
-                fixset = set(int(i) for i in fix)
-                frees.append([i for i in range(int(atom0[k + 1] - atom0[k])) if i not in fixset])
-            else:
-                frees.append(None)
-        if not any_fixed:
+        mask, frees = None, None
+        if any_fixed and cmask is not None:          # the gather pass has already marked the fixed atoms
+            mask = np.frombuffer(cmask, dtype=np.uint8)
+            if mask.all():
+                mask = None
+        elif any_fixed:
+            mask = np.ones(natoms, dtype=np.uint8)
+            for k, s in enumerate(mine_strucs):
+                if has_fixed_atoms(s):
+                    fix = self._get_fixed_atoms(s)
+                    if len(fix):
+                        mask[atom0[k] + np.asarray(fix, dtype=np.int64)] = 0
+            if mask.all():
+                mask = None
+        if mask is None:
             frees = [None] * len(mine_strucs)
         nfree = natoms if mask is None else int(mask.sum())
         m = len(mine_strucs) + 3 * nfree
@@ -903,11 +908,14 @@ class GP():
             raise RuntimeError(f"neighbour table is not symmetric: {int(host[nout])} force rows missing")
         self._last_counts = (nfree == natoms, int(atom0[1] - atom0[0]) if len(mine_strucs) and natoms == len(mine_strucs) * int(atom0[1] - atom0[0])
                              and bool((np.diff(atom0) == atom0[1] - atom0[0]).all()) else -1)
+        # for the caller's scatter of the force rows: atom offsets and the global indices of the moving atoms
+        self._last_layout = (atom0, None if mask is None else np.flatnonzero(mask))
         return host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
 
     _nbr_hint = None
     _pinned_out = None
     _last_counts = None
+    _last_layout = None
     _poll_results = True
 
     native_batch = True
@@ -954,8 +962,31 @@ class GP():
                 else:
                     for s, k in enumerate(mine):
                         results[k] = (Eb[s], Fb[s], None, None)
+            layout = self._last_layout if (fast is not None and not uniform) else None
+            if layout is not None:
+                # ragged batch and / or fixed atoms: one scatter of all force rows into [natoms, 3], then per-structure views
+                atom0, free_idx = layout
+                natoms = int(atom0[-1])
+                Fall = np.zeros((natoms, 3))
+                Sall = np.zeros((natoms, 3)) if return_std else None
+                if free_idx is None:
+                    Fall[:] = mean[nS:].reshape(natoms, 3)
+                    if return_std:
+                        Sall[:] = std[nS:].reshape(natoms, 3)
+                else:
+                    Fall[free_idx] = mean[nS:].reshape(-1, 3)
+                    if return_std:
+                        Sall[free_idx] = std[nS:].reshape(-1, 3)
+                Eall = mean[:nS] * np.diff(atom0)
+                for s, k in enumerate(mine):
+                    a0, a1 = int(atom0[s]), int(atom0[s + 1])
+                    E, F = Eall[s], Fall[a0:a1]
+                    if self.base_potential is not None:
+                        e_off, f_off, _ = self.compute_base_potential(strucs[k])
+                        E, F = E + e_off, F + f_off
+                    results[k] = (E, F, std[s], Sall[a0:a1]) if return_std else (E, F, None, None)
             off = nS
-            for s, k in enumerate(mine if not uniform else ()):
+            for s, k in enumerate(mine if (not uniform and layout is None) else ()):
                 n, free_ids = len(strucs[k]), frees[s]
                 nf = 3 * (n if free_ids is None else len(free_ids))
                 E = mean[s] * n

@@ -131,14 +131,21 @@ def test_c_gather_matches_numpy_batch_arrays():
         n = 3 + 2 * k
         strucs.append(SimpleAtoms(numbers=rng.choice([8, 46, 78], n), positions=rng.normal(size=(n, 3)),
                                   cell=rng.normal(size=(3, 3)) + 5 * np.eye(3), pbc=[True, k % 2 == 0, False]))
-    a0, num, pos, cel, pbc, fixed = _pygather.gather(strucs)
+    a0, num, pos, cel, pbc, fixed, cmask = _pygather.gather(strucs)
     ref = batch_arrays(strucs)
     assert np.array_equal(np.frombuffer(a0, np.int32), ref[0]) and np.array_equal(np.frombuffer(num, np.int32), ref[1])
     assert np.array_equal(np.frombuffer(pos, np.float64).reshape(-1, 3), ref[2])
     assert np.array_equal(np.frombuffer(cel, np.float64).reshape(-1, 9), ref[3])
-    assert np.array_equal(np.frombuffer(pbc, np.int32).reshape(-1, 3), ref[4]) and fixed is False
-    strucs[2].fixed = np.array([1])
-    assert _pygather.gather(strucs)[5] is True
+    assert np.array_equal(np.frombuffer(pbc, np.int32).reshape(-1, 3), ref[4]) and fixed is False and cmask is None
+    strucs[2].fixed = np.array([1, int(np.diff(ref[0])[2]) - 1])
+    strucs[4].fixed = np.array([0], dtype=np.int32)
+    got = _pygather.gather(strucs)
+    want = np.ones(int(ref[0][-1]), np.uint8)
+    want[ref[0][2] + 1] = 0; want[ref[0][3] - 1] = 0; want[ref[0][4]] = 0
+    assert got[5] is True and np.array_equal(np.frombuffer(got[6], np.uint8), want)
+    strucs[1].fixed = np.array([99])              # out of range (or negative): the caller resolves (and reports) it
+    assert _pygather.gather(strucs)[6] is None
+    strucs[1].fixed = np.zeros(0, dtype=np.int64)
     assert _pygather.gather([]) is not None and len(_pygather.gather([])[1]) == 0
 
     class Listy:                                  # attributes that are not array buffers
