@@ -1,0 +1,287 @@
+"""Golden vectors for the GP layer, produced by the reference's OWN Python (kernels/rbf_kernel.py, dot_kernel.py,
+RBF_mb.py, Dot_mb.py, utilities.py, SO3.py, gaussianprocess.py, imported unmodified from /root/reference through
+the third-party placeholders of refshim.py) on top of the reference's own C++ (oracle/_ref).  Build container only.
+
+    python tests/golden/make_golden_gp.py            # small cases (seconds to a minute each)
+
+Outputs (data only): tests/golden/gp_wrappers.npz, tests/golden/gp_<case>.npz
+What is recorded per model case:
+  * training structures, labels, the force-point selection, hyper-parameters (inputs)
+  * the packed training dictionaries train_x exactly as GP.set_train_pts built them, y_train
+  * kernel.k_total / k_total_with_grad / diag; GP.fit(opt=False) -> L_, alpha_, _K_inv
+  * GP.log_marginal_likelihood(+gradient) at two hyper-parameter points (with and without the noise parameter)
+  * GP.predict_structure E / F / E_std / F_std for test structures (one with fixed atoms), the data dictionary
+    and K_trans / diag the reference formed inside that call (recorded through a delegating kernel proxy)
+  * GP.validate_data on the training set, GP.add_structure selection on the trained model, queue semantics,
+    the refit after the add
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim                                                     # noqa: E402
+from refshim import RefAtoms                                       # noqa: E402
+from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces  # noqa: E402
+from oracle.natives import make_case                               # noqa: E402
+
+
+class Recorder:
+    """delegates everything to the reference kernel object; remembers the last arguments / results of the calls
+    GP makes (the GP only uses the duck-typed kernel protocol, gaussianprocess.py:155-163, 875-878, 904)"""
+
+    def __init__(self, kernel):
+        object.__setattr__(self, "_k", kernel)
+        object.__setattr__(self, "calls", {})
+
+    def __getattr__(self, name):
+        attr = getattr(self._k, name)
+        if name in ("k_total", "k_total_with_stress", "diag", "k_total_with_grad"):
+            def wrapped(*a, **kw):
+                out = attr(*a, **kw)
+                self.calls[name] = (a, kw, out)
+                return out
+            return wrapped
+        return attr
+
+    def __setattr__(self, name, value):
+        setattr(self._k, name, value)
+
+    def __str__(self):
+        return str(self._k)
+
+
+def put_energy_tuple(p, key, t):
+    X, ELE, counts = t
+    p[key + "_X"], p[key + "_ELE"], p[key + "_counts"] = np.asarray(X), np.asarray(ELE), np.asarray(counts)
+
+
+def put_force_tuple(p, key, t):
+    X, dXdR, ELE, counts = t
+    p[key + "_X"], p[key + "_dXdR"], p[key + "_ELE"], p[key + "_counts"] = (
+        np.asarray(X), np.asarray(dXdR), np.asarray(ELE), np.asarray(counts))
+
+
+def put_data(p, key, data, ns, stress=False):
+    """a data dictionary as predict_structure builds it (energy tuple + object array of force tuples)"""
+    put_energy_tuple(p, key + "_energy", data["energy"])
+    put_force_tuple(p, key + "_force", ns.utilities.list_to_tuple(list(data["force"]), stress=stress))
+
+
+def atoms_of(a, fixed=()):
+    return RefAtoms(a.numbers, a.positions, a.cell, a.pbc, fixed=fixed)
+
+
+def structure_data(ns, des, t, fixed=(), stress=False):
+    """the data dictionary of GP.predict_structure (gaussianprocess.py:846-870), with the force points in a LIST
+    (upstream hands over an object ndarray, which only RBF's kef_C / kff_C pack -- rbf_kernel.py:112 -- so
+    predict_structure itself only runs with RBF_mb and stress=False)"""
+    d = des.calculate(t)
+    ele = np.array([refshim.atomic_number(s) for s in d["elements"]])
+    fdata = []
+    for i in range(len(t)):
+        if i in fixed and not stress:
+            continue
+        ids = np.argwhere(d["seq"][:, 1] == i).flatten()
+        ci = d["seq"][ids, 0]
+        dx = d["dxdr"][ids]
+        if stress:
+            r = d["rdxdr"][ids].reshape(len(ids), d["x"].shape[1], 9)[:, :, [0, 4, 8, 1, 2, 5]]
+            dx = np.concatenate((dx, r), axis=2)
+        fdata.append((d["x"][ci, :], dx, ele[ci]))
+    return {"energy": ns.utilities.list_to_tuple([(d["x"], ele)], mode="energy"), "force": fdata}
+
+
+def predict_lists(ns, gp, des, t, fixed):
+    """E, F, E_std, F_std through GP.predict on list data, assembled as gaussianprocess.py:880-911 does"""
+    data = structure_data(ns, des, t, fixed)
+    y, std = gp.predict(data, return_std=True)
+    n = len(t)
+    free = [i for i in range(n) if i not in set(fixed)]
+    F, F_std = np.zeros((n, 3)), np.zeros((n, 3))
+    F[free], F_std[free] = y[1:].reshape(-1, 3), std[1:].reshape(-1, 3)
+    return data, y[0] * n, F, std[0], F_std
+
+
+def train_points(ns, des, strucs, force_ids):
+    """the dictionary GP.set_train_pts takes, built the way extract_db does (gaussianprocess.py:783-800):
+    energy point (x, E/n, ele); force point of atom a = rows of seq with seq[:,1]==a"""
+    pts = {"energy": [], "force": [], "db": []}
+    for (atoms, E, F), fids in zip(strucs, force_ids):
+        d = des.calculate(atoms)
+        ele = np.array([refshim.atomic_number(s) for s in d["elements"]])
+        pts["energy"].append((d["x"], E / len(atoms), ele))
+        for a in fids:
+            ids = np.argwhere(d["seq"][:, 1] == a).flatten()
+            ci = d["seq"][ids, 0]
+            pts["force"].append((d["x"][ci, :], d["dxdr"][ids], F[a], ele[ci]))
+        pts["db"].append((atoms, E, F, True, list(fids)))
+    return pts
+
+
+def model_case(ns, name, kind, para, zeta, species, reps, n_train, force_ids, tests, noise=(0.002, 0.1),
+               stress_test=False, sigma_pos=0.08, opt_iters=0):
+    p = dict(kind=kind, para=np.asarray(para, float), zeta=float(zeta), noise_e=noise[0], noise_f=noise[1],
+             nmax=3, lmax=4, rcut=5.0, alpha=2.0, n_train=n_train)
+    des = ns.SO3.SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0, derivative=True, stress=stress_test)
+    kern = (ns.RBF_mb.RBF_mb if kind == "RBF" else ns.Dot_mb.Dot_mb)(para=list(para), zeta=zeta)
+    rec = Recorder(kern)
+    gp = ns.gaussianprocess.GP(kernel=rec, descriptor=des, noise_e=noise[0], noise_f=noise[1],
+                               log_file="/tmp/ref_gp.log")
+    strucs = []
+    for s in range(n_train):
+        a = atoms_of(fcc_cell(seed=s, reps=reps, species=species, sigma=sigma_pos))
+        E, F = lj_energy_forces(a)
+        strucs.append((a, E, F))
+        p[f"train{s}_numbers"], p[f"train{s}_positions"], p[f"train{s}_cell"], p[f"train{s}_pbc"] = (
+            a.numbers, a.positions, a.cell, a.pbc)
+        p[f"train{s}_E"], p[f"train{s}_F"] = E, F
+        p[f"train{s}_force_ids"] = np.asarray(force_ids[s], int)
+    pts = train_points(ns, des, strucs, force_ids)
+    gp.fit(pts, show=False, opt=False)
+    put_energy_tuple(p, "trainx_energy", gp.train_x["energy"])
+    put_force_tuple(p, "trainx_force", gp.train_x["force"])
+    p["y_train"], p["L"], p["alpha"], p["K_inv"] = gp.y_train, gp.L_, gp.alpha_, gp._K_inv
+    p["K"] = kern.k_total(gp.train_x)
+    Kg, dK = kern.k_total_with_grad(gp.train_x)
+    p["K_with_grad"], p["dK"] = Kg, dK
+    p["diag_train"] = kern.diag({"energy": gp.train_x["energy"],
+                                 "force": ns.utilities.tuple_to_list(gp.train_x["force"])})
+    # log-marginal likelihood and gradient: at the fit point and at a second point; then with the noise parameter
+    thetas = [list(para), [para[0] * 1.3, para[1] * 0.8]]
+    for k, th in enumerate(thetas):
+        lml, g = gp.log_marginal_likelihood(np.array(th), eval_gradient=True)
+        p[f"lml{k}_theta"], p[f"lml{k}"], p[f"lml{k}_grad"] = np.array(th), lml, g
+        p[f"lml{k}_nograd"] = gp.log_marginal_likelihood(np.array(th), eval_gradient=False)
+    gp.noise_bounds = [1e-4, 1e-1]                                   # noise_e optimised too (3 parameters)
+    th = list(para) + [0.004]
+    lml, g = gp.log_marginal_likelihood(np.array(th), eval_gradient=True)
+    p["lml_noise_theta"], p["lml_noise"], p["lml_noise_grad"], p["f_coef"] = np.array(th), lml, g, gp.f_coef
+    gp.noise_bounds = None
+    kern.update(list(para))
+    # predictions
+    for k, (seed, fixed) in enumerate(tests):
+        t = atoms_of(fcc_cell(seed=seed, reps=reps, species=species, sigma=sigma_pos), fixed=fixed)
+        if kind == "RBF":
+            E, F, S, E_std, F_std = gp.predict_structure(t, stress=False, return_std=True, f_tol=1e-12)
+            a, kw, K_trans = rec.calls["k_total"]
+            data = a[0]
+            _, E2, F2, Es2, Fs2 = predict_lists(ns, gp, des, t, fixed)       # GP.predict on the same data (f_tol 1e-10)
+            assert abs(E - E2) < 1e-9 and np.abs(F - F2).max() < 1e-9 and np.abs(F_std - Fs2).max() < 1e-9
+        else:
+            data, E, F, E_std, F_std = predict_lists(ns, gp, des, t, fixed)
+            a, kw, K_trans = rec.calls["k_total"]
+        put_data(p, f"test{k}_data", data, ns)
+        p[f"test{k}_K_trans"], p[f"test{k}_diag"] = K_trans, kern.diag(
+            {"energy": data["energy"], "force": list(data["force"])})
+        p[f"test{k}_numbers"], p[f"test{k}_positions"], p[f"test{k}_cell"], p[f"test{k}_pbc"] = (
+            t.numbers, t.positions, t.cell, t.pbc)
+        p[f"test{k}_fixed"] = np.asarray(fixed, int)
+        p[f"test{k}_E"], p[f"test{k}_F"], p[f"test{k}_E_std"], p[f"test{k}_F_std"] = E, F, E_std, F_std
+        if stress_test:
+            # GP.predict_structure(stress=True) cannot run upstream: it hands the force points over as an object
+            # ndarray, which kff_C / kef_C do not pack (rbf_kernel.py:213: isinstance(X1, list)); RBF_mb.py:210
+            # calls the path obsolete.  The kernel-level call works with a list: record k_total_with_stress on the
+            # data dictionary of gaussianprocess.py:852-865 (all atoms, dxdr ++ rdxdr[:, :, (xx,yy,zz,xy,xz,yz)]).
+            sdata = structure_data(ns, des, atoms_of(t), stress=True)
+            Kt, Kt1 = kern.k_total_with_stress(sdata, gp.get_train_x(), 1e-12)
+            p[f"test{k}_stress_K_trans"], p[f"test{k}_stress_K_trans1"] = Kt, Kt1
+            put_data(p, f"test{k}_stress_data", sdata, ns, stress=True)
+    p["n_tests"] = len(tests)
+    # validate_data on the training set
+    # (return_std=True fails upstream on the packed training tuples: RBF_mb.diag takes len() of the tuple, RBF_mb.py:88)
+    E, Ep, F, Fp = gp.validate_data()
+    p["val_E"], p["val_E_pred"], p["val_F"], p["val_F_pred"] = E, Ep, F, Fp
+    # add_structure on the trained model: selection, queue, predictions unchanged until the refit
+    new = atoms_of(fcc_cell(seed=77, reps=reps, species=species, sigma=2.5 * sigma_pos))
+    En, Fn = lj_energy_forces(new)
+    added, n_pts, errors = gp.add_structure((new, En, Fn.copy()))
+    p["add_numbers"], p["add_positions"], p["add_cell"], p["add_pbc"], p["add_E"], p["add_F"] = (
+        new.numbers, new.positions, new.cell, new.pbc, En, Fn)
+    p["add_force_in"], p["add_N_pts"] = np.asarray(added["db"][0][4], int), n_pts
+    p["add_err_E"], p["add_err_E_pred"], p["add_err_E_std"] = errors[0], errors[1], errors[2]
+    p["add_err_F"], p["add_err_F_pred"], p["add_err_F_std"] = errors[3], errors[4], errors[5]
+    p["add_counters"] = np.array([gp.N_energy, gp.N_forces, gp.N_energy_queue, gp.N_forces_queue, gp.N_queue])
+    t = atoms_of(fcc_cell(seed=tests[0][0], reps=reps, species=species, sigma=sigma_pos), fixed=tests[0][1])
+    _, E, F, E_std, F_std = predict_lists(ns, gp, des, t, tests[0][1])
+    p["queued_E"], p["queued_F_std"] = E, F_std                       # equal to test0_* (queue invisible)
+    gp.fit(show=False, opt=False)
+    p["refit_alpha"], p["refit_y_train"] = gp.alpha_, gp.y_train
+    _, E, F, E_std, F_std = predict_lists(ns, gp, des, t, tests[0][1])
+    p["refit_E"], p["refit_F"], p["refit_E_std"], p["refit_F_std"] = E, F, E_std, F_std
+    if opt_iters:
+        kern.update(list(para))
+        gp.fit(show=False, opt=True, maxiter=opt_iters)
+        p["opt_iters"], p["opt_params"] = opt_iters, np.array(kern.parameters())
+        p["opt_alpha"] = gp.alpha_
+        _, E, F, E_std, F_std = predict_lists(ns, gp, des, t, tests[0][1])
+        p["opt_E"], p["opt_F"], p["opt_E_std"], p["opt_F_std"] = E, F, E_std, F_std
+    path = os.path.join(HERE, f"gp_{name}.npz")
+    np.savez_compressed(path, **p)
+    print(f"gp_{name}.npz  N={len(p['y_train'])}  {os.path.getsize(path) / 1024:.0f} KiB  E0={p['test0_E']:.6f} "
+          f"E_std0={p['test0_E_std']:.3e}  add force_in={p['add_force_in'].tolist()}"
+          + (f"  opt -> {p['opt_params']}" if opt_iters else ""))
+
+
+def wrappers(ns):
+    """kee_C / kef_C / kff_C of both kernels: value, hyper-gradient, stress and transpose forms
+    (rbf_kernel.py:7-337, dot_kernel.py:9-270) on random rows with mixed species"""
+    c = make_case(11, 30, [5, 9, 3, 7], [6, 4, 8, 2, 5], species=(8, 46), zeta=2.0, sigma=2.5, l=1.3, sigma0=1.7)
+    p = {k: v for k, v in c.items()}
+    XE1 = (c["x1"], c["ele1"], c["counts1"].tolist())
+    XE2 = (c["x2"], c["ele2"], c["counts2"].tolist())
+    XF1 = (c["x1"], c["dx1dr"], c["ele1"], c["counts1"].tolist())
+    XF2 = (c["x2"], c["dx2dr"], c["ele2"], c["counts2"].tolist())
+    XF1s = (c["x1"], c["dx1dr9"], c["ele1"], c["counts1"].tolist())
+    s, l, s0 = c["sigma"], c["l"], c["sigma0"]
+    for zeta in (2.0, 3.0):
+        z = f"z{int(zeta)}"
+        r, d = ns.rbf_kernel, ns.dot_kernel
+        p[f"rbf_kee_{z}"] = r.kee_C(XE1, XE2, s, l, zeta)
+        p[f"rbf_kee_grad_{z}"] = np.stack(r.kee_C(XE1, XE2, s, l, zeta, grad=True))
+        p[f"rbf_kef_{z}"] = r.kef_C(XE1, XF2, s, l, zeta)
+        p[f"rbf_kef_grad_{z}"] = np.stack(r.kef_C(XE1, XF2, s, l, zeta, grad=True))
+        p[f"rbf_kef_T_{z}"] = r.kef_C(XE1, XF2, s, l, zeta, transpose=True)
+        a, b = r.kef_C(XE2, XF1s, s, l, zeta, stress=True, transpose=True)
+        p[f"rbf_kef_stress_T_{z}"], p[f"rbf_kef_stress_T1_{z}"] = a, b
+        p[f"rbf_kff_{z}"] = r.kff_C(XF1, XF2, s, l, zeta, tol=1e-12)
+        p[f"rbf_kff_grad_{z}"] = np.stack(r.kff_C(XF1, XF2, s, l, zeta, grad=True))
+        a, b = r.kff_C(XF1s, XF2, s, l, zeta, stress=True, tol=1e-12)
+        p[f"rbf_kff_stress_{z}"], p[f"rbf_kff_stress1_{z}"] = a, b
+        p[f"dot_kee_{z}"] = d.kee_C(XE1, XE2, s, s0, zeta)
+        p[f"dot_kee_grad_{z}"] = np.stack(d.kee_C(XE1, XE2, s, s0, zeta, grad=True))
+        p[f"dot_kef_{z}"] = d.kef_C(XE1, XF2, s, s0, zeta)
+        p[f"dot_kef_grad_{z}"] = np.stack(d.kef_C(XE1, XF2, s, s0, zeta, grad=True))
+        p[f"dot_kef_T_{z}"] = d.kef_C(XE1, XF2, s, s0, zeta, transpose=True)
+        a, b = d.kef_C(XE2, XF1s, s, s0, zeta, stress=True, transpose=True)
+        p[f"dot_kef_stress_T_{z}"], p[f"dot_kef_stress_T1_{z}"] = a, b
+        p[f"dot_kff_{z}"] = d.kff_C(XF1, XF2, s, s0, zeta)
+        p[f"dot_kff_grad_{z}"] = np.stack(d.kff_C(XF1, XF2, s, s0, zeta, grad=True))
+        a, b = d.kff_C(XF1s, XF2, s, s0, zeta, stress=True)
+        p[f"dot_kff_stress_{z}"], p[f"dot_kff_stress1_{z}"] = a, b
+    path = os.path.join(HERE, "gp_wrappers.npz")
+    np.savez_compressed(path, **p)
+    print("gp_wrappers.npz", os.path.getsize(path) // 1024, "KiB", len(p), "arrays")
+
+
+def main():
+    warnings.simplefilter("ignore")
+    ns = refshim.import_reference()
+    wrappers(ns)
+    f3 = [[0, 2, 3]] * 4
+    model_case(ns, "rbf_pd", "RBF", [2.5, 1.3], 2.0, (46,), 1, 4, f3, [(40, [1]), (41, [])], opt_iters=3)
+    model_case(ns, "rbf_pdpt", "RBF", [2.5, 1.3], 2.0, (46, 78), 1, 4, f3, [(40, [1]), (41, [])], stress_test=True)
+    model_case(ns, "dot_pd", "Dot", [2.0, 2.0], 2.0, (46,), 1, 4, f3, [(40, [1]), (41, [])], opt_iters=3)
+    model_case(ns, "dot_pdpt", "Dot", [2.0, 2.0], 2.0, (46, 78), 1, 4, f3, [(40, [1]), (41, [])], stress_test=True)
+    model_case(ns, "dot_z3", "Dot", [1.5, 1.2], 3.0, (46, 78), 1, 3, [[0, 1], [2], [1, 3]], [(40, [])])
+    # 32-atom cells (the cell of BASELINE configs 2-4), eight atoms fixed as in the cfg1 slab
+    f32 = [[0, 5, 9, 17, 30], [3, 8, 21], [1, 14, 26, 31]]
+    model_case(ns, "rbf_32", "RBF", [2.5, 1.3], 2.0, (46, 78), 2, 3, f32, [(40, list(range(8)))], sigma_pos=0.1)
+    model_case(ns, "dot_32", "Dot", [2.0, 2.0], 2.0, (46, 78), 2, 3, f32, [(40, list(range(8)))], sigma_pos=0.1)
+
+
+if __name__ == "__main__":
+    main()

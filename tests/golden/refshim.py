@@ -1,0 +1,194 @@
+"""Placeholders for the THIRD-PARTY modules the reference imports at module top and this image lacks
+(mpi4py, pyxtal, ase, cffi, matplotlib), so that the reference's OWN Python files
+(/root/reference/gpr_calc/*.py, kernels/*.py) import and run unmodified in the build container and can
+produce golden vectors.  Build-container tooling only: nothing here is product code, nothing here travels as
+a dependency of the GPU tests (only the .npz fixtures do), and no reference source is copied.
+
+What each placeholder is:
+  mpi4py.MPI          a COMM_WORLD of size 1 (bcast/gather/scatter/allreduce/Allreduce/barrier are identities)
+  pyxtal...Element    Element(symbol).z from a periodic-table list (the only use on the path,
+                      gaussianprocess.py:788,847; utilities.py:109)
+  ase.neighborlist    gpr_calculator_amd.neighbors.NeighborListCompat (same three calls; unpinned third party)
+  ase.constraints     FixAtoms with get_indices() (gaussianprocess.py:823-832)
+  ase.db, ase.calculators..., matplotlib   import-only placeholders (never called by the generators)
+  cffi.FFI            new / buffer / release over ctypes arrays (rbf_kernel.py:40-80, 246-329)
+  gpr_calc.kernels._rbf_kernel.lib / _dot_kernel.lib
+                      ctypes handles of oracle/_ref/lib{rbf,dot}_ref.so = the UNMODIFIED reference C++
+                      compiled by oracle/Makefile (what cffi's API mode would have wrapped)
+"""
+import ctypes as C
+import importlib.util
+import os
+import re
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+REF = "/root/reference"
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from gpr_calculator_amd.neighbors import NeighborListCompat, SimpleAtoms, atomic_number  # noqa: E402
+from oracle.natives import SIGS  # noqa: E402   (argtypes of the 13 natives, from rbf_kernel.h / dot_kernel.h)
+
+
+# ---------------------------------------------------------------- mpi4py
+class _Comm:
+    def __init__(self, rank=0, size=1):
+        self._rank, self._size = rank, size
+
+    rank = property(lambda self: self._rank)
+    size = property(lambda self: self._size)
+
+    def Get_rank(self): return self._rank
+    def Get_size(self): return self._size
+    def bcast(self, obj, root=0): return obj
+    def gather(self, obj, root=0): return [obj]
+    def allgather(self, obj): return [obj]
+    def scatter(self, objs, root=0): return objs[0]
+    def allreduce(self, obj, op=None): return obj
+    def barrier(self): pass
+    def Barrier(self): pass
+
+    def Allreduce(self, sendbuf, recvbuf, op=None):
+        src = sendbuf[0] if isinstance(sendbuf, (list, tuple)) else sendbuf
+        dst = recvbuf[0] if isinstance(recvbuf, (list, tuple)) else recvbuf
+        np.copyto(np.asarray(dst), np.asarray(src))
+
+    def Reduce(self, sendbuf, recvbuf, op=None, root=0):
+        self.Allreduce(sendbuf, recvbuf)
+
+
+# ---------------------------------------------------------------- cffi
+class _CArray:
+    """what ffi.new('double[n]', init) returns, as far as the wrappers use it"""
+
+    def __init__(self, ctype, n, init):
+        self.arr = (ctype * n)()
+        if init is not None:
+            self.arr[:len(init)] = init
+
+    def __setitem__(self, k, v): self.arr[k] = v
+    def __getitem__(self, k): return self.arr[k]
+    def __len__(self): return len(self.arr)
+
+    @property
+    def _as_parameter_(self):
+        return self.arr
+
+
+class FFI:
+    _pat = re.compile(r"^(double|int)\[(\d*)\]$")
+
+    def new(self, decl, init=None):
+        m = self._pat.match(decl.replace(" ", ""))
+        assert m, decl
+        ctype = C.c_double if m.group(1) == "double" else C.c_int
+        if init is not None and not isinstance(init, (list, tuple)):
+            init = list(init)
+        n = int(m.group(2)) if m.group(2) else len(init)
+        return _CArray(ctype, n, init)
+
+    def buffer(self, cdata, nbytes):
+        return memoryview(cdata.arr).cast("B")[:nbytes]
+
+    def release(self, cdata):
+        pass        # CPython cffi: no effect on ffi.new() memory (it lives inside the cdata object)
+
+
+class _Lib:
+    def __init__(self, path):
+        self._dll = C.CDLL(path)
+
+    def __getattr__(self, name):
+        fn = getattr(self._dll, name)
+        sig = SIGS[name]
+        fn.restype = None
+        fn.argtypes = [t if t in (C.c_int, C.c_double) else C.c_void_p for t in sig]
+
+        def call(*args):
+            conv = []
+            for a, t in zip(args, sig):
+                if isinstance(a, _CArray):
+                    conv.append(C.cast(a.arr, C.c_void_p))
+                elif t is C.c_int:
+                    conv.append(int(a))
+                else:
+                    conv.append(float(a))
+            assert len(conv) == len(sig), (name, len(args), len(sig))
+            fn(*conv)
+        return call
+
+
+# ---------------------------------------------------------------- ase / pyxtal / matplotlib
+class FixAtoms:
+    def __init__(self, indices):
+        self.index = np.asarray(indices, dtype=int)
+
+    def get_indices(self):
+        return self.index
+
+
+class RefAtoms(SimpleAtoms):
+    """SimpleAtoms + the `constraints` list the reference inspects (gaussianprocess.py:823-832)"""
+
+    def __init__(self, numbers, positions, cell=None, pbc=False, fixed=()):
+        super().__init__(numbers, positions, cell, pbc, fixed)
+        self.constraints = [FixAtoms(list(fixed))] if len(fixed) else []
+
+
+class _Element:
+    def __init__(self, symbol):
+        self.z = atomic_number(symbol)
+
+
+def _module(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def import_reference(rank=0, size=1):
+    """Register the placeholders and import the reference's own modules; returns a namespace with
+    base, rbf_kernel, dot_kernel, RBF_mb, Dot_mb, utilities, SO3, gaussianprocess (modules)."""
+    comm = _Comm(rank, size)
+    MPI = _module("mpi4py.MPI", COMM_WORLD=comm, SUM="sum", DOUBLE="double")
+    _module("mpi4py", MPI=MPI)
+    _module("pyxtal.database.element", Element=_Element)
+    _module("pyxtal.database")
+    _module("pyxtal", pyxtal=None)
+    _module("ase")
+    _module("ase.neighborlist", NeighborList=NeighborListCompat, PrimitiveNeighborList=None)
+    _module("ase.constraints", FixAtoms=FixAtoms, full_3x3_to_voigt_6_stress=None)
+    _module("ase.db", connect=None)
+    plt = _module("matplotlib.pyplot")
+    _module("matplotlib", use=lambda *a, **k: None, pyplot=plt)
+    _module("cffi", FFI=FFI)
+    kdir = os.path.join(REF, "gpr_calc", "kernels")
+    pkg = _module("gpr_calc"); pkg.__path__ = [os.path.join(REF, "gpr_calc")]
+    kpk = _module("gpr_calc.kernels"); kpk.__path__ = [kdir]
+    _module("gpr_calc.kernels._rbf_kernel", lib=_Lib(os.path.join(ROOT, "oracle", "_ref", "librbf_ref.so")))
+    _module("gpr_calc.kernels._dot_kernel", lib=_Lib(os.path.join(ROOT, "oracle", "_ref", "libdot_ref.so")))
+    ns = types.SimpleNamespace()
+    ns.utilities = _load("gpr_calc.utilities", os.path.join(REF, "gpr_calc", "utilities.py"))
+    ns.base = _load("gpr_calc.kernels.base", os.path.join(kdir, "base.py"))
+    ns.rbf_kernel = _load("gpr_calc.kernels.rbf_kernel", os.path.join(kdir, "rbf_kernel.py"))
+    ns.dot_kernel = _load("gpr_calc.kernels.dot_kernel", os.path.join(kdir, "dot_kernel.py"))
+    ns.RBF_mb = _load("gpr_calc.kernels.RBF_mb", os.path.join(kdir, "RBF_mb.py"))
+    ns.Dot_mb = _load("gpr_calc.kernels.Dot_mb", os.path.join(kdir, "Dot_mb.py"))
+    ns.SO3 = _load("gpr_calc.SO3", os.path.join(REF, "gpr_calc", "SO3.py"))
+    ns.gaussianprocess = _load("gpr_calc.gaussianprocess", os.path.join(REF, "gpr_calc", "gaussianprocess.py"))
+    ns.comm = comm
+    return ns
