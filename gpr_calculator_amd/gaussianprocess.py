@@ -1088,7 +1088,9 @@ class GP():
             F = F1 = force.flatten()
             E_std = 2 * tol_e_var
             F_std = 2 * tol_f_var * np.ones((len(atoms), 3))
-        F, F1 = np.asarray(F).reshape(len(atoms), 3), np.asarray(F1).reshape(len(atoms), 3)
+        # the reference keeps F / F1 flat ([3n]) and still indexes them with the atom id (gaussianprocess.py:978):
+        # the error test of atom f_id looks at flat component f_id.  Reproduced as is: it decides which points train.
+        F, F1 = np.asarray(F, dtype=np.float64).reshape(-1), np.asarray(F1, dtype=np.float64).reshape(-1)
 
         pts_to_add["energy"] = my_data["energy"]
         N_energy, energy_in = 1, True
@@ -1118,7 +1120,7 @@ class GP():
             pts_to_add["db"].append((atoms, energy, force, energy_in, force_in))
             self.set_train_pts(pts_to_add, mode="a+")
         errors = (E[0] + energy_off, E1[0] + energy_off, E_std,
-                  F.flatten() + force_off.flatten(), F1.flatten() + force_off.flatten(), F_std)
+                  F + force_off.flatten(), F1 + force_off.flatten(), F_std)
         return pts_to_add, N_pts, errors
 
     # ------------------------------------------------------------------ persistence (json + ASE db)

@@ -125,7 +125,7 @@ def train_points(ns, des, strucs, force_ids):
 def model_case(ns, name, kind, para, zeta, species, reps, n_train, force_ids, tests, noise=(0.002, 0.1),
                stress_test=False, sigma_pos=0.08, opt_iters=0):
     p = dict(kind=kind, para=np.asarray(para, float), zeta=float(zeta), noise_e=noise[0], noise_f=noise[1],
-             nmax=3, lmax=4, rcut=5.0, alpha=2.0, n_train=n_train)
+             nmax=3, lmax=4, rcut=5.0, des_alpha=2.0, n_train=n_train)
     des = ns.SO3.SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0, derivative=True, stress=stress_test)
     kern = (ns.RBF_mb.RBF_mb if kind == "RBF" else ns.Dot_mb.Dot_mb)(para=list(para), zeta=zeta)
     rec = Recorder(kern)
