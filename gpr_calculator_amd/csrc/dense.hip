@@ -221,130 +221,6 @@ __global__ void __launch_bounds__(256) trsm_diag_kernel(int trans, const double 
     for (int i = 0; i < kb; i++) b[(long long)i * ldb + col] = x[i];
 }
 
-// Cholesky of one kb x kb diagonal block (kb <= 64) in LDS by one workgroup, followed by the inverse of the factor;
-// writes L back (upper part zeroed) and L^-1 as a zero-padded 64 x 64 row-major block to `dinv`: panel solves and
-// triangular solves then become small matrix products (tri_apply_kernel).  This kernel sits on the critical path of
-// the blocked factorisation (one launch per 64 columns), so it is built for latency: the block is split 32 + 32,
-//   L = [[L11, 0], [L21, L22]],   L^-1 = [[W1, 0], [-W2 L21 W1, W2]],   W = inverse of the diagonal factor,
-// the two 32 x 32 factorisations / inversions run in one wavefront with compact loops (no block barriers inside; a
-// fully unrolled register version was instruction-fetch bound at ~90 us), and the three coupling products use all
-// 256 threads.
-__device__ __forceinline__ void wave_lds_sync() {
-    __builtin_amdgcn_wave_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-}
-
-// one wavefront: in-place Cholesky of the 32 x 32 block of T at offset o and its inverse into the same block of X
-// (X zero-initialised).  Left-looking, lane = row (factor) / column (inverse): per column one dot product over the
-// finished columns, one v_readlane broadcast of the pivot, one reciprocal square root, one LDS store and one
-// wavefront-level LDS sync -- the 32-step dependency chain carries nothing else.
-__device__ __forceinline__ double readlane_f64(double v, int l) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
-    return __hiloint2double(hi, lo);
-}
-
-__device__ void chol32_inv(double (*T)[NB + 1], double (*X)[NB + 1], double *D, int o, int lane, int k0, int *info) {
-    const int i = lane & 31;
-    for (int j = 0; j < 32; j++) {
-        double s0 = 0.0, s1 = 0.0;
-        int q = 0;
-        for (; q + 1 < j; q += 2) {
-            s0 += T[o + i][o + q] * T[o + j][o + q];
-            s1 += T[o + i][o + q + 1] * T[o + j][o + q + 1];
-        }
-        if (q < j) s0 += T[o + i][o + q] * T[o + j][o + q];
-        const double s = T[o + i][o + j] - (s0 + s1);          // meaningful for rows i >= j
-        const double ajj = readlane_f64(s, j);
-        if (lane == 0 && !(ajj > 0.0) && info) atomicCAS(info, 0, k0 + o + j + 1);
-        const double inv = rsqrt(ajj);
-        if (lane < 32 && i >= j) T[o + i][o + j] = (i == j) ? ajj * inv : s * inv;
-        if (lane == j) D[o + j] = inv;                          // 1 / L_jj
-        wave_lds_sync();
-    }
-    for (int r = 0; r < 32; r++) {                              // forward substitution L x = e_i, column i per lane
-        double v0 = (r == i) ? 1.0 : 0.0, v1 = 0.0;
-        int q = 0;
-        for (; q + 1 < r; q += 2) {
-            v0 -= T[o + r][o + q] * X[o + q][o + i];
-            v1 -= T[o + r][o + q + 1] * X[o + q + 1][o + i];
-        }
-        if (q < r) v0 -= T[o + r][o + q] * X[o + q][o + i];
-        if (lane < 32) X[o + r][o + i] = (v0 + v1) * D[o + r];
-        wave_lds_sync();
-    }
-}
-
-__global__ void __launch_bounds__(256) potrf_diag_inv_kernel(double *a, long long lda, int kb, int k0, int *info,
-                                                              double *dinv) {
-    __shared__ double T[NB][NB + 1];
-    __shared__ double X[NB][NB + 1];
-    __shared__ double D[NB];
-    const int tid = threadIdx.x, c = tid & 63, ty = tid >> 6;
-    for (int i = ty; i < NB; i += 4) {
-        double v = (i == c) ? 1.0 : 0.0;                       // identity padding beyond kb
-        if (i < kb && c < kb) v = (c <= i) ? a[(long long)i * lda + c] : 0.0;
-        T[i][c] = v;
-        X[i][c] = 0.0;
-    }
-    __syncthreads();
-    if (ty == 0) chol32_inv(T, X, D, 0, c, k0, info);          // L11, W1
-    __syncthreads();
-    const int pr = tid >> 5, pc = tid & 31;                    // product threads: rows pr + 8u, column pc
-    double acc[4];
-    // L21 = A21 W1^T
-#pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] = 0.0;
-    for (int k = 0; k <= pc; k++) {
-        const double w = X[pc][k];
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) T[32 + pr + 8 * u][pc] = acc[u];
-    __syncthreads();
-    // A22 -= L21 L21^T
-#pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] = 0.0;
-    for (int k = 0; k < 32; k++) {
-        const double w = T[32 + pc][k];
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) T[32 + pr + 8 * u][32 + pc] -= acc[u];
-    __syncthreads();
-    if (ty == 0) chol32_inv(T, X, D, 32, c, k0, info);         // L22, W2
-    __syncthreads();
-    // Y = L21 W1 (parked in the upper-right block of X), then X21 = -W2 Y
-#pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] = 0.0;
-    for (int k = pc; k < 32; k++) {                            // W1 is lower triangular: rows k >= pc of column pc
-        const double w = X[k][pc];
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] += T[32 + pr + 8 * u][k] * w;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; u++) X[pr + 8 * u][32 + pc] = acc[u];
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) acc[u] = 0.0;
-    for (int k = 0; k < 32; k++) {
-        const double y = X[k][32 + pc];
-#pragma unroll
-        for (int u = 0; u < 4; u++) acc[u] -= X[32 + pr + 8 * u][32 + k] * y;     // W2 upper part is zero
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < 4; u++) { X[32 + pr + 8 * u][pc] = acc[u]; X[pr + 8 * u][32 + pc] = 0.0; }
-    __syncthreads();
-    for (int i = ty; i < NB; i += 4) {
-        if (i < kb && c < kb) a[(long long)i * lda + c] = (c <= i) ? T[i][c] : 0.0;
-        dinv[i * NB + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
-    }
-}
-
 // 64-wide slabs times a 64 x 64 block W (= L_kk^-1, zero padded):
 //   mode 0: P[rows, kb] <- P W^T        (Cholesky panel: X L^T = P), one workgroup per 64 rows
 //   mode 1: B[kb, ncols] <- W B         (forward solve of a diagonal block), one workgroup per 64 columns
@@ -780,61 +656,10 @@ extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, lo
     return rc;
 }
 
-// Blocked right-looking lower Cholesky with two block levels: inside a 256-wide outer panel the 64-wide
-// steps (diagonal factor + inverse, panel product with the inverse, update of the rest of the panel)
-// touch only the panel's columns; the trailing matrix is then updated once per outer panel with a
-// k = 256 product on the matrix cores (lower tiles only).  `dinv` (device, ceil(n/64) * 4096 doubles)
-// receives the inverse of every 64 x 64 diagonal block of L for gpr_trsm_lower_dinv.
-extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
-    hipStream_t st = (hipStream_t)stream;
-    GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
-    if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
-    constexpr int OB = 256;
-    for (int K0 = 0; K0 < n; K0 += OB) {
-        const int KB = (n - K0 < OB) ? n - K0 : OB;
-        for (int k0 = K0; k0 < K0 + KB; k0 += NB) {
-            const int kb = (K0 + KB - k0 < NB) ? K0 + KB - k0 : NB;
-            double *akk = a + (long long)k0 * lda + k0;
-            double *wk = dinv + (size_t)(k0 / NB) * NB * NB;
-            hipLaunchKernelGGL(potrf_diag_inv_kernel, dim3(1), dim3(256), 0, st, akk, lda, kb, k0, info_dev, wk);
-            LAUNCH_CHECK("potrf_diag_inv");
-            const int rows = n - k0 - kb;
-            if (rows > 0) {
-                double *p = a + (long long)(k0 + kb) * lda + k0;
-                hipLaunchKernelGGL(tri_apply_kernel, dim3((rows + NB - 1) / NB), dim3(256), 0, st, 0, wk, p, lda, kb, rows);
-                LAUNCH_CHECK("tri_apply(panel)");
-                const int w = K0 + KB - (k0 + kb);              // columns of the outer panel still to update
-                if (w > 0) {
-                    int rc = launch_gemm(st, 0, 1, rows, w, kb, -1.0, p, lda, p, lda, 1.0,
-                                         a + (long long)(k0 + kb) * lda + (k0 + kb), lda, 0);
-                    if (rc) return rc;
-                }
-            }
-        }
-        const int R = n - K0 - KB;
-        if (R > 0) {
-            const double *p2 = a + (long long)(K0 + KB) * lda + K0;
-            int rc = launch_gemm(st, 0, 1, R, R, KB, -1.0, p2, lda, p2, lda, 1.0,
-                                 a + (long long)(K0 + KB) * lda + (K0 + KB), lda, 1);
-            if (rc) return rc;
-        }
-    }
-    if (n > 1) {
-        hipLaunchKernelGGL(zero_upper_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
-        LAUNCH_CHECK("zero_upper");
-    }
-    return GPR_OK;
-}
-
-extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
-    hipStream_t st = (hipStream_t)stream;
-    if (n <= 0) return GPR_OK;
-    void *tmp;
-    int rc = gpr_dev_alloc(&tmp, (size_t)((n + NB - 1) / NB) * NB * NB * sizeof(double), st);
-    if (rc) return rc;
-    rc = gpr_potrf_lower_dinv(stream, n, a, lda, info_dev, (double *)tmp);
-    int rc2 = gpr_dev_free(tmp, st);
-    return rc ? rc : rc2;
+// (the Cholesky factorisation itself lives in potrf.hip; it calls back into the tiled GEMM through this)
+int gpr_gemm_internal(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
+                      const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
+    return launch_gemm(st, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);
 }
 
 // Blocked triangular solve L X = B (trans 0) / L^T X = B (trans 1), in place.  With `dinv` (from

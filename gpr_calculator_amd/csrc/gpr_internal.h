@@ -104,6 +104,11 @@ enum gpr_prof_kind { GPR_PROF_FF = 0, GPR_PROF_EF = 1, GPR_PROF_EE = 2, GPR_PROF
 int gpr_prof_begin(hipStream_t st, int kind);
 void gpr_prof_end(hipStream_t st, int id);
 
+// tiled FP64 GEMM of dense.hip: C = alpha op(A) op(B) + beta C; lower_only bit 0: skip tiles above the diagonal,
+// bit 1: op(A) lower triangular, bit 2: op(B) = B^T with B lower triangular
+int gpr_gemm_internal(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
+                      const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only);
+
 // small helpers
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
 int gpr_dev_free(void *p, hipStream_t st);

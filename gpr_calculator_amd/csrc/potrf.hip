@@ -1,0 +1,305 @@
+// potrf.hip -- blocked right-looking lower Cholesky, FP64, built so that the sequential part (the diagonal blocks)
+// is a handful of launches instead of one per 64 columns.  Replaces scipy.linalg.cholesky of
+// gaussianprocess.py:175, 297 (K + noise -> L).  Row-major storage.
+//
+// One outer step (256 columns):
+//   potrf_diag256_kernel   one 512-thread workgroup factors the 256 x 256 diagonal block with its lower triangle
+//                          resident in registers as 16 x 16 tiles in MFMA accumulator layout (136 tiles over 8
+//                          wavefronts).  16 stages: chol16 + inverse of the diagonal tile in one wavefront (lane = row,
+//                          pivots and multipliers by v_readlane), panel tiles L_ik = A_ik W_k^T and trailing tiles
+//                          A_ij -= L_ik L_jk^T on the matrix cores with operands exchanged through LDS in operand order.
+//                          Emits L, and W_k / L_jk once more in MFMA A-operand order for the panel kernel.
+//   potrf_panel256_kernel  rows below the block: one wavefront per 16 rows keeps its 16 x 256 slab in registers and
+//                          runs the same 16 stages (X_k = P_k W_k^T, P_j -= X_k L_jk^T) with no cross-wave traffic.
+//   gemm128_kernel         trailing update A22 -= L21 L21^T (lower tiles), k = 256.
+// tri_inv64_kernel then forms the inverse of every 64 x 64 diagonal block of L (`dinv`, used by gpr_trsm_lower_dinv).
+#include "gpr_internal.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int DT = 16;                 // base tile
+constexpr int DB = 256;                // diagonal block = 16 x 16 tiles
+constexpr int NTILE = 136;             // lower tiles of a 16 x 16 tile grid
+constexpr int DWAVES = 8;              // wavefronts of the diagonal kernel
+constexpr int DSLOTS = NTILE / DWAVES; // 17 tiles per wavefront
+constexpr int TILE_DOUBLES = 256;      // one tile in operand order [s = 0..3][lane = 0..63]
+
+// tiles ordered by column descending, row ascending inside a column: the tiles still active at stage k (column > k)
+// are a prefix of the order, so dealing tile t to wavefront t % 8 keeps every stage balanced; t = base(j) + (i - j)
+__host__ __device__ constexpr int tile_base(int j) { return (15 - j) * (16 - j) / 2; }
+__host__ __device__ constexpr int tile_index(int i, int j) { return tile_base(j) + (i - j); }
+
+struct tile_map { unsigned char i[NTILE], j[NTILE]; };
+constexpr tile_map make_tile_map() {
+    tile_map m{};
+    for (int j = 0; j < 16; j++)
+        for (int i = j; i < 16; i++) { m.i[tile_index(i, j)] = (unsigned char)i; m.j[tile_index(i, j)] = (unsigned char)j; }
+    return m;
+}
+__constant__ tile_map c_tiles = make_tile_map();
+
+__device__ __forceinline__ double readlane_d(double v, int l) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), l), hi = __builtin_amdgcn_readlane(__double2hiint(v), l);
+    return __hiloint2double(hi, lo);
+}
+
+// LDS layout of the diagonal kernel
+struct diag_lds {
+    double lt[16][TILE_DOUBLES];       // L_ik of the current stage in operand order, indexed by tile row i
+    double wt[TILE_DOUBLES];           // W_k = L_kk^-1 in operand order
+    double dg[16][17];                 // diagonal tile, row-major, for the factor wavefront
+};
+
+// Cholesky of a 16 x 16 tile and the inverse of its factor in ONE wavefront.
+//   in : a[c] of lane i (i < 16) = A[i][c]
+//   out: a[c] of lane i = L[i][c] (c <= i; garbage above the diagonal), x[r] of lane c = W[r][c] (W = L^-1, lower)
+// Right-looking: at step j the pivot and the multipliers L[k][j] are wave-uniform (v_readlane); the same multipliers
+// drive the forward substitution for W, so the inverse costs no second sweep.  Returns the first bad pivot (1-based) or 0.
+__device__ __forceinline__ int chol16_inv(double (&a)[16], double (&x)[16], int lane) {
+    int bad = 0;
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = (r == lane) ? 1.0 : 0.0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+        const double ajj = readlane_d(a[j], j);
+        if (!(ajj > 0.0) && bad == 0) bad = j + 1;
+        const double inv = rsqrt(ajj);
+        a[j] = a[j] * inv;                                  // column j of L (lane j: sqrt(ajj))
+        x[j] = x[j] * inv;                                  // row j of W is final: all earlier columns were applied
+#pragma unroll
+        for (int k = j + 1; k < 16; k++) {
+            const double lkj = readlane_d(a[j], k);         // L[k][j]
+            a[k] = __builtin_fma(-a[j], lkj, a[k]);         // A[i][k] -= L[i][j] L[k][j]
+            x[k] = __builtin_fma(-lkj, x[j], x[k]);         // forward substitution, column `lane` of W
+        }
+    }
+    return bad;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// diagonal block: a = &A[k0][k0], kb <= 256 valid rows / columns (identity padding beyond)
+//   wop [16][256]  : W_k in operand order;   lop [136][256] : L_ik in operand order (tile_index(i, k), i > k)
+__global__ void __launch_bounds__(512) potrf_diag256_kernel(double *__restrict__ a, long long lda, int kb, int k0,
+                                                             int *info, double *__restrict__ wop,
+                                                             double *__restrict__ lop) {
+    __shared__ diag_lds S;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nt = (kb + DT - 1) / DT;
+    const int lr = lane & 15, lq = lane >> 4;
+    // register tiles, transposed storage: reg r of lane l = A[16 i + (l & 15)][16 j + (l >> 4) + 4 r]
+    d4 acc[DSLOTS];
+    int ti[DSLOTS], tj[DSLOTS];
+#pragma unroll
+    for (int s = 0; s < DSLOTS; s++) {
+        const int t = s * DWAVES + wave;
+        ti[s] = c_tiles.i[t]; tj[s] = c_tiles.j[t];
+        const int row = ti[s] * DT + lr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = tj[s] * DT + lq + 4 * r;
+            double v = (row == col) ? 1.0 : 0.0;
+            if (row < kb && col < kb && ti[s] < nt) v = a[(long long)row * lda + col];
+            acc[s][r] = v;
+        }
+    }
+    for (int k = 0; k < nt; k++) {
+        // ---- phase A: the owner of tile (k, k) hands it to LDS, factors it, publishes W_k and L_kk
+        const int tkk = tile_index(k, k);
+        if (wave == tkk % DWAVES) {
+#pragma unroll
+            for (int s = 0; s < DSLOTS; s++)
+                if (s == tkk / DWAVES) {
+#pragma unroll
+                    for (int r = 0; r < 4; r++) S.dg[lr][lq + 4 * r] = acc[s][r];
+                }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            double ar[16], xr[16];
+            const int i = lane & 15;
+#pragma unroll
+            for (int c = 0; c < 16; c++) ar[c] = S.dg[i][c];
+            const int bad = chol16_inv(ar, xr, i);
+            if (bad && lane == 0 && info) atomicCAS(info, 0, k0 + k * DT + bad);
+            if (lane < 16) {
+                // L_kk to global (zeros above the diagonal), W_k row-major into dg for the operand-order re-read
+                const int row = k * DT + i;
+#pragma unroll
+                for (int c = 0; c < 16; c++) {
+                    const int col = k * DT + c;
+                    if (row < kb && col < kb) a[(long long)row * lda + col] = (c <= i) ? ar[c] : 0.0;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; r++) S.dg[r][i] = (r >= i) ? xr[r] : 0.0;      // W[r][c = i]
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int s = 0; s < 4; s++) {                    // operand order: value (s, lane) = W[lane & 15][(lane >> 4) + 4 s]
+                const double w = S.dg[lr][lq + 4 * s];
+                S.wt[s * 64 + lane] = w;
+                wop[(size_t)k * TILE_DOUBLES + s * 64 + lane] = w;
+            }
+        }
+        __syncthreads();
+        // ---- phase B: panel tiles (i, k), i > k:  X^T = W A_ik^T  (A operand W from LDS, B operand = the register tile)
+#pragma unroll
+        for (int s = 0; s < DSLOTS; s++) {
+            if (tj[s] == k && ti[s] > k && ti[s] < nt) {
+                d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(S.wt[q * 64 + lane], acc[s][q], d, 0, 0, 0);
+                acc[s] = d;
+                const int row = ti[s] * DT + lr;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    S.lt[ti[s]][r * 64 + lane] = d[r];       // register tile == operand order
+                    lop[(size_t)tile_index(ti[s], k) * TILE_DOUBLES + r * 64 + lane] = d[r];
+                    const int col = k * DT + lq + 4 * r;
+                    if (row < kb && col < kb) a[(long long)row * lda + col] = d[r];
+                }
+            }
+        }
+        __syncthreads();
+        // ---- phase C: trailing tiles (i, j), k < j <= i:  S_ij -= L_jk L_ik^T
+#pragma unroll
+        for (int s = 0; s < DSLOTS; s++) {
+            if (tj[s] > k && ti[s] < nt) {
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S.lt[tj[s]][q * 64 + lane], S.lt[ti[s]][q * 64 + lane],
+                                                                  acc[s], 0, 0, 0);
+            }
+        }
+        // no barrier here: the next stage's factor wavefront touches only dg / wt (wt was last read before the barrier
+        // above), and lt is rewritten only after the barrier that follows that phase A, which every wavefront reaches
+        // after its phase C
+    }
+}
+
+// rows below the diagonal block: p = &A[r0][k0], `rows` rows; one wavefront per 16 rows, 4 per workgroup
+__global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb,
+                                                              const double *__restrict__ wop,
+                                                              const double *__restrict__ lop) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * DT;
+    if (r0 >= rows) return;
+    const int nt = (kb + DT - 1) / DT;
+    const int lr = lane & 15, lq = lane >> 4;
+    const bool rok = r0 + lr < rows;
+    d4 t[16];
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = c * DT + lq + 4 * r;
+            t[c][r] = (c < nt && rok && col < kb) ? p[(long long)(r0 + lr) * lda + col] : 0.0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        if (k < nt) {
+            const double *w = wop + (size_t)k * TILE_DOUBLES + lane;
+            d4 d = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q * 64], t[k][q], d, 0, 0, 0);
+            t[k] = d;
+#pragma unroll
+            for (int j = k + 1; j < 16; j++) {
+                if (j < nt) {
+                    const double *l = lop + (size_t)tile_index(j, k) * TILE_DOUBLES + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-l[q * 64], d[q], t[j], 0, 0, 0);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 16; c++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = c * DT + lq + 4 * r;
+            if (c < nt && rok && col < kb) p[(long long)(r0 + lr) * lda + col] = t[c][r];
+        }
+    }
+}
+
+// inverse of one 64 x 64 lower-triangular diagonal block of L -> dinv block (zero padded); one workgroup per block.
+// Column c of the inverse by forward substitution in thread c; the block and the running solution live in LDS.
+__global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict__ a, long long lda, int n,
+                                                        double *__restrict__ dinv) {
+    __shared__ double T[64][65];
+    __shared__ double X[64][65];
+    const int b = blockIdx.x, k0 = b * 64, kb = min(64, n - k0), c = threadIdx.x;
+    for (int i = 0; i < 64; i++) {
+        double v = (i == c) ? 1.0 : 0.0;
+        if (i < kb && c < kb) v = (c <= i) ? a[(long long)(k0 + i) * lda + k0 + c] : 0.0;
+        T[i][c] = v;
+    }
+    __syncthreads();
+    for (int r = 0; r < 64; r++) {
+        double v0 = (r == c) ? 1.0 : 0.0, v1 = 0.0;
+        int q = c;                                            // X[q][c] = 0 for q < c
+        for (; q + 1 < r; q += 2) {
+            v0 = __builtin_fma(-T[r][q], X[q][c], v0);
+            v1 = __builtin_fma(-T[r][q + 1], X[q + 1][c], v1);
+        }
+        if (q < r) v0 = __builtin_fma(-T[r][q], X[q][c], v0);
+        X[r][c] = (r >= c) ? (v0 + v1) / T[r][r] : 0.0;
+    }
+    __syncthreads();
+    double *out = dinv + (size_t)b * 4096;
+    for (int i = 0; i < 64; i++) out[i * 64 + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
+}
+
+__global__ void zero_upper2_kernel(int n, double *a, long long lda) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j < n && j > i) a[(long long)i * lda + j] = 0.0;
+}
+
+}  // namespace
+
+#define LAUNCH_CHECK(name)                                                                   \
+    do { hipError_t _e = hipGetLastError();                                                  \
+         if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
+
+extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
+    if (n == 0) return GPR_OK;
+    if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+    void *scratch;
+    int rc = gpr_dev_alloc(&scratch, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double), st);
+    if (rc) return rc;
+    double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES;
+    for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
+        const int KB = (n - K0 < DB) ? n - K0 : DB;
+        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(512), 0, st, a + (long long)K0 * lda + K0, lda, KB, K0,
+                           info_dev, wop, lop);
+        const int R = n - K0 - KB;
+        if (R > 0) {
+            double *p = a + (long long)(K0 + KB) * lda + K0;
+            hipLaunchKernelGGL(potrf_panel256_kernel, dim3((R + 63) / 64), dim3(256), 0, st, p, lda, R, KB, wop, lop);
+            rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, a + (long long)(K0 + KB) * lda + (K0 + KB),
+                                   lda, 1);
+        }
+    }
+    hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
+    if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
+    const hipError_t e = hipGetLastError();
+    const int rc2 = gpr_dev_free(scratch, st);
+    if (e != hipSuccess) { gpr_set_error("potrf launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return rc ? rc : rc2;
+}
+
+extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
+    hipStream_t st = (hipStream_t)stream;
+    if (n <= 0) return GPR_OK;
+    void *tmp;
+    int rc = gpr_dev_alloc(&tmp, (size_t)((n + 63) / 64) * 4096 * sizeof(double), st);
+    if (rc) return rc;
+    rc = gpr_potrf_lower_dinv(stream, n, a, lda, info_dev, (double *)tmp);
+    const int rc2 = gpr_dev_free(tmp, st);
+    return rc ? rc : rc2;
+}

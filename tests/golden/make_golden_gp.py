@@ -212,6 +212,7 @@ def model_case(ns, name, kind, para, zeta, species, reps, n_train, force_ids, te
     p["refit_alpha"], p["refit_y_train"] = gp.alpha_, gp.y_train
     _, E, F, E_std, F_std = predict_lists(ns, gp, des, t, tests[0][1])
     p["refit_E"], p["refit_F"], p["refit_E_std"], p["refit_F_std"] = E, F, E_std, F_std
+    p["refit_L"], p["refit_K_trans"] = gp.L_, rec.calls["k_total"][2]
     if opt_iters:
         kern.update(list(para))
         gp.fit(show=False, opt=True, maxiter=opt_iters)

@@ -44,3 +44,25 @@ def training_rows(z):
     """(atoms, E, F, energy_in, force_ids) rows of the case's training set"""
     return [(atoms(z, f"train{s}"), float(z[f"train{s}_E"]), z[f"train{s}_F"], True, z[f"train{s}_force_ids"].tolist())
             for s in range(int(z["n_train"]))]
+
+
+def stable_std(L, K_trans, diag):
+    """sqrt(max(0, diag - |L^-1 k|^2)): the reference's predictive variance (gaussianprocess.py:903-907) evaluated
+    from the reference's OWN L, K_trans and diag through a triangular solve instead of its explicit K^-1"""
+    from scipy.linalg import solve_triangular
+    v = solve_triangular(np.asarray(L), np.asarray(K_trans).T, lower=True)
+    return np.sqrt(np.clip(np.asarray(diag) - (v * v).sum(axis=0), 0.0, None))
+
+
+def explicit_inverse_noise(L, diag):
+    """rounding noise of var = diag - k K^-1 k through an explicit inverse: ~ cond(K + noise) * eps * diag.  The
+    reference's recorded std carries it (checked against long-double arithmetic when the fixtures were made: its
+    E_std of the one-species 4-atom cases is off by 2e-5 while the triangular form agrees to 1e-11)."""
+    return 20 * 1.1e-16 * np.linalg.cond(np.asarray(L)) ** 2 * float(np.abs(diag).max())
+
+
+def split_std(std_flat, n, fixed):
+    free = [i for i in range(n) if i not in set(int(f) for f in fixed)]
+    F_std = np.zeros((n, 3))
+    F_std[free] = std_flat[1:].reshape(-1, 3)
+    return std_flat[0], F_std

@@ -5,10 +5,25 @@ forces 1e-5 eV/A, the same for the standard deviations; blocks 1e-12 relative.""
 import numpy as np
 import pytest
 
-from gp_golden import MODEL_CASES, atoms, load, predicted_data, rel, train_x, training_rows
+from gp_golden import (MODEL_CASES, atoms, explicit_inverse_noise, load, predicted_data, rel, split_std, stable_std,
+                       train_x, training_rows)
 
 pytestmark = pytest.mark.gpu
 E_TOL, F_TOL = 1e-6, 1e-5
+
+
+def check_std(E_std, F_std, z, k, L_key="L", Kt_key=None, tag="test"):
+    """predictive standard deviations against the reference: (1) at the north-star tolerance against the reference's
+    own L / K_trans / diag evaluated through a triangular solve, (2) against the std the reference recorded, within the
+    rounding noise of its explicit-inverse formula (gp_golden.explicit_inverse_noise)"""
+    n, fixed = len(z[f"test{k}_numbers"]), z[f"test{k}_fixed"]
+    diag = z[f"test{k}_diag"]
+    Es, Fs = split_std(stable_std(z[L_key], z[Kt_key or f"test{k}_K_trans"], diag), n, fixed)
+    assert abs(E_std - Es) < E_TOL and np.abs(F_std - Fs).max() < F_TOL, (tag, k)
+    dvar = explicit_inverse_noise(z[L_key], diag)
+    ref_E, ref_F = float(z[f"{tag}{k}_E_std" if tag == "test" else f"{tag}_E_std"]), z[f"{tag}{k}_F_std" if tag == "test" else f"{tag}_F_std"]
+    assert abs(E_std ** 2 - ref_E ** 2) < max(dvar, 2 * E_TOL * ref_E), (tag, k, E_std, ref_E, dvar)
+    assert np.abs(F_std ** 2 - ref_F ** 2).max() < max(dvar, 2 * F_TOL * np.abs(ref_F).max())
 
 
 def make_gp(z, stress=False):
@@ -118,8 +133,7 @@ def test_fit_and_predict_structure_match_reference(name):
             E, F, S, E_std, F_std = gp.predict_structure(t, stress=False, return_std=True, f_tol=1e-12)
             assert abs(E - float(z[f"test{k}_E"])) < E_TOL, (route, k)
             assert np.abs(F - z[f"test{k}_F"]).max() < F_TOL
-            assert abs(E_std - float(z[f"test{k}_E_std"])) < E_TOL
-            assert np.abs(F_std - z[f"test{k}_F_std"]).max() < F_TOL
+            check_std(E_std, F_std, z, k)
             assert S is None and np.all(F[z[f"test{k}_fixed"]] == 0) and np.all(F_std[z[f"test{k}_fixed"]] == 0)
             E2, F2, _ = gp.predict_structure(t, stress=False, return_std=False, f_tol=1e-12)
             assert abs(E2 - E) < 1e-9 and np.abs(F2 - F).max() < 1e-9
@@ -128,7 +142,7 @@ def test_fit_and_predict_structure_match_reference(name):
     Es, Fs, Es_std, Fs_std = gp.predict_structures(ts, return_std=True, f_tol=1e-12)
     for k in range(len(ts)):
         assert abs(Es[k] - float(z[f"test{k}_E"])) < E_TOL and np.abs(Fs[k] - z[f"test{k}_F"]).max() < F_TOL
-        assert abs(Es_std[k] - float(z[f"test{k}_E_std"])) < E_TOL and np.abs(Fs_std[k] - z[f"test{k}_F_std"]).max() < F_TOL
+        check_std(Es_std[k], Fs_std[k], z, k)
     # validate_data on the training set
     E, Ep, F, Fp = gp.validate_data()
     assert np.abs(E - z["val_E"]).max() < 1e-12 and np.abs(F - z["val_F"]).max() < 1e-12
@@ -185,19 +199,21 @@ def test_add_structure_queue_and_refit_match_reference(name):
     pts, n_pts, errors = gp.add_structure((new, float(z["add_E"]), z["add_F"].copy()))
     assert list(pts["db"][0][4]) == z["add_force_in"].tolist() and n_pts == int(z["add_N_pts"])
     assert abs(errors[0] - float(z["add_err_E"])) < 1e-12 and abs(errors[1] - float(z["add_err_E_pred"])) < E_TOL
-    assert abs(errors[2] - float(z["add_err_E_std"])) < E_TOL
-    assert np.abs(errors[4] - z["add_err_F_pred"]).max() < F_TOL and np.abs(errors[5] - z["add_err_F_std"]).max() < F_TOL
+    dvar = explicit_inverse_noise(z["L"], z["test0_diag"])          # the recorded std carries the explicit-inverse noise
+    assert abs(errors[2] ** 2 - float(z["add_err_E_std"]) ** 2) < max(dvar, 2 * E_TOL * float(z["add_err_E_std"]))
+    assert np.abs(errors[4] - z["add_err_F_pred"]).max() < F_TOL
+    assert np.abs(errors[5] ** 2 - z["add_err_F_std"] ** 2).max() < max(dvar, 2 * F_TOL * np.abs(z["add_err_F_std"]).max())
     assert [gp.N_energy, gp.N_forces, gp.N_energy_queue, gp.N_forces_queue, gp.N_queue] == z["add_counters"].tolist()
     t = atoms(z, "test0", fixed=z["test0_fixed"])
     E, F, _, E_std, F_std = gp.predict_structure(t, stress=False, return_std=True, f_tol=1e-12)
-    assert abs(E - float(z["queued_E"])) < E_TOL and np.abs(F_std - z["queued_F_std"]).max() < F_TOL
-    assert abs(E - float(z["test0_E"])) < E_TOL
+    assert abs(E - float(z["queued_E"])) < E_TOL and abs(E - float(z["test0_E"])) < E_TOL
+    check_std(E_std, F_std, z, 0)                                    # queued points change nothing
     gp.fit(show=False, opt=False)
     assert np.abs(gp.y_train - z["refit_y_train"]).max() < 1e-12
     assert rel(gp.alpha_, z["refit_alpha"]) < 1e-5
     E, F, _, E_std, F_std = gp.predict_structure(t, stress=False, return_std=True, f_tol=1e-12)
     assert abs(E - float(z["refit_E"])) < E_TOL and np.abs(F - z["refit_F"]).max() < F_TOL
-    assert abs(E_std - float(z["refit_E_std"])) < E_TOL and np.abs(F_std - z["refit_F_std"]).max() < F_TOL
+    check_std(E_std, F_std, z, 0, L_key="refit_L", Kt_key="refit_K_trans", tag="refit")
     if "opt_params" in z.files:
         gp.kernel.update([float(v) for v in z["para"]])
         gp.fit(show=False, opt=True, maxiter=int(z["opt_iters"]))
