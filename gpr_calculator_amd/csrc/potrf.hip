@@ -22,8 +22,7 @@ namespace {
 constexpr int DT = 16;                 // base tile
 constexpr int DB = 256;                // diagonal block = 16 x 16 tiles
 constexpr int NTILE = 136;             // lower tiles of a 16 x 16 tile grid
-constexpr int DWAVES = 8;              // wavefronts of the diagonal kernel
-constexpr int DSLOTS = NTILE / DWAVES; // 17 tiles per wavefront
+constexpr int DWAVES = 12;             // wavefronts of the diagonal kernel: 1 factor + 2 idle (same SIMD) + 9 tile waves
 constexpr int TILE_DOUBLES = 256;      // one tile in operand order [s = 0..3][lane = 0..63]
 
 // tiles ordered by column descending, row ascending inside a column: the tiles still active at stage k (column > k)
@@ -52,28 +51,23 @@ struct diag_lds {
     double dg[16][17];                 // diagonal tile, row-major, for the factor wavefront
 };
 
-// Cholesky of a 16 x 16 tile and the inverse of its factor in ONE wavefront.
-//   in : a[c] of lane i (i < 16) = A[i][c]
-//   out: a[c] of lane i = L[i][c] (c <= i; garbage above the diagonal), x[r] of lane c = W[r][c] (W = L^-1, lower)
-// Right-looking: at step j the pivot and the multipliers L[k][j] are wave-uniform (v_readlane); the same multipliers
-// drive the forward substitution for W, so the inverse costs no second sweep.  Returns the first bad pivot (1-based) or 0.
-__device__ __forceinline__ int chol16_inv(double (&a)[16], double (&x)[16], int lane) {
+// Cholesky of a 16 x 16 tile and the inverse of its factor in ONE wavefront, one instruction stream for both:
+//   lanes  0..15 hold the rows of A      (v[c] of lane i      = A[i][c]),
+//   lanes 16..31 hold the columns of W   (v[r] of lane 16 + c = W[r][c], starting from the identity; W = L^-1),
+// and the right-looking step  v[j] *= 1/sqrt(a_jj);  v[k] -= v[j] L[k][j] (k > j)  is at once the elimination of
+// column j of A and the forward substitution of every column of W.  The pivot a_jj and the multipliers L[k][j] are
+// wave-uniform (v_readlane from lanes j / k).  Out: lanes 0..15 v[c] = L[i][c] for c <= i (garbage above the
+// diagonal), lanes 16..31 v[r] = W[r][c] (zero for r < c).  Returns the first bad pivot (1-based) or 0.
+__device__ __forceinline__ int chol16_inv(double (&v)[16]) {
     int bad = 0;
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = (r == lane) ? 1.0 : 0.0;
-#pragma unroll
     for (int j = 0; j < 16; j++) {
-        const double ajj = readlane_d(a[j], j);
+        const double ajj = readlane_d(v[j], j);
         if (!(ajj > 0.0) && bad == 0) bad = j + 1;
         const double inv = rsqrt(ajj);
-        a[j] = a[j] * inv;                                  // column j of L (lane j: sqrt(ajj))
-        x[j] = x[j] * inv;                                  // row j of W is final: all earlier columns were applied
+        v[j] = v[j] * inv;
 #pragma unroll
-        for (int k = j + 1; k < 16; k++) {
-            const double lkj = readlane_d(a[j], k);         // L[k][j]
-            a[k] = __builtin_fma(-a[j], lkj, a[k]);         // A[i][k] -= L[i][j] L[k][j]
-            x[k] = __builtin_fma(-lkj, x[j], x[k]);         // forward substitution, column `lane` of W
-        }
+        for (int k = j + 1; k < 16; k++) v[k] = __builtin_fma(-v[j], readlane_d(v[j], k), v[k]);
     }
     return bad;
 }
@@ -81,113 +75,148 @@ __device__ __forceinline__ int chol16_inv(double (&a)[16], double (&x)[16], int 
 // ---------------------------------------------------------------------------------------------------------------------
 // diagonal block: a = &A[k0][k0], kb <= 256 valid rows / columns (identity padding beyond)
 //   wop [16][256]  : W_k in operand order;   lop [136][256] : L_ik in operand order (tile_index(i, k), i > k)
-__global__ void __launch_bounds__(512) potrf_diag256_kernel(double *__restrict__ a, long long lda, int kb, int k0,
+// Wavefront 0 only factors diagonal tiles.  The FP64 VALU and the FP64 matrix core share one datapath, and a
+// v_mfma_f64_16x16x4 holds it for 64 cycles, so the factor wavefront must not share its SIMD with matrix-core work:
+// wavefronts 4 and 8 (same SIMD as 0 under the round-robin placement) only keep the barriers company, the nine others
+// own the 136 tiles (tile t -> tile wave t % 9).  Per stage k three block barriers:  B1 tile (k, k) is in LDS | B2 W_k is in LDS | B3 the L_ik of the stage are in LDS.
+// Between B1 and B2 the factor wavefront works on tile (k, k) while the tile wavefronts finish the trailing updates of
+// stage k - 1 (tile (k, k) itself was brought up to date right after B3 of stage k - 1), so the sequential factor and
+// the matrix-core updates overlap.  The two roles are separate code paths: neither holds the other's registers.
+constexpr int TWAVES = DWAVES - 3;                  // 9 tile wavefronts
+constexpr int TSLOTS = (NTILE + TWAVES - 1) / TWAVES;   // 16 tiles per wavefront at most
+
+__global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__restrict__ a, long long lda, int kb, int k0,
                                                              int *info, double *__restrict__ wop,
                                                              double *__restrict__ lop) {
     __shared__ diag_lds S;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
-    // register tiles, transposed storage: reg r of lane l = A[16 i + (l & 15)][16 j + (l >> 4) + 4 r]
-    d4 acc[DSLOTS];
-    int ti[DSLOTS], tj[DSLOTS];
+    if (wave == 0) {
+        __builtin_amdgcn_s_setprio(3);
+        for (int k = 0; k < nt; k++) {
+            __syncthreads();                                 // B1: tile (k, k), row-major, in S.dg
+            double v[16];
+            const bool wl = (lane & 48) == 16;               // lanes 16..31: columns of W
 #pragma unroll
-    for (int s = 0; s < DSLOTS; s++) {
-        const int t = s * DWAVES + wave;
-        ti[s] = c_tiles.i[t]; tj[s] = c_tiles.j[t];
-        const int row = ti[s] * DT + lr;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const int col = tj[s] * DT + lq + 4 * r;
-            double v = (row == col) ? 1.0 : 0.0;
-            if (row < kb && col < kb && ti[s] < nt) v = a[(long long)row * lda + col];
-            acc[s][r] = v;
-        }
-    }
-    for (int k = 0; k < nt; k++) {
-        // ---- phase A: the owner of tile (k, k) hands it to LDS, factors it, publishes W_k and L_kk
-        const int tkk = tile_index(k, k);
-        if (wave == tkk % DWAVES) {
-#pragma unroll
-            for (int s = 0; s < DSLOTS; s++)
-                if (s == tkk / DWAVES) {
-#pragma unroll
-                    for (int r = 0; r < 4; r++) S.dg[lr][lq + 4 * r] = acc[s][r];
-                }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            double ar[16], xr[16];
-            const int i = lane & 15;
-#pragma unroll
-            for (int c = 0; c < 16; c++) ar[c] = S.dg[i][c];
-            const int bad = chol16_inv(ar, xr, i);
+            for (int c = 0; c < 16; c++) v[c] = wl ? ((c == lr) ? 1.0 : 0.0) : S.dg[lr][c];
+            const int bad = chol16_inv(v);
             if (bad && lane == 0 && info) atomicCAS(info, 0, k0 + k * DT + bad);
-            if (lane < 16) {
-                // L_kk to global (zeros above the diagonal), W_k row-major into dg for the operand-order re-read
-                const int row = k * DT + i;
+            if (wl) {                                        // W[r][c = lr] straight into operand order:
+#pragma unroll                                               //   (q, lane') = W[lane' & 15][(lane' >> 4) + 4 q]
+                for (int r = 0; r < 16; r++) S.wt[(lr >> 2) * 64 + 16 * (lr & 3) + r] = v[r];
+            }
+            __syncthreads();                                 // B2: W_k in S.wt
+#pragma unroll
+            for (int q = 0; q < 4; q++) wop[(size_t)k * TILE_DOUBLES + q * 64 + lane] = S.wt[q * 64 + lane];
+            if (lane < 16) {                                 // L_kk to global, zeros above the diagonal
+                const int row = k * DT + lr;
 #pragma unroll
                 for (int c = 0; c < 16; c++) {
                     const int col = k * DT + c;
-                    if (row < kb && col < kb) a[(long long)row * lda + col] = (c <= i) ? ar[c] : 0.0;
+                    if (row < kb && col < kb) a[(long long)row * lda + col] = (c <= lr) ? v[c] : 0.0;
                 }
-#pragma unroll
-                for (int r = 0; r < 16; r++) S.dg[r][i] = (r >= i) ? xr[r] : 0.0;      // W[r][c = i]
             }
-            __builtin_amdgcn_wave_barrier();
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __syncthreads();                                 // B3
+        }
+        return;
+    }
+    if (wave == 4 || wave == 8) {
+        for (int k = 0; k < nt; k++) { __syncthreads(); __syncthreads(); __syncthreads(); }
+        return;
+    }
+    const int tw = wave - 1 - (wave > 4) - (wave > 8);      // 0..8
+    // ---- tile wavefronts.  Register tiles, transposed storage: reg r of lane l = A[16 i + (l & 15)][16 j + (l >> 4) + 4 r]
+    d4 acc[TSLOTS];
+    int tij[TSLOTS];                                         // i | j << 8, or -1
 #pragma unroll
-            for (int s = 0; s < 4; s++) {                    // operand order: value (s, lane) = W[lane & 15][(lane >> 4) + 4 s]
-                const double w = S.dg[lr][lq + 4 * s];
-                S.wt[s * 64 + lane] = w;
-                wop[(size_t)k * TILE_DOUBLES + s * 64 + lane] = w;
+    for (int s = 0; s < TSLOTS; s++) {
+        const int t = s * TWAVES + tw;
+        tij[s] = -1;
+        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
+        if (t < NTILE && c_tiles.i[t] < nt) {
+            const int ti = c_tiles.i[t], tj = c_tiles.j[t];
+            tij[s] = ti | (tj << 8);
+            const int row = ti * DT + lr;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int col = tj * DT + lq + 4 * r;
+                acc[s][r] = (row < kb && col < kb) ? a[(long long)row * lda + col] : ((row == col) ? 1.0 : 0.0);
             }
         }
-        __syncthreads();
-        // ---- phase B: panel tiles (i, k), i > k:  X^T = W A_ik^T  (A operand W from LDS, B operand = the register tile)
+    }
+    // tij[s] is read through an opaque move inside the stage loop: otherwise every address derived from it (LDS tile
+    // bases, global rows, operand-order slots; 16 slots of each) is hoisted out of the loop and spilled to scratch
+    auto slot = [&](int s) { int v = __builtin_amdgcn_readfirstlane(tij[s]); asm volatile("" : "+s"(v)); return v; };
+    auto hand_over_diag = [&](int k) {                       // the owner of tile (k, k) puts it into S.dg
 #pragma unroll
-        for (int s = 0; s < DSLOTS; s++) {
-            if (tj[s] == k && ti[s] > k && ti[s] < nt) {
+        for (int s = 0; s < TSLOTS; s++)
+            if (slot(s) == (k | (k << 8))) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) S.dg[lr][lq + 4 * r] = acc[s][r];
+            }
+    };
+    auto update = [&](int s, int v) {                        // S_ij -= L_jk L_ik^T from the stage-k tiles in S.lt
+        const int ti = v & 255, tj = v >> 8;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S.lt[tj][q * 64 + lane], S.lt[ti][q * 64 + lane], acc[s], 0, 0, 0);
+    };
+    hand_over_diag(0);
+    for (int k = 0; k < nt; k++) {
+        __syncthreads();                                     // B1
+        if (k > 0) {                                         // rest of the trailing update of stage k - 1
+#pragma unroll
+            for (int s = 0; s < TSLOTS; s++) {
+                const int v = slot(s);
+                if (v >= 0 && (v >> 8) > k - 1 && v != (k | (k << 8))) update(s, v);
+            }
+        }
+        __syncthreads();                                     // B2
+        // panel tiles (i, k), i > k:  X^T = W A_ik^T  (A operand W from LDS, B operand = the register tile)
+#pragma unroll
+        for (int s = 0; s < TSLOTS; s++) {
+            const int v = slot(s);
+            if (v >= 0 && (v >> 8) == k && (v & 255) > k) {
+                const int ti = v & 255;
                 d4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(S.wt[q * 64 + lane], acc[s][q], d, 0, 0, 0);
                 acc[s] = d;
-                const int row = ti[s] * DT + lr;
+                const int row = ti * DT + lr;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    S.lt[ti[s]][r * 64 + lane] = d[r];       // register tile == operand order
-                    lop[(size_t)tile_index(ti[s], k) * TILE_DOUBLES + r * 64 + lane] = d[r];
+                    S.lt[ti][r * 64 + lane] = d[r];          // register tile == operand order
+                    lop[(size_t)tile_index(ti, k) * TILE_DOUBLES + r * 64 + lane] = d[r];
                     const int col = k * DT + lq + 4 * r;
                     if (row < kb && col < kb) a[(long long)row * lda + col] = d[r];
                 }
             }
         }
-        __syncthreads();
-        // ---- phase C: trailing tiles (i, j), k < j <= i:  S_ij -= L_jk L_ik^T
+        __syncthreads();                                     // B3
+        if (k + 1 < nt) {                                    // next diagonal tile first, so that its factor can start
 #pragma unroll
-        for (int s = 0; s < DSLOTS; s++) {
-            if (tj[s] > k && ti[s] < nt) {
-#pragma unroll
-                for (int q = 0; q < 4; q++)
-                    acc[s] = __builtin_amdgcn_mfma_f64_16x16x4f64(-S.lt[tj[s]][q * 64 + lane], S.lt[ti[s]][q * 64 + lane],
-                                                                  acc[s], 0, 0, 0);
+            for (int s = 0; s < TSLOTS; s++) {
+                const int v = slot(s);
+                if (v == ((k + 1) | ((k + 1) << 8))) update(s, v);
             }
+            hand_over_diag(k + 1);
         }
-        // no barrier here: the next stage's factor wavefront touches only dg / wt (wt was last read before the barrier
-        // above), and lt is rewritten only after the barrier that follows that phase A, which every wavefront reaches
-        // after its phase C
     }
 }
 
-// rows below the diagonal block: p = &A[r0][k0], `rows` rows; one wavefront per 16 rows, 4 per workgroup
+// rows below the diagonal block: p = &A[r0][k0], `rows` rows; one wavefront per 16 rows, 4 per workgroup.  The operand
+// tiles of a stage (W_k and L_jk, j > k) are the same for every wavefront: the workgroup stages them through LDS,
+// stage k + 1 loading while stage k computes.
 __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb,
                                                               const double *__restrict__ wop,
                                                               const double *__restrict__ lop) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ double ops[2][16 * TILE_DOUBLES];             // [buffer][slot = j - k][operand order]; slot 0 = W_k
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r0 = (blockIdx.x * 4 + wave) * DT;
-    if (r0 >= rows) return;
     const int nt = (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
-    const bool rok = r0 + lr < rows;
+    const bool live = r0 < rows, rok = r0 + lr < rows;
     d4 t[16];
 #pragma unroll
     for (int c = 0; c < 16; c++) {
@@ -197,22 +226,36 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
             t[c][r] = (c < nt && rok && col < kb) ? p[(long long)(r0 + lr) * lda + col] : 0.0;
         }
     }
+    // tile u of stage k: u = 0 -> W_k, u >= 1 -> L_{k+u, k}
+    auto src = [&](int k, int u) { return u == 0 ? wop + (size_t)k * TILE_DOUBLES : lop + (size_t)tile_index(k + u, k) * TILE_DOUBLES; };
+    for (int u = 0; u < nt; u++) ops[0][u * TILE_DOUBLES + tid] = src(0, u)[tid];
+    __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if (k < nt) {
-            const double *w = wop + (size_t)k * TILE_DOUBLES + lane;
-            d4 d = {0.0, 0.0, 0.0, 0.0};
+            const double *cur = ops[k & 1];
+            double pf[15];
 #pragma unroll
-            for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(w[q * 64], t[k][q], d, 0, 0, 0);
-            t[k] = d;
+            for (int u = 0; u < 15 - k; u++)                 // stage k + 1 has nt - k - 1 tiles
+                if (k + 1 + u < nt) pf[u] = src(k + 1, u)[tid];
+            if (live) {
+                d4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int j = k + 1; j < 16; j++) {
-                if (j < nt) {
-                    const double *l = lop + (size_t)tile_index(j, k) * TILE_DOUBLES + lane;
+                for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[q * 64 + lane], t[k][q], d, 0, 0, 0);
+                t[k] = d;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) t[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-l[q * 64], d[q], t[j], 0, 0, 0);
+                for (int j = k + 1; j < 16; j++) {
+                    if (j < nt) {
+                        const double *l = cur + (j - k) * TILE_DOUBLES + lane;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) t[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-l[q * 64], d[q], t[j], 0, 0, 0);
+                    }
                 }
             }
+#pragma unroll
+            for (int u = 0; u < 15 - k; u++)
+                if (k + 1 + u < nt) ops[(k + 1) & 1][u * TILE_DOUBLES + tid] = pf[u];
+            __syncthreads();
         }
     }
 #pragma unroll
@@ -273,9 +316,12 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     int rc = gpr_dev_alloc(&scratch, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double), st);
     if (rc) return rc;
     double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES;
+    // (An outer level of 1024-column panels brought up to date left-looking, k = all factored columns, was measured:
+    // the trailing matrix is then read and written 4 x less often, but the tall-skinny products of the last panels
+    // have too few tiles for 256 CUs -- 7.6 ms against 6.5 ms at N = 6063.)
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
-        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(512), 0, st, a + (long long)K0 * lda + K0, lda, KB, K0,
+        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, st, a + (long long)K0 * lda + K0, lda, KB, K0,
                            info_dev, wop, lop);
         const int R = n - K0 - KB;
         if (R > 0) {
