@@ -9,8 +9,8 @@
 //                          pivots and multipliers by v_readlane), panel tiles L_ik = A_ik W_k^T and trailing tiles
 //                          A_ij -= L_ik L_jk^T on the matrix cores with operands exchanged through LDS in operand order.
 //                          Emits L, and W_k / L_jk once more in MFMA A-operand order for the panel kernel.
-//   potrf_panel256_kernel  rows below the block: one wavefront per 16 rows keeps its 16 x 256 slab in registers and
-//                          runs the same 16 stages (X_k = P_k W_k^T, P_j -= X_k L_jk^T) with no cross-wave traffic.
+//   potrf_panel256_kernel  rows below the block: one workgroup per 16 rows keeps its 16 x 256 slab in the registers of
+//                          four wavefronts and runs the same 16 stages (X_k = P_k W_k^T, P_j -= X_k L_jk^T).
 //   gemm128_kernel         trailing update A22 -= L21 L21^T (lower tiles), k = 256.
 // tri_inv64_kernel then forms the inverse of every 64 x 64 diagonal block of L (`dinv`, used by gpr_trsm_lower_dinv).
 #include "gpr_internal.h"
@@ -205,25 +205,31 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
     }
 }
 
-// rows below the diagonal block: p = &A[r0][k0], `rows` rows; one wavefront per 16 rows, 4 per workgroup.  The operand
-// tiles of a stage (W_k and L_jk, j > k) are the same for every wavefront: the workgroup stages them through LDS,
-// stage k + 1 loading while stage k computes.
-__global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb,
+// rows below the diagonal block: p = &A[r0][k0], `rows` rows.  One workgroup (4 wavefronts) per 16 rows: the slab's
+// 16 column tiles are dealt to the wavefronts (tile j -> wavefront j % 4), so the 136 tile updates of a slab run four
+// abreast; what is sequential per stage is one tile solve X_k = P_k W_k^T in the owner of tile k, handed to the others
+// through LDS in B-operand order (= the accumulator layout it is produced in).  The operand tiles of a stage (W_k and
+// L_jk, j > k) are staged through LDS, stage k + 1 loading while stage k computes.
+// FULL: kb == 256, every bound on the column tiles is a compile-time constant (the guarded form branches per tile).
+template <bool FULL>
+__global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb_,
                                                               const double *__restrict__ wop,
                                                               const double *__restrict__ lop) {
     __shared__ double ops[2][16 * TILE_DOUBLES];             // [buffer][slot = j - k][operand order]; slot 0 = W_k
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r0 = (blockIdx.x * 4 + wave) * DT;
-    const int nt = (kb + DT - 1) / DT;
+    __shared__ double xk[2][TILE_DOUBLES];                   // X_k^T of the stage, B-operand order
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r0 = blockIdx.x * DT;
+    const int kb = FULL ? DB : kb_;
+    const int nt = FULL ? 16 : (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
-    const bool live = r0 < rows, rok = r0 + lr < rows;
-    d4 t[16];
+    const bool rok = r0 + lr < rows;
+    d4 t[4];                                                 // column tiles wave, wave + 4, wave + 8, wave + 12
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < 4; c++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int col = c * DT + lq + 4 * r;
-            t[c][r] = (c < nt && rok && col < kb) ? p[(long long)(r0 + lr) * lda + col] : 0.0;
+            const int col = (wave + 4 * c) * DT + lq + 4 * r;
+            t[c][r] = (rok && col < kb) ? p[(long long)(r0 + lr) * lda + col] : 0.0;
         }
     }
     // tile u of stage k: u = 0 -> W_k, u >= 1 -> L_{k+u, k}
@@ -238,18 +244,25 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
 #pragma unroll
             for (int u = 0; u < 15 - k; u++)                 // stage k + 1 has nt - k - 1 tiles
                 if (k + 1 + u < nt) pf[u] = src(k + 1, u)[tid];
-            if (live) {
+            if (wave == (k & 3)) {                           // X_k^T = W_k P_k^T
                 d4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-                for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[q * 64 + lane], t[k][q], d, 0, 0, 0);
-                t[k] = d;
+                for (int q = 0; q < 4; q++) d = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[q * 64 + lane], t[k >> 2][q], d, 0, 0, 0);
+                t[k >> 2] = d;
 #pragma unroll
-                for (int j = k + 1; j < 16; j++) {
-                    if (j < nt) {
-                        const double *l = cur + (j - k) * TILE_DOUBLES + lane;
+                for (int q = 0; q < 4; q++) xk[k & 1][q * 64 + lane] = d[q];
+            }
+            __syncthreads();
+            double xb[4];
 #pragma unroll
-                        for (int q = 0; q < 4; q++) t[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(-l[q * 64], d[q], t[j], 0, 0, 0);
-                    }
+            for (int q = 0; q < 4; q++) xb[q] = xk[k & 1][q * 64 + lane];
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int j = wave + 4 * c;
+                if (j > k && j < nt) {
+                    const double *l = cur + (j - k) * TILE_DOUBLES + lane;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(-l[q * 64], xb[q], t[c], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -259,11 +272,11 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
         }
     }
 #pragma unroll
-    for (int c = 0; c < 16; c++) {
+    for (int c = 0; c < 4; c++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int col = c * DT + lq + 4 * r;
-            if (c < nt && rok && col < kb) p[(long long)(r0 + lr) * lda + col] = t[c][r];
+            const int col = (wave + 4 * c) * DT + lq + 4 * r;
+            if (rok && col < kb) p[(long long)(r0 + lr) * lda + col] = t[c][r];
         }
     }
 }
@@ -326,7 +339,8 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         const int R = n - K0 - KB;
         if (R > 0) {
             double *p = a + (long long)(K0 + KB) * lda + K0;
-            hipLaunchKernelGGL(potrf_panel256_kernel, dim3((R + 63) / 64), dim3(256), 0, st, p, lda, R, KB, wop, lop);
+            if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
+            else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
             rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, a + (long long)(K0 + KB) * lda + (K0 + KB),
                                    lda, 1);
         }
