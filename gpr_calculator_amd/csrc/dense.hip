@@ -586,7 +586,8 @@ __global__ void gemm_splitk_reduce_kernel(int m, int n, int nz, const double *__
 int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                 const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     if (m <= 0 || n <= 0) return GPR_OK;
-    if (m >= 256 && n >= 256) {      // enough tiles to fill the chip with the 128x128 kernel
+    if (m >= 256 && n >= 256 && !(lower_only & 8)) {      // enough tiles to fill the chip with the 128x128 kernel
+        // (bit 3 of lower_only: the caller wants the 64 x 64 tiles -- narrow updates on a latency-critical chain)
         dim3 g2((n + GN - 1) / GN, (m + GM - 1) / GM), b2(256);
         // tall-skinny A^T B (the F x F Gram matrices of the weight-space fit: a handful of tiles, k in the thousands):
         // slices of k on blockIdx.z, partial tiles to a workspace, summed in slice order

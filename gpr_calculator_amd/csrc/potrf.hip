@@ -316,10 +316,44 @@ __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
 
 }  // namespace
 
+#include <cstdlib>
 #define LAUNCH_CHECK(name)                                                                   \
     do { hipError_t _e = hipGetLastError();                                                  \
          if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
 
+// second stream + events of the look-ahead (one set per process; the factorisation is not re-entrant anyway: it owns
+// the scratch of the diagonal kernel for the duration of the call)
+struct lookahead_ctx {
+    hipStream_t side = nullptr;
+    std::vector<hipEvent_t> ev;
+    size_t next = 0;
+    int init() {
+        if (side) return GPR_OK;
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
+        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
+        ev.resize(128);
+        for (auto &e : ev)
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GPR_ERR_HIP;
+        return GPR_OK;
+    }
+    hipEvent_t take() { return ev[next++ % ev.size()]; }
+};
+static lookahead_ctx g_la;
+
+// Right-looking, 256 columns per step, with look-ahead: the caller's stream carries the sequential chain
+//   diag(K) -> panel(K) -> update of column block K + 1 by panel K                      (narrow, k = 256)
+// and a side stream the bulk of the trailing update by panel K, column block K + 2 first and the rest after it, so
+// that the chain of step K + 1 runs while the matrix cores are still busy with step K.  Who waits for whom:
+//   side:   bulk(K) after panel(K)                                  [event P_K recorded on the main stream]
+//   main:   the narrow update of step K + 1 (it writes column block K + 2) after bulk(K)'s first part [event B_K]
+//   main:   the end of the call after the last bulk update
+// The two narrow products run on 64 x 64 tiles (a 128 x 128 tile at k = 256 takes ~60 us however few there are).
+// Measured at N = 6063: 5.5 ms against 6.0 ms on one stream; updating every second step with two panels at once
+// (k = 512, half the read-modify-write traffic of the trailing matrix) was slower, 6.3 ms: the narrow products in
+// between cost more than the wider one saves.
+// Everything else is ordered by the streams themselves: bulk(K) reads column block K only, which the main stream
+// never touches again; diag / panel of step K + 1 touch column block K + 1 only, which no bulk update still writes.
 extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
@@ -329,22 +363,44 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     int rc = gpr_dev_alloc(&scratch, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double), st);
     if (rc) return rc;
     double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES;
-    // (An outer level of 1024-column panels brought up to date left-looking, k = all factored columns, was measured:
-    // the trailing matrix is then read and written 4 x less often, but the tall-skinny products of the last panels
-    // have too few tiles for 256 CUs -- 7.6 ms against 6.5 ms at N = 6063.)
+    const bool la = n > 3 * DB && !getenv("GPR_POTRF_NO_LOOKAHEAD") && g_la.init() == GPR_OK;
+    hipEvent_t bulk_first = nullptr, bulk_last = nullptr;       // B_{K-1}; the last event of the side stream
+    auto at = [&](int r, int c) { return a + (long long)r * lda + c; };
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
-        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, st, a + (long long)K0 * lda + K0, lda, KB, K0,
-                           info_dev, wop, lop);
-        const int R = n - K0 - KB;
-        if (R > 0) {
-            double *p = a + (long long)(K0 + KB) * lda + K0;
-            if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
-            else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
-            rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, a + (long long)(K0 + KB) * lda + (K0 + KB),
-                                   lda, 1);
+        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop);
+        const int c1 = K0 + KB, R = n - c1;                      // first row / column after the block
+        if (R <= 0) break;
+        double *p = at(c1, K0);
+        if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
+        else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
+        if (!la) {
+            rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, at(c1, c1), lda, 1);
+            continue;
+        }
+        // narrow update: column block K + 1 (it was last written by the first part of bulk(K - 1))
+        const int KB1 = (n - c1 < DB) ? n - c1 : DB;
+        if (bulk_first) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_first, 0));
+        rc = gpr_gemm_internal(st, 0, 1, R, KB1, KB, -1.0, p, lda, p, lda, 1.0, at(c1, c1), lda, 1 | 8);
+        const int c2 = c1 + KB1;
+        if (rc || c2 >= n) { bulk_first = nullptr; continue; }
+        hipEvent_t pk = g_la.take();
+        GPR_HIP_TRY(hipEventRecord(pk, st));
+        GPR_HIP_TRY(hipStreamWaitEvent(g_la.side, pk, 0));
+        // bulk, part 1: column block K + 2
+        const int KB2 = (n - c2 < DB) ? n - c2 : DB;
+        rc = gpr_gemm_internal(g_la.side, 0, 1, n - c2, KB2, KB, -1.0, at(c2, K0), lda, at(c2, K0), lda, 1.0, at(c2, c2), lda, 1 | 8);
+        bulk_first = g_la.take();
+        GPR_HIP_TRY(hipEventRecord(bulk_first, g_la.side));
+        bulk_last = bulk_first;
+        const int c3 = c2 + KB2;
+        if (rc == GPR_OK && c3 < n) {                            // part 2: everything to the right of it
+            rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, KB, -1.0, at(c3, K0), lda, at(c3, K0), lda, 1.0, at(c3, c3), lda, 1);
+            bulk_last = g_la.take();
+            GPR_HIP_TRY(hipEventRecord(bulk_last, g_la.side));
         }
     }
+    if (bulk_last) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_last, 0));
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
     if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
     const hipError_t e = hipGetLastError();
