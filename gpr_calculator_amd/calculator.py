@@ -2,8 +2,9 @@
 
 `GPR(base=..., ff=gp, save=..., tag=..., freq=..., stress=..., f_tol=..., return_std=...)` predicts with
 the surrogate, compares the predictive standard deviations with the tolerances, falls back to the base
-calculator when they are exceeded, queues the new data and triggers a refit -- the same decision logic,
-thresholds and counters as the reference.  ASE is imported lazily: the class derives from
+calculator when they are exceeded, queues the new data and triggers a refit -- the decision rules, thresholds,
+counters and console lines of the reference (tests/golden/gpr_trace.npz is a trace of the reference's own
+calculator on a scripted run; tests/test_gpu_calculator_trace.py replays it).  ASE is imported lazily: the class derives from
 ase.calculators.calculator.Calculator when ASE is installed and from a minimal stand-in otherwise (so
 that the decision logic stays testable in containers without ASE).
 """
@@ -19,7 +20,10 @@ except Exception:                               # ASE absent: minimal protocol s
     all_changes = ['positions', 'numbers', 'cell', 'pbc', 'initial_charges', 'initial_magmoms']
 
     class _Params(dict):
-        __getattr__ = dict.__getitem__
+        def __getattr__(self, key):             # ase.calculators.calculator.Parameters: AttributeError when absent
+            if key not in self:
+                return dict.__getattribute__(self, key)
+            return self[key]
 
         def __setattr__(self, k, v):
             self[k] = v
@@ -72,67 +76,89 @@ class GPR(Calculator):
         self.update = True
         self.allow_base = True
 
-    def calculate(self, atoms=None, properties=['energy', 'forces'], system_changes=all_changes):
-        """One force call of an optimiser (gpr_calc/calculator.py:48-117)."""
-        gp_model = self.parameters.ff
-        comm, rank = gp_model.comm, gp_model.comm.rank
-        fix_ids = fixed_indices(atoms)
+    # ---- one force call of an optimiser.  Behaviour of gpr_calc/calculator.py:48-117:
+    #   1. every rank works on rank 0's geometry;
+    #   2. the surrogate predicts E, F and both standard deviations;
+    #   3. the prediction is rejected when N * E_std exceeds 1.2 * N * noise_e (only with ignore_E_std off; otherwise the
+    #      bound is 100 eV, i.e. never) or when any force component's std reaches max(1.2 * noise_f, |F|max / 2.5);
+    #   4. rejected (or force_base): rank 0 runs the base calculator, fixed atoms get zero force, the labelled structure
+    #      is queued with add_structure and the base numbers become the result;
+    #   5. with update_gpr on, a refit (opt=True, maxiter=10) is triggered once more than `freq` points are queued
+    #      (max(2, freq // 2) beyond 100 force points) or two energies; the refit saves, validates and stops the
+    #      program when the training error exceeds 0.1 eV/atom or 0.3 eV/A.
+    # The two console lines are parsed by the reference's examples/Pd4/analysis.py:35-46 and keep its format.
+    E_TOL_OFF = 100                     # eV: the energy criterion when ignore_E_std is set
+    MAE_LIMITS = (0.1, 0.3)             # eV/atom, eV/A: a refit worse than this aborts the run
 
-        atoms.positions = comm.bcast(atoms.positions, root=0)
-        if hasattr(atoms.cell, "array"):
-            atoms.cell.array = comm.bcast(atoms.cell.array, root=0)
+    def _tolerances(self, natoms):
+        gp = self.parameters.ff
+        e_tol = self.E_TOL_OFF if self.ignore_E_std else 1.2 * natoms * gp.noise_e
+        return e_tol, 1.2 * gp.noise_f
 
-        self._calculate(atoms, properties, system_changes)
-        if self.ignore_E_std:
-            e_tol = 100
-        else:
-            e_tol = 1.2 * len(atoms) * gp_model.noise_e
-        f_tol = 1.2 * gp_model.noise_f
-        E_std, F_std = self.results['var_e'] * len(atoms), self.results['var_f'].max()
-        E = self.results['energy']
+    def _uncertain(self, natoms):
+        """(reject?, numbers for the log line) from the surrogate's results"""
+        e_tol, f_tol = self._tolerances(natoms)
+        E_std = self.results['var_e'] * natoms
+        F_std = self.results['var_f'].max()
         Fmax = np.abs(self.results['forces']).max()
-        E_fail = E_std > e_tol
-        f_ref = max(f_tol, Fmax / 2.5)
-        force_fail = not (F_std < f_ref).all()
-        if self.force_base or (self.allow_base and (E_fail or force_fail)):
-            gp_model.use_base += 1
-            if rank == 0:
-                atoms.calc = self.parameters.base
-                eng = atoms.get_potential_energy()
-                forces = atoms.get_forces()
-                forces[fix_ids] = 0.0
-                atoms.calc = None
-                data = (atoms.copy(), eng, forces)
-                f_max = np.abs(forces).max()
-                if self.verbose:
-                    print(f"From Base model E: {E_std:.3f}/{E:.3f}/{eng:.3f}, F: {F_std:.3f}/{Fmax:.3f}/{f_max:.3f}")
-            else:
-                data, eng, forces = None, None, None
-            data, eng, forces = comm.bcast((data, eng, forces), root=0)
-            comm.barrier()
-            gp_model.add_structure(data)
-            self.results["energy"] = eng
-            self.results["forces"] = forces
-            atoms.calc = self
-        else:
-            gp_model.use_surrogate += 1
-            if rank == 0 and self.verbose:
-                print(f"From Surrogate  E: {E_std:.3f}/{e_tol:.3f}/{E:.3f}, F: {F_std:.3f}/{f_tol:.3f}/{Fmax:.3f}")
+        reject = bool(E_std > e_tol) or not bool((F_std < max(f_tol, Fmax / 2.5)).all())
+        return reject, (E_std, F_std, Fmax, e_tol, f_tol)
 
-        # refit when enough points are queued (gpr_calc/calculator.py:101-117)
-        freq = max([2, self.freq // 2]) if gp_model.N_forces > 100 else self.freq
-        if self.update_gpr and (gp_model.N_queue > freq or gp_model.N_energy_queue >= 2):
-            gp_model.fit(opt=True, show=False, maxiter=10)
-            if rank == 0 and self.save:
-                gp_model.save(f'{self.tag}-gpr.json', f'{self.tag}-gpr.db', verbose=False)
-                print(gp_model)
-            gp_model.validate_data(show=True)
-            if gp_model.error['energy_mae'] > 0.1 or gp_model.error['forces_mae'] > 0.3:
-                print("ERROR: The error is too large, check the data.")
-                print(gp_model.error)
-                print("The program stops here!\n")
-                import sys
-                sys.exit()
+    def _label_with_base(self, atoms, log):
+        """run the base calculator on rank 0, share the labelled structure, queue it; returns (energy, forces)"""
+        gp = self.parameters.ff
+        E_std, F_std, Fmax = log[:3]
+        payload = None
+        if gp.comm.rank == 0:
+            atoms.calc = self.parameters.base
+            eng, forces = atoms.get_potential_energy(), atoms.get_forces()
+            forces[fixed_indices(atoms)] = 0.0
+            atoms.calc = None
+            payload = ((atoms.copy(), eng, forces), eng, forces)
+            if self.verbose:
+                E = self.results['energy']
+                print(f"From Base model E: {E_std:.3f}/{E:.3f}/{eng:.3f}, F: {F_std:.3f}/{Fmax:.3f}/{np.abs(forces).max():.3f}")
+        data, eng, forces = gp.comm.bcast(payload, root=0)
+        gp.comm.barrier()
+        gp.add_structure(data)
+        atoms.calc = self
+        return eng, forces
+
+    def _refit_due(self):
+        gp = self.parameters.ff
+        freq = max(2, self.freq // 2) if gp.N_forces > 100 else self.freq
+        return self.update_gpr and (gp.N_queue > freq or gp.N_energy_queue >= 2)
+
+    def _refit(self):
+        gp = self.parameters.ff
+        gp.fit(opt=True, show=False, maxiter=10)
+        if gp.comm.rank == 0 and self.save:
+            gp.save(f'{self.tag}-gpr.json', f'{self.tag}-gpr.db', verbose=False)
+            print(gp)
+        gp.validate_data(show=True)
+        if gp.error['energy_mae'] > self.MAE_LIMITS[0] or gp.error['forces_mae'] > self.MAE_LIMITS[1]:
+            print("ERROR: The error is too large, check the data.")
+            print(gp.error)
+            print("The program stops here!\n")
+            raise SystemExit
+
+    def calculate(self, atoms=None, properties=['energy', 'forces'], system_changes=all_changes):
+        gp = self.parameters.ff
+        atoms.positions = gp.comm.bcast(atoms.positions, root=0)
+        if hasattr(atoms.cell, "array"):
+            atoms.cell.array = gp.comm.bcast(atoms.cell.array, root=0)
+        self._calculate(atoms, properties, system_changes)
+        reject, log = self._uncertain(len(atoms))
+        if self.force_base or (self.allow_base and reject):
+            gp.use_base += 1
+            self.results["energy"], self.results["forces"] = self._label_with_base(atoms, log)
+        else:
+            gp.use_surrogate += 1
+            if gp.comm.rank == 0 and self.verbose:
+                E_std, F_std, Fmax, e_tol, f_tol = log
+                print(f"From Surrogate  E: {E_std:.3f}/{e_tol:.3f}/{self.results['energy']:.3f}, F: {F_std:.3f}/{f_tol:.3f}/{Fmax:.3f}")
+        if self._refit_due():
+            self._refit()
 
     def _calculate(self, atoms, properties, system_changes):
         """E / F / sigma from the GP (gpr_calc/calculator.py:119-155)"""

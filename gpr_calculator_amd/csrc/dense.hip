@@ -95,6 +95,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
 //   stored [row][k]  (A not transposed, B transposed):  row stride 17 doubles
 //   stored [k][col]  (A transposed, B not transposed):  row stride 144 doubles
 constexpr int GM = 128, GN = 128, GK = 16, GLDK = GM + 16, GLDR = GK + 1;
+// C rows = rows lb0*nb.. of the row blocks (size nb, a multiple of 128) rank `rank` of `nranks` owns under a 1-D
+// block-cyclic distribution (local block b = global block b*nranks + rank); C column j = global column col0 + j
+struct cyc_rule { int nb, nranks, rank, lb0, col0; };
 constexpr int GBUF = (GK * GLDK > GM * GLDR) ? GK * GLDK : GM * GLDR;
 
 template <bool TA, bool TB>
@@ -102,10 +105,15 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
                                                        const double *__restrict__ A, long long lda,
                                                        const double *__restrict__ B, long long ldb,
                                                        double beta, double *__restrict__ C, long long ldc,
-                                                       int lower_only, int ksplit, double *__restrict__ ws) {
+                                                       int lower_only, int ksplit, double *__restrict__ ws, cyc_rule cyc) {
     __shared__ double As[2][GBUF];
     __shared__ double Bs[2][GBUF];
     const int bm0 = blockIdx.y * GM, bn0 = blockIdx.x * GN;
+    if (cyc.nb > 0) {            // rows are the block-cyclic rows of one rank: skip tiles above the GLOBAL diagonal
+        const int last = min(bm0 + GM, m) - 1;                                   // last local row of the tile
+        const long long grow = ((long long)(cyc.lb0 + last / cyc.nb) * cyc.nranks + cyc.rank) * cyc.nb + last % cyc.nb;
+        if ((long long)cyc.col0 + bn0 > grow) return;
+    }
     if (ksplit > 0) {            // split-K slice blockIdx.z: rows [k0, k0 + ksplit) of op(A), op(B); plain sums into ws[z]
         const int k0 = blockIdx.z * ksplit;
         A += TA ? (long long)k0 * lda : (long long)k0;
@@ -600,7 +608,7 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
             int rc = gpr_dev_alloc(&wsp, (size_t)nz * m * n * sizeof(double), st);
             if (rc) return rc;
             g2.z = nz;
-            hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp);
+            hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp, cyc_rule{0, 0, 0, 0, 0});
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, nz,
                                (const double *)wsp, alpha, beta, c, ldc);
             const hipError_t e3 = hipGetLastError();
@@ -608,10 +616,10 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
             if (e3 != hipSuccess) { gpr_set_error("split-K gemm launch failed: %s", hipGetErrorString(e3)); return GPR_ERR_HIP; }
             return GPR_OK;
         }
-        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
-        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
-        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
-        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr);
+        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
+        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
+        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
+        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { gpr_set_error("gemm128 launch failed: %s", hipGetErrorString(e2)); return GPR_ERR_HIP; }
         return GPR_OK;
@@ -631,6 +639,46 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
          if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
 
 }  // namespace
+
+__global__ void mirror_lower_kernel(int n, double *a, long long lda) {       // a[i][j] = a[j][i] for j > i
+    __shared__ double t[32][33];
+    const int bi = blockIdx.y * 32, bj = blockIdx.x * 32;
+    if (bj < bi) return;                                                        // tiles with some j > i only
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) { const int j = bj + r, i = bi + tx; t[r][tx] = (j < n && i < n) ? a[(long long)j * lda + i] : 0.0; }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) { const int i = bi + r, j = bj + tx; if (i < n && j < n && j > i) a[(long long)i * lda + j] = t[tx][r]; }
+}
+
+// upper triangle <- transpose of the lower one, in place (a covariance matrix assembled as row slabs that hold the
+// lower trapezoid only)
+extern "C" int gpr_mirror_lower(void *stream, int n, double *a, long long lda) {
+    GPR_REQUIRE(n >= 0 && (n == 0 || a) && lda >= n, "gpr_mirror_lower: bad arguments");
+    if (n < 2) return GPR_OK;
+    const unsigned nb = (n + 31) / 32;
+    hipLaunchKernelGGL(mirror_lower_kernel, dim3(nb, nb), dim3(256), 0, (hipStream_t)stream, n, a, lda);
+    LAUNCH_CHECK("mirror_lower");
+    return GPR_OK;
+}
+
+// C[m, n] -= A[m, k] B[n, k]^T restricted to the lower triangle of the GLOBAL matrix, where the m rows of C (and A)
+// are the block-cyclic rows lb0*nb.. of rank `rank` (cyc_rule above) and column j of C is global column col0 + j.
+// The trailing update of the row-distributed Cholesky (distributed.py); nb must be a multiple of 128.
+extern "C" int gpr_gemm_nt_cyclic_lower(void *stream, int m, int n, int k, double alpha, const double *a, long long lda,
+                                        const double *b, long long ldb, double beta, double *c, long long ldc, int nb,
+                                        int nranks, int rank, int lb0, int col0) {
+    GPR_REQUIRE(m >= 0 && n >= 0 && k >= 0 && nb > 0 && nb % GM == 0 && nranks >= 1 && rank >= 0 && rank < nranks && lb0 >= 0,
+                "gpr_gemm_nt_cyclic_lower: bad arguments (nb=%d must be a multiple of %d)", nb, GM);
+    if (m == 0 || n == 0) return GPR_OK;
+    GPR_REQUIRE(a && b && c, "gpr_gemm_nt_cyclic_lower: null pointer");
+    const int pid = gpr_prof_begin((hipStream_t)stream, GPR_PROF_GEMM);
+    dim3 g2((n + GN - 1) / GN, (m + GM - 1) / GM), b2(256);
+    hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, (hipStream_t)stream, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, 0,
+                       (double *)nullptr, cyc_rule{nb, nranks, rank, lb0, col0});
+    gpr_prof_end((hipStream_t)stream, pid);
+    LAUNCH_CHECK("gemm128(cyclic)");
+    return GPR_OK;
+}
 
 extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
                         const double *a, long long lda, const double *b, long long ldb, double beta,

@@ -409,6 +409,41 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     return rc ? rc : rc2;
 }
 
+// ---- building blocks of a factorisation whose rows live on several GPUs (gpr_calculator_amd/distributed.py):
+// the owner of a diagonal block factors it and hands the operand tiles (W_k and L_jk in MFMA operand order, 311 KB) to
+// the other ranks, which apply them to their own rows of the panel.
+extern "C" int gpr_potrf_ops_doubles(void) { return (16 + NTILE) * TILE_DOUBLES; }
+
+extern "C" int gpr_potrf_diag_block(void *stream, int kb, double *a, long long lda, int k0, int *info_dev, double *ops) {
+    GPR_REQUIRE(kb >= 1 && kb <= DB && a && ops && lda >= kb, "gpr_potrf_diag_block: bad arguments (kb=%d)", kb);
+    hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, (hipStream_t)stream, a, lda, kb, k0, info_dev, ops,
+                       ops + 16 * TILE_DOUBLES);
+    LAUNCH_CHECK("potrf_diag256");
+    return GPR_OK;
+}
+
+extern "C" int gpr_potrf_panel_rows(void *stream, int kb, const double *ops, double *p, long long lda, int rows) {
+    GPR_REQUIRE(kb >= 1 && kb <= DB && rows >= 0, "gpr_potrf_panel_rows: bad arguments (kb=%d rows=%d)", kb, rows);
+    if (rows == 0) return GPR_OK;
+    GPR_REQUIRE(ops && p && lda >= kb, "gpr_potrf_panel_rows: null pointer / short rows");
+    const double *wop = ops, *lop = ops + 16 * TILE_DOUBLES;
+    if (kb == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((rows + DT - 1) / DT), dim3(256), 0, (hipStream_t)stream, p, lda, rows, kb, wop, lop);
+    else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((rows + DT - 1) / DT), dim3(256), 0, (hipStream_t)stream, p, lda, rows, kb, wop, lop);
+    LAUNCH_CHECK("potrf_panel256");
+    return GPR_OK;
+}
+
+// dinv of an already factored matrix (inverse of every 64 x 64 diagonal block of L) and the zeroing of the strict upper
+// triangle: the tail of gpr_potrf_lower_dinv, for a factor that was put together from row blocks
+extern "C" int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, double *dinv) {
+    GPR_REQUIRE(n >= 0 && (n == 0 || l) && ldl >= n, "gpr_potrf_finish: bad arguments");
+    if (n == 0) return GPR_OK;
+    if (dinv) hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, l, ldl, n, dinv);
+    if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, n, l, ldl);
+    LAUNCH_CHECK("potrf_finish");
+    return GPR_OK;
+}
+
 extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {
     hipStream_t st = (hipStream_t)stream;
     if (n <= 0) return GPR_OK;

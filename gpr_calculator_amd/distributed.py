@@ -1,0 +1,216 @@
+"""Multi-GPU fit: one process per GPU (parallel.Comm over torch.distributed: RCCL on xGMI, gloo in the CPU tests).
+
+What is sharded, and what moves:
+
+  * covariance assembly (`assemble_sharded`): the training points -- energy structures and force environments --
+    are cut into contiguous shards, balanced by the work their rows cost.  Rank g computes the row slab of its points,
+    lower trapezoid only (K[shard_g, columns of the points up to the end of shard_g]); the slabs are ALL-GATHERED into
+    the full matrix on every rank and the upper triangle is filled by mirroring.  The reference splits the same way
+    (contiguous chunks of the first set's points, gather to rank 0, broadcast: RBF_mb.py:257-301, 351-431, 471-521).
+    Each matrix element crosses the links once (an all-reduce of zero-padded partial matrices moves it twice and adds it).
+
+  * Cholesky (`cholesky_block_cyclic`), for matrices large enough that the N^3/3 matters (cfg4: N = 24 250): 1-D
+    block-cyclic rows (256-row blocks, block b on rank b % G), right-looking.  Per block step: the owner factors the
+    diagonal block and BROADCASTS its operand tiles (311 KB); every rank solves its own rows of the panel; the panel
+    rows are ALL-GATHERED (N x 256 doubles at most); every rank updates its own rows of the trailing matrix on the matrix
+    cores.  The factor is gathered at the end (predictions keep using a replicated L).
+
+Both routines take the local arithmetic as an `ops` object: `DeviceOps` (libgprhip.so) in production, a numpy / scipy
+implementation in tests/test_distributed_gloo.py, which runs the very same schedule over gloo with world size 2.
+"""
+import numpy as np
+import torch
+
+from .parallel import balanced_ranges
+
+NB = 256        # row-block size of the distributed factorisation (= the diagonal block of csrc/potrf.hip)
+
+
+# ------------------------------------------------------------------------------------------------ point shards
+def slice_energy(e, p0, p1):
+    X, ELE, counts = e
+    r0, r1 = int(np.sum(counts[:p0])), int(np.sum(counts[:p1]))
+    return (X[r0:r1], ELE[r0:r1], list(counts[p0:p1]))
+
+
+def slice_force(f, p0, p1):
+    X, dXdR, ELE, counts = f
+    r0, r1 = int(np.sum(counts[:p0])), int(np.sum(counts[:p1]))
+    return (X[r0:r1], dXdR[r0:r1], ELE[r0:r1], list(counts[p0:p1]))
+
+
+def shard_points(counts_e, counts_f, size):
+    """[(e0, e1, f0, f1)] per rank.  Force points are weighted by rows x (rows of all points up to and including
+    themselves) -- the cost of their lower-trapezoid slab; energy points (cheap) by rows."""
+    ce, cf = np.asarray(counts_e, dtype=np.float64), np.asarray(counts_f, dtype=np.float64)
+    er = balanced_ranges(ce, size) if len(ce) else [(0, 0)] * size
+    fr = balanced_ranges(cf * (ce.sum() + np.cumsum(cf)), size) if len(cf) else [(0, 0)] * size
+    return [(er[r][0], er[r][1], fr[r][0], fr[r][1]) for r in range(size)]
+
+
+def assemble_sharded(train_x, comm, block_fn, ops, nmat=1):
+    """Full symmetric K(train, train) on every rank from per-rank row slabs.
+
+    block_fn(data1, data2) -> tuple of `nmat` matrices [rows(data1), rows(data2)] (K, or K and dK/dl) on this rank's
+    device; ops: zeros((r, c)), mirror_lower_(M).  Returns the tuple of gathered matrices."""
+    E, F = train_x.get("energy") or (None, None, []), train_x.get("force") or (None, None, None, [])
+    nE, nF = len(E[-1]), len(F[-1])
+    N = nE + 3 * nF
+    shards = shard_points(E[-1], F[-1], comm.size)
+    e0, e1, f0, f1 = shards[comm.rank]
+    slab_e = [ops.zeros((e1 - e0, N)) for _ in range(nmat)]
+    slab_f = [ops.zeros((3 * (f1 - f0), N)) for _ in range(nmat)]
+    if e1 > e0:         # energy rows: columns of the energy points up to the shard's end
+        out = block_fn({"energy": slice_energy(E, e0, e1)}, {"energy": slice_energy(E, 0, e1)})
+        for s, o in zip(slab_e, out):
+            s[:, :e1] = o
+    if f1 > f0:         # force rows: all energy columns, force columns up to the shard's end
+        d2 = {"force": slice_force(F, 0, f1)}
+        if nE:
+            d2 = {"energy": E, "force": d2["force"]}
+        out = block_fn({"force": slice_force(F, f0, f1)}, d2)
+        for s, o in zip(slab_f, out):
+            s[:, :nE + 3 * f1] = o
+    ce = [s[1] - s[0] for s in shards]
+    cf = [3 * (s[3] - s[2]) for s in shards]
+    res = []
+    for se, sf in zip(slab_e, slab_f):
+        K = torch.cat((comm.all_gather_rows(se, ce), comm.all_gather_rows(sf, cf)), dim=0)
+        ops.mirror_lower_(K)
+        res.append(K)
+    return tuple(res)
+
+
+# ------------------------------------------------------------------------------------------------ row distribution
+class RowBlockCyclic:
+    """rows of an n x n matrix in blocks of nb, block b on rank b % size; a rank stores its blocks in increasing order"""
+
+    def __init__(self, n, size, nb=NB):
+        self.n, self.size, self.nb = int(n), int(size), int(nb)
+        self.nblk = (self.n + self.nb - 1) // self.nb
+
+    def block_rows(self, b):
+        return min(self.nb, self.n - b * self.nb)
+
+    def blocks_upto(self, rank, k):
+        """number of `rank`'s blocks with id <= k"""
+        return 0 if k < rank else (k - rank) // self.size + 1
+
+    def local_row0(self, rank, b):
+        """local row at which block b (owned by rank) starts; only the last block can be short, and it is the last local one"""
+        return ((b - rank) // self.size) * self.nb
+
+    def local_nrows(self, rank):
+        return sum(self.block_rows(b) for b in range(rank, self.nblk, self.size))
+
+    def rows_after(self, rank, k):
+        """(first local row, number of local rows) of `rank` in blocks with id > k"""
+        r0 = self.blocks_upto(rank, k) * self.nb
+        return min(r0, self.local_nrows(rank)), max(self.local_nrows(rank) - r0, 0)
+
+    def global_rows(self, rank):
+        return np.concatenate([np.arange(b * self.nb, b * self.nb + self.block_rows(b)) for b in
+                               range(rank, self.nblk, self.size)] or [np.zeros(0, dtype=np.int64)]).astype(np.int64)
+
+    def perm_after(self, k):
+        """index into the rank-major concatenation of every rank's rows-after-k that lists them in global row order
+        (global rows (k + 1) * nb .. n - 1); k = -1: all rows"""
+        g = np.arange((k + 1) * self.nb, self.n, dtype=np.int64)
+        b = g // self.nb
+        r = b % self.size
+        cnt = np.array([self.rows_after(q, k)[1] for q in range(self.size)], dtype=np.int64)
+        off = np.concatenate(([0], np.cumsum(cnt)[:-1]))
+        done = np.array([self.blocks_upto(q, k) for q in range(self.size)], dtype=np.int64)
+        local = ((b - r) // self.size - done[r]) * self.nb + g % self.nb
+        return off[r] + local
+
+
+def cholesky_block_cyclic(Aloc, dist, comm, ops):
+    """In-place lower Cholesky of a symmetric matrix held as block-cyclic row blocks: Aloc [local rows, n] holds, on
+    return, this rank's rows of L (entries above the diagonal are unspecified).  Only the lower triangle is read."""
+    rank, size, nb, n = comm.rank, comm.size, dist.nb, dist.n
+    for k in range(dist.nblk):
+        k0, kb, owner = k * nb, dist.block_rows(k), k % size
+        buf = ops.new_tiles()
+        if rank == owner:
+            ops.diag_(Aloc, dist.local_row0(rank, k), k0, kb, buf)
+        comm.broadcast_(buf, root=owner)
+        c1 = k0 + kb
+        if c1 >= n:
+            break
+        r0, m = dist.rows_after(rank, k)
+        if m > 0:
+            ops.panel_(buf, Aloc, r0, k0, kb, m)
+        counts = [dist.rows_after(q, k)[1] for q in range(size)]
+        mine = Aloc[r0:r0 + m, k0:c1].contiguous()
+        panel = comm.all_gather_rows(mine, counts)                  # rank-major
+        panel = ops.take_rows(panel, dist.perm_after(k))            # global order: rows c1 .. n - 1
+        if m > 0:
+            ops.update_(Aloc, r0, m, k0, kb, panel, c1, n - c1, dist, rank)
+    return Aloc
+
+
+def gather_factor(Aloc, dist, comm, ops):
+    """the full n x n factor on every rank, rows in global order"""
+    counts = [dist.local_nrows(q) for q in range(comm.size)]
+    full = comm.all_gather_rows(Aloc, counts)
+    return ops.take_rows(full, dist.perm_after(-1))
+
+
+def potrf_distributed(K, comm, ops, nb=NB):
+    """Cholesky of the replicated symmetric matrix K with the work spread over the ranks; returns the replicated L
+    (strict upper triangle zero) and the diagonal-block inverses (see device.potrf_lower_)."""
+    n = K.shape[0]
+    dist = RowBlockCyclic(n, comm.size, nb)
+    Aloc = ops.take_rows(K, dist.global_rows(comm.rank))
+    cholesky_block_cyclic(Aloc, dist, comm, ops)
+    L = gather_factor(Aloc, dist, comm, ops)
+    return ops.finish_(L)
+
+
+# ------------------------------------------------------------------------------------------------ device arithmetic
+class DeviceOps:
+    """local arithmetic of the routines above on the GPU (libgprhip.so)"""
+
+    def __init__(self):
+        from . import _lib, device as dev
+        self.lib, self.dev = _lib.lib(), dev
+        self.info = torch.zeros(1, dtype=torch.int32, device=dev.device())
+        self.ntile = int(self.lib.gpr_potrf_ops_doubles())
+
+    def zeros(self, shape):
+        return torch.zeros(shape, dtype=self.dev.F64, device=self.dev.device())
+
+    def mirror_lower_(self, M):
+        self.dev.check(self.lib.gpr_mirror_lower(self.dev.stream_ptr(), M.shape[0], self.dev.ptr(M), int(M.stride(0))), "gpr_mirror_lower")
+        return M
+
+    def new_tiles(self):
+        return torch.empty(self.ntile, dtype=self.dev.F64, device=self.dev.device())
+
+    def take_rows(self, M, idx):
+        return M.index_select(0, torch.from_numpy(np.ascontiguousarray(idx)).to(M.device))
+
+    def _at(self, M, r, c):
+        return M.data_ptr() + 8 * (r * int(M.stride(0)) + c)
+
+    def diag_(self, Aloc, r, c, kb, buf):
+        self.dev.check(self.lib.gpr_potrf_diag_block(self.dev.stream_ptr(), kb, self._at(Aloc, r, c), int(Aloc.stride(0)), c,
+                                                     self.dev.ptr(self.info), self.dev.ptr(buf)), "gpr_potrf_diag_block")
+
+    def panel_(self, buf, Aloc, r0, c, kb, m):
+        self.dev.check(self.lib.gpr_potrf_panel_rows(self.dev.stream_ptr(), kb, self.dev.ptr(buf), self._at(Aloc, r0, c),
+                                                     int(Aloc.stride(0)), m), "gpr_potrf_panel_rows")
+
+    def update_(self, Aloc, r0, m, c, kb, panel, c1, ncols, dist, rank):
+        ld = int(Aloc.stride(0))
+        self.dev.check(self.lib.gpr_gemm_nt_cyclic_lower(
+            self.dev.stream_ptr(), m, ncols, kb, -1.0, self._at(Aloc, r0, c), ld, self.dev.ptr(panel), int(panel.stride(0)), 1.0,
+            self._at(Aloc, r0, c1), ld, dist.nb, dist.size, rank, r0 // dist.nb, c1), "gpr_gemm_nt_cyclic_lower")
+
+    def finish_(self, L):
+        n = L.shape[0]
+        dinv = torch.empty(((n + 63) // 64) * 4096, dtype=self.dev.F64, device=L.device)
+        self.dev.check(self.lib.gpr_potrf_finish(self.dev.stream_ptr(), n, self.dev.ptr(L), int(L.stride(0)), self.dev.ptr(dinv)),
+                       "gpr_potrf_finish")
+        return L, dinv, self.info

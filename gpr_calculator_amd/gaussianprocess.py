@@ -21,6 +21,7 @@ neighbour search, descriptor and regrouping on the device; for the weight-space 
 import json
 import logging
 import os
+import time
 from copy import deepcopy
 
 import numpy as np
@@ -105,7 +106,7 @@ class GP():
     def _ensure_dense(self):
         if self._dense_pending:
             self._dense_pending = False
-            self._factor_dense()
+            self._factor_dense(lazy=True)
 
     @property
     def _L_dev(self):
@@ -265,45 +266,50 @@ class GP():
         species = kernel._feature_path(train_x, None, kernel.zeta)
         if species is None:
             return None
-        Psi = kernel._psi(train_x, species)
-        N, F = Psi.shape
-        NE = self._n_energy_points(train_x)
         sig, sig0 = float(kernel.sigma), float(kernel.sigma0)
-        rs = torch.empty(N, dtype=dev.F64, device=Psi.device)
-        rs[:NE] = 1.0 / noise_e
-        rs[NE:] = 1.0 / noise_f
-        S = Psi * (sig * rs)[:, None]
-        yt = dev.to_dev(self.y_train).reshape(-1) * rs
-        G = dev.gemm(S, S, transa=True)
+        S, yt, rs, NE_loc = self._ws_share(train_x, species, noise_e, noise_f)      # this rank's rows
+        N, NE, F = len(self.y_train), self._n_energy_points(train_x), S.shape[1]
+        zeros = lambda *shape: torch.zeros(shape, dtype=dev.F64, device=S.device)
+        have = S.shape[0] > 0
+        G = dev.gemm(S, S, transa=True) if have else zeros(F, F)
+        b = dev.gemm(S, yt.reshape(-1, 1), transa=True) if have else zeros(F, 1)
+        yy = (yt * yt).sum().reshape(1) if have else zeros(1)
+        self._ws_sum(G, b, yy)
         G.diagonal().add_(1.0)
-        b = dev.gemm(S, yt.reshape(-1, 1), transa=True)
         info, dinv = dev.potrf_lower_(G, want_dinv=True)
         if int(info.item()) != 0:
             return (-np.inf, np.zeros(3)) if eval_gradient else (-np.inf,)
         u = b.clone()
         dev.trsm_lower_(G, u, dinv=dinv)
         dev.trsm_lower_(G, u, trans=True, dinv=dinv)                      # G^-1 b = Psi'^T alpha
-        quad = float((yt * yt).sum().item()) - dev.frob_dot(b, u).item()
+        quad = float(yy.item()) - dev.frob_dot(b, u).item()
         logdet = 2.0 * (NE * np.log(noise_e) + (N - NE) * np.log(noise_f)) + 2.0 * dev.sum_log_diag(G).item()
         MLL = -0.5 * quad - 0.5 * logdet - N / 2 * np.log(2 * np.pi)
         if not eval_gradient:
             return (MLL,)
         # every G^-1 quadratic form goes through C^-1 (G = C C^T): x^T G^-1 x = |C^-1 x|^2 keeps the cancellations below
         # (N_E / noise_e^2 - ..., 1 - ...) at working precision, which an explicit G^-1 (cond ~ 1e10) does not
-        Ci = torch.eye(F, dtype=dev.F64, device=Psi.device)
+        Ci = torch.eye(F, dtype=dev.F64, device=S.device)
         dev.trsm_lower_(G, Ci, dinv=dinv)                                   # C^-1
         tr_Ginv = dev.frob_dot(Ci, Ci).item()
         g_sigma = (dev.frob_dot(u, u).item() - (F - tr_Ginv)) / sig
-        alpha = rs * (yt - dev.gemm(S, u).reshape(-1))                     # (K+D)^-1 y
-        uE = (S[:NE] * rs[:NE, None]).sum(dim=0).reshape(-1, 1)            # Psi'^T D^-1 1_E
+        # row sums over this rank's rows, then over ranks: Psi'^T D^-1 1_E, sum of alpha over the energy rows, and the
+        # noise-column sums of alpha^2 - diag (K+D)^-1 over energy / force rows
+        if have:
+            alpha = rs * (yt - dev.gemm(S, u).reshape(-1))                 # (K+D)^-1 y, this rank's rows
+            uE = (S[:NE_loc] * rs[:NE_loc, None]).sum(dim=0).reshape(-1, 1)
+            W = dev.gemm(S, Ci, transb=True)                                # rows C^-1 s_i
+            a2 = alpha * alpha - rs * rs * (1.0 - dev.rowdot(W, W))        # alpha^2 - diag (K+D)^-1
+            sums = torch.stack((alpha[:NE_loc].sum(), a2[:NE_loc].sum(), a2[NE_loc:].sum()))
+        else:
+            uE, sums = zeros(F, 1), zeros(3)
+        self._ws_sum(uE, sums)
         zE = dev.gemm(Ci, uE)
         one_Kinv_one = NE / noise_e ** 2 - dev.frob_dot(zE, zE).item()
+        sums = sums.cpu().numpy()
         c0 = 0.8 * 2 * sig ** 2 * sig0                                      # dot_kernel.py:58 (sic)
-        g_sigma0 = 0.5 * c0 * (float(alpha[:NE].sum().item()) ** 2 - one_Kinv_one)
-        W = dev.gemm(S, Ci, transb=True)                                    # rows C^-1 s_i
-        kd = rs * rs * (1.0 - dev.rowdot(W, W))                             # diag (K+D)^-1
-        a2 = alpha * alpha - kd
-        g_noise = 0.5 * (2 * noise_e * a2[:NE].sum().item() + 2 * noise_f * a2[NE:].sum().item())
+        g_sigma0 = 0.5 * c0 * (float(sums[0]) ** 2 - one_Kinv_one)
+        g_noise = 0.5 * (2 * noise_e * float(sums[1]) + 2 * noise_f * float(sums[2]))
         return MLL, np.array([g_sigma, g_sigma0, g_noise])
 
     def optimize(self, fun, theta0, bounds, maxiter=10):
@@ -359,6 +365,9 @@ class GP():
         self._Linv_dev = None
         self._ws_cache = None
         self._host = {}
+        # what this fit describes: points queued later (add_structure replaces train_x / y_train by longer arrays, the
+        # old ones stay alive here) must not leak into a dense factorisation that is only formed on first access
+        self._fit_train_x, self._fit_y = dict(self.train_x), self.y_train
         if self.weight_space_fit and self._fit_weight_space():
             self._dense_pending = True          # L_, alpha_, _K_inv are factored on first access
             self.logging.info("Weight-space fit is complete")
@@ -373,15 +382,24 @@ class GP():
         self.N_queue = 0
         self.fits += 1
 
-    def _factor_dense(self):
-        """K + noise -> L -> alpha on the device (gaussianprocess.py:286-317)"""
-        K = self._train_K()
-        NE = self._n_energy_points(self.train_x)
+    def _factor_dense(self, lazy=False):
+        """K + noise -> L -> alpha on the device (gaussianprocess.py:286-317) for the training set of the last fit.
+        lazy: called from an attribute access after a weight-space fit -- possibly on one rank only, possibly after
+        more points were queued: no collective, and the set / targets as they were at fit time."""
+        train_x, y_train = self._fit_train_x, self._fit_y
+        K = self.kernel.k_total_dev(train_x, comm=None if lazy else self.comm)
+        NE = self._n_energy_points(train_x)
+        assert K.shape[0] == len(y_train), (K.shape, len(y_train))
         dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
-        info, dinv = dev.potrf_lower_(K, want_dinv=True)
+        if not lazy and self.comm.size > 1 and K.shape[0] >= self.dist_chol_min_n:
+            # rows of K block-cyclic over the ranks, panels exchanged over RCCL (distributed.py); L comes back replicated
+            from .distributed import DeviceOps, potrf_distributed
+            K, dinv, info = potrf_distributed(K, self.comm, DeviceOps())
+        else:
+            info, dinv = dev.potrf_lower_(K, want_dinv=True)
         if int(info.item()) != 0:
             raise np.linalg.LinAlgError(f"{int(info.item())}-th leading minor of K + noise is not positive definite")
-        alpha = dev.to_dev(self.y_train).clone()
+        alpha = dev.to_dev(y_train).clone()
         dev.trsm_lower_(K, alpha, dinv=dinv)
         dev.trsm_lower_(K, alpha, trans=True, dinv=dinv)
         self._dense = {"L": K, "alpha": alpha, "dinv": dinv}
@@ -392,6 +410,50 @@ class GP():
     #   M = sigma^4 Psi^T (K + D)^-1 Psi = sigma^2 (I - G^-1)
     # -- the same w and M the dense route derives from L and alpha (_weight_space), without forming K at all.
     weight_space_fit = True
+    dist_chol_min_n = 16384     # several ranks: matrices from this size on are factored with the rows spread over them
+
+    def _ws_share(self, train_x, species, noise_e, noise_f):
+        """This rank's share of the weight-space system: (S, y~, rs, NE_local) with S = D^-1/2 sigma Psi for the rows of
+        the rank's energy points followed by those of its force points, y~ = D^-1/2 y, rs = D^-1/2.  One rank: all
+        rows.  Everything the fit and the log-marginal likelihood need is a sum over rows (S^T S, S^T y~, ...), so the
+        ranks exchange only F x F matrices, F-vectors and scalars (`_ws_sum`): the feature rows -- the expensive part,
+        24.6 kflop per descriptor row -- are computed once, on the rank that owns the point."""
+        kernel = self.kernel
+        NE_all = self._n_energy_points(train_x)
+        y_all = np.asarray(self.y_train).reshape(-1)
+        if self.comm.size > 1:
+            from .distributed import shard_points, slice_energy, slice_force
+            E, Fc = train_x["energy"], train_x["force"]
+            key = (id(E[0]), id(Fc[0]), self.comm.rank, self.comm.size)
+            if getattr(self, "_ws_sub_key", None) != key:            # keep the slices alive: the pack cache keys on them
+                e0, e1, f0, f1 = shard_points(E[-1], Fc[-1], self.comm.size)[self.comm.rank]
+                sub = {}
+                if e1 > e0:
+                    sub["energy"] = slice_energy(E, e0, e1)
+                if f1 > f0:
+                    sub["force"] = slice_force(Fc, f0, f1)
+                self._ws_sub_key, self._ws_sub = key, (sub, (e0, e1, f0, f1))
+            sub, (e0, e1, f0, f1) = self._ws_sub
+            y = np.concatenate((y_all[e0:e1], y_all[NE_all + 3 * f0:NE_all + 3 * f1]))
+            NE = e1 - e0
+        else:
+            sub, y, NE = train_x, y_all, NE_all
+        nfeat = len(species) * (kernel.feature_dim(train_x))
+        if len(y) == 0:
+            z = torch.zeros((0, nfeat), dtype=dev.F64, device=dev.device())
+            return z, z[:, 0], z[:, 0], 0
+        Psi = kernel._psi(sub, species)
+        rs = torch.empty(Psi.shape[0], dtype=dev.F64, device=Psi.device)
+        rs[:NE] = 1.0 / noise_e
+        rs[NE:] = 1.0 / noise_f
+        S = Psi * (float(kernel.sigma) * rs)[:, None]
+        return S, dev.to_dev(y).reshape(-1) * rs, rs, NE
+
+    def _ws_sum(self, *tensors):
+        """sum over ranks, in place (one all-reduce per tensor; no-op with one rank)"""
+        for t in tensors:
+            self.comm.all_reduce_sum_(t)
+        return tensors[0] if len(tensors) == 1 else tensors
 
     def _fit_weight_space(self):
         if not hasattr(self.kernel, "_feature_path"):
@@ -400,24 +462,19 @@ class GP():
         species = self.kernel._feature_path(train_x, None, self.kernel.zeta)
         if species is None:
             return False
-        Psi = self.kernel._psi(train_x, species)                                  # [N, F]
-        N, F = Psi.shape
-        NE = self._n_energy_points(train_x)
-        rs = torch.empty(N, dtype=dev.F64, device=Psi.device)                    # D^-1/2
-        rs[:NE] = 1.0 / self.noise_e
-        rs[NE:] = 1.0 / self.noise_f
+        S, y, rs, NE = self._ws_share(train_x, species, self.noise_e, self.noise_f)    # rows of this rank
+        F = S.shape[1]
         sig = float(self.kernel.sigma)
-        S = Psi * (sig * rs)[:, None]                                             # D^-1/2 Psi'
-        y = dev.to_dev(self.y_train).reshape(-1) * rs
-        G = dev.gemm(S, S, transa=True)
+        G = dev.gemm(S, S, transa=True) if S.shape[0] else torch.zeros((F, F), dtype=dev.F64, device=S.device)
+        b = (dev.gemv_t(S, y) if S.shape[0] else torch.zeros(F, dtype=dev.F64, device=S.device)).reshape(-1, 1)   # Psi'^T D^-1 y
+        self._ws_sum(G, b)
         G.diagonal().add_(1.0)
-        b = dev.gemv_t(S, y).reshape(-1, 1)                                       # Psi'^T D^-1 y
         info, dinv = dev.potrf_lower_(G, want_dinv=True)
         if int(info.item()) != 0:
             return False
         dev.trsm_lower_(G, b, dinv=dinv)
         dev.trsm_lower_(G, b, trans=True, dinv=dinv)                              # G^-1 b
-        Ci = torch.eye(F, dtype=dev.F64, device=Psi.device)
+        Ci = torch.eye(F, dtype=dev.F64, device=G.device)
         dev.trsm_lower_(G, Ci, dinv=dinv)                                         # C^-1, G = C C^T
         # M = sigma^2 (I - G^-1) is formed from C^-1 only when the unfactored variance form asks for it (_ws_M)
         self._ws_cache = [species, None, b * sig, Ci]                     # Ci = C^-1 feeds the factored variance form
@@ -890,12 +947,20 @@ class GP():
             # the status words are written by the last kernel of the call: poll them in host memory (a blocking stream
             # synchronisation sleeps and wakes tens of microseconds late); everything queued before that kernel has
             # completed, in stream order, when they appear
-            spins = 0
-            while self._poll_results and np.isnan(tailw).any():
-                spins += 1
-                if spins > 200000:                    # ~0.3 s without an answer: let the runtime report what happened,
-                    self._poll_results = False        # and stop polling (host memory that is not coherent with the device)
-            if not self._poll_results:
+            polled = self._poll_results
+            if polled:
+                deadline = None
+                while np.isnan(tailw).any():
+                    if deadline is None:
+                        deadline = time.perf_counter() + 2.0 + 1e-3 * len(mine_strucs)
+                    elif time.perf_counter() > deadline:      # no answer in seconds: let the runtime report what happened
+                        polled = False
+                        if not GP._poll_warned:
+                            GP._poll_warned = True
+                            self.logging.warning("batched prediction: status words did not appear in host memory in time; "
+                                                 "falling back to a stream synchronisation for this call")
+                        break
+            if not polled:
                 torch.cuda.current_stream().synchronize()
             host = view.copy()                        # the pinned buffer is reused by the next call
             if host[nout + 1] == 0.0:
@@ -916,7 +981,8 @@ class GP():
     _pinned_out = None
     _last_counts = None
     _last_layout = None
-    _poll_results = True
+    _poll_results = True        # False: always synchronise the stream instead of polling the status words
+    _poll_warned = False
 
     native_batch = True
     device_single = True

@@ -61,6 +61,13 @@ class Dot_mb(DeviceKernel):
                         out.update(np.unique(np.asarray(ele)).tolist())
         return tuple(sorted(int(z) for z in out))
 
+    def feature_dim(self, data):
+        """features per species of the zeta = 2 map: d (d + 1) / 2 quadratic monomials + the constant"""
+        ent = data["force"] if "force" in data and n_points(data["force"]) > 0 else data["energy"]
+        X = ent.x if isinstance(ent, dev.SetPair) else ent[0]
+        d = int(X.shape[1])
+        return d * (d + 1) // 2 + 1
+
     def _psi(self, data, species):
         """Psi = [Psi_E ; Psi_F] of a data dictionary (csrc/features.hip), cached with the packed sets"""
         parts = []

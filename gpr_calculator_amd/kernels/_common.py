@@ -102,8 +102,19 @@ class DeviceKernel:
 
         transpose=True returns K(data1, data2)^T, computed directly in that layout, with data1
         still on the streamed side (predict: data1 = structures, data2 = training set).
-        comm (parallel.Comm of size > 1): the point-pair tasks of every block are dealt round-robin to the
-        ranks and the partial matrices summed with one all-reduce (exact: each element has one owner)."""
+        comm (parallel.Comm of size > 1), covariance of one set with itself (fit, log-marginal likelihood): the points
+        are cut into contiguous shards, every rank computes the lower-trapezoid row slab of its shard and the slabs are
+        all-gathered (distributed.assemble_sharded).  Two different sets: the point-pair tasks of every block are dealt
+        round-robin to the ranks and the partial matrices summed with one all-reduce (each element has one owner)."""
+        if comm is not None and comm.size > 1 and data2 is None and not transpose:
+            from ..distributed import DeviceOps, assemble_sharded
+
+            def block_fn(d1, d2):
+                out = self._assemble(d1, d2, kp_ee, kp_ef, kp_ff, grad=grad)
+                return out[:2] if grad else (out,)
+            mats = assemble_sharded(data1, comm, block_fn, DeviceOps(), nmat=2 if grad else 1)
+            nE = n_points(data1["energy"]) if "energy" in data1 and len(data1["energy"]) > 0 else 0
+            return (mats[0], mats[1], nE) if grad else mats[0]
         if comm is not None and comm.size > 1:
             dev.set_shard(comm.size, comm.rank)
             try:

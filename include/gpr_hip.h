@@ -308,6 +308,22 @@ int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev
 /* same, and additionally stores the inverse of every 64 x 64 diagonal block of L (zero padded, row-major,
  * block b at dinv + b*4096) into the device buffer dinv[ceil(n/64)*4096] */
 int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv);
+/* Pieces of the factorisation for a matrix whose rows are spread over several GPUs (1-D block-cyclic row blocks of 256;
+ * gpr_calculator_amd/distributed.py drives them, RCCL moves `ops` and the panels):
+ *   gpr_potrf_diag_block   factor the kb x kb (kb <= 256) diagonal block at a in place and write its operand tiles
+ *                          (gpr_potrf_ops_doubles() doubles) to ops
+ *   gpr_potrf_panel_rows   p[rows, kb] <- p L_kk^-T for `rows` rows of the panel below that block, from ops
+ *   gpr_gemm_nt_cyclic_lower   the trailing update C -= A B^T of this rank's rows, skipping tiles above the global diagonal
+ *   gpr_potrf_finish       dinv (as gpr_potrf_lower_dinv) of an assembled factor and zeroing of its strict upper triangle
+ *   gpr_mirror_lower       a[i][j] = a[j][i] for j > i (covariance matrix gathered from lower-trapezoid row slabs)        */
+int gpr_potrf_ops_doubles(void);
+int gpr_potrf_diag_block(void *stream, int kb, double *a, long long lda, int k0, int *info_dev, double *ops);
+int gpr_potrf_panel_rows(void *stream, int kb, const double *ops, double *p, long long lda, int rows);
+int gpr_gemm_nt_cyclic_lower(void *stream, int m, int n, int k, double alpha, const double *a, long long lda,
+                             const double *b, long long ldb, double beta, double *c, long long ldc, int nb, int nranks,
+                             int rank, int lb0, int col0);
+int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, double *dinv);
+int gpr_mirror_lower(void *stream, int n, double *a, long long lda);
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
 int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                    double *b, long long ldb);

@@ -10,7 +10,9 @@ What each placeholder is:
                       gaussianprocess.py:788,847; utilities.py:109)
   ase.neighborlist    gpr_calculator_amd.neighbors.NeighborListCompat (same three calls; unpinned third party)
   ase.constraints     FixAtoms with get_indices() (gaussianprocess.py:823-832)
-  ase.db, ase.calculators..., matplotlib   import-only placeholders (never called by the generators)
+  ase.calculators.calculator   Calculator = the ASE-less stand-in of gpr_calculator_amd/calculator.py (parameters,
+                      results, atoms copy: what GPR relies on), all_changes
+  ase.db, matplotlib  import-only placeholders (never called by the generators)
   cffi.FFI            new / buffer / release over ctypes arrays (rbf_kernel.py:40-80, 246-329)
   gpr_calc.kernels._rbf_kernel.lib / _dot_kernel.lib
                       ctypes handles of oracle/_ref/lib{rbf,dot}_ref.so = the UNMODIFIED reference C++
@@ -140,6 +142,43 @@ class RefAtoms(SimpleAtoms):
         self.constraints = [FixAtoms(list(fixed))] if len(fixed) else []
 
 
+class Cell:
+    """ase.cell.Cell as far as calculator.py:58-59 and the descriptor use it: an `array` attribute, array protocol"""
+
+    def __init__(self, a):
+        self.array = np.array(a, dtype=float).reshape(3, 3)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.array if dtype is None else self.array.astype(dtype)
+
+    def copy(self):
+        return Cell(self.array.copy())
+
+
+class CalcAtoms(RefAtoms):
+    """RefAtoms + what GPR.calculate touches on an ase.Atoms: cell.array, calc, get_potential_energy / get_forces, copy"""
+
+    def __init__(self, numbers, positions, cell=None, pbc=False, fixed=()):
+        super().__init__(numbers, positions, np.asarray(cell), pbc, fixed)
+        self.cell = Cell(cell)
+        self.calc = None
+
+    def get_cell(self):
+        return self.cell.array
+
+    def get_volume(self):
+        return abs(np.linalg.det(self.cell.array))
+
+    def get_potential_energy(self):
+        return self.calc.get_potential_energy(self)
+
+    def get_forces(self):
+        return self.calc.get_forces(self)
+
+    def copy(self):
+        return CalcAtoms(self.numbers.copy(), self.positions.copy(), self.cell.array.copy(), self.pbc.copy(), self.fixed.copy())
+
+
 class _Element:
     def __init__(self, symbol):
         self.z = atomic_number(symbol)
@@ -173,6 +212,9 @@ def import_reference(rank=0, size=1):
     _module("ase.neighborlist", NeighborList=NeighborListCompat, PrimitiveNeighborList=None)
     _module("ase.constraints", FixAtoms=FixAtoms, full_3x3_to_voigt_6_stress=None)
     _module("ase.db", connect=None)
+    from gpr_calculator_amd import calculator as _own          # its ASE-less Calculator stand-in: parameters / results /
+    _module("ase.calculators")                                 # atoms bookkeeping of ase.calculators.calculator.Calculator
+    _module("ase.calculators.calculator", Calculator=_own.Calculator, all_changes=_own.all_changes)
     plt = _module("matplotlib.pyplot")
     _module("matplotlib", use=lambda *a, **k: None, pyplot=plt)
     _module("cffi", FFI=FFI)
@@ -190,5 +232,6 @@ def import_reference(rank=0, size=1):
     ns.Dot_mb = _load("gpr_calc.kernels.Dot_mb", os.path.join(kdir, "Dot_mb.py"))
     ns.SO3 = _load("gpr_calc.SO3", os.path.join(REF, "gpr_calc", "SO3.py"))
     ns.gaussianprocess = _load("gpr_calc.gaussianprocess", os.path.join(REF, "gpr_calc", "gaussianprocess.py"))
+    ns.calculator = _load("gpr_calc.calculator", os.path.join(REF, "gpr_calc", "calculator.py"))
     ns.comm = comm
     return ns

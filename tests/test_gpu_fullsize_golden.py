@@ -1,0 +1,118 @@
+"""GPU, full size, against the reference itself: BASELINE.json configs 2 and 3 built exactly as bench.py builds them,
+compared with fixtures the reference's own Python + C++ produced at that size (tests/golden/make_golden_cfg.py;
+~50 core-minutes of the reference's dot_kff_many / rbf_kff_many in the build container).
+  cfg3 (headline): Dot kernel, N_train = 2000 force environments + 63 energies, N = 6063 -- the one-call native batch
+        route (descriptor -> feature rows -> weight-space mean / variance) against the reference's GP.predict;
+  cfg2: RBF kernel, N_train = 500 (N = 1516) -- fit(opt=False) + predict_structure, the log-marginal likelihood and its
+        gradient, then fit(opt=True, maxiter=10) as the calculator triggers it."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+E_TOL, F_TOL = 1e-6, 1e-5
+# The reference evaluates var = diag - k K^-1 k through an explicit N x N inverse (gaussianprocess.py:128-131, 903-907);
+# at these sizes its rounding noise on the VARIANCE is ~1e-7..1e-6 (cond(K + noise) * eps * diag) -- as large as the
+# energy variance itself: for image 37 of cfg3 the reference's energy variance came out negative and was clamped to 0.
+# The recorded standard deviations are therefore compared on the variance with that absolute bound; the stable
+# evaluation is pinned at the north-star tolerance by the small fixtures (test_gpu_gp_golden.check_std) and, here, by
+# the agreement of the weight-space and the dense route.
+VAR_NOISE = 1e-6
+
+
+def build(kind, n_train):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    kern = Dot_mb(para=[2.0, 2.0], zeta=2.0) if kind == "Dot" else RBF_mb(para=[2.5, 1.3], zeta=2.0)
+    gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0), noise_e=0.002, noise_f=0.1,
+            log_file="/tmp/gpr_test.log")
+    rows, left = [], n_train
+    for s in range(math.ceil(n_train / 32)):
+        a = fcc_cell(seed=s)
+        E, F = lj_energy_forces(a)
+        take = min(32, left)
+        rows.append((a, E, F, True, list(range(take))))
+        left -= take
+    gp.set_train_pts(gp.points_from_structures(rows))
+    return gp
+
+
+def images(z):
+    from gpr_calculator_amd.synthetic import neb_images
+    imgs = neb_images(64)
+    out = []
+    for k in range(int(z["n_tests"])):
+        a = imgs[int(z[f"test{k}_image"])]
+        assert np.abs(a.positions - z[f"test{k}_positions"]).max() == 0.0      # the seeded generator is the fixture's
+        a.fixed = np.asarray(z[f"test{k}_fixed"], dtype=np.int64)
+        out.append(a)
+    return out
+
+
+def test_cfg3_dot_native_batch_matches_the_reference_at_full_size():
+    z = np.load(os.path.join(GOLD, "gp_cfg3_dot.npz"))
+    gp = build("Dot", int(z["n_train"]))
+    assert len(gp.y_train) == int(z["N"]) == 6063 and np.abs(gp.y_train - z["y_train"]).max() < 1e-12
+    gp.fit(show=False, opt=False)                                   # weight-space fit (F x F system)
+    assert gp._dense_pending
+    strucs = images(z)
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(strucs, return_std=True)     # gpr_predict_dot2_batch
+    for k in range(len(strucs)):
+        assert abs(Es[k] - float(z[f"test{k}_E"])) < E_TOL, (k, Es[k], float(z[f"test{k}_E"]))
+        assert np.abs(Fs[k] - z[f"test{k}_F"]).max() < F_TOL
+        assert abs(Es_std[k] ** 2 - float(z[f"test{k}_E_std"]) ** 2) < VAR_NOISE, (k, Es_std[k], float(z[f"test{k}_E_std"]))
+        assert np.abs(Fs_std[k] ** 2 - z[f"test{k}_F_std"] ** 2).max() < VAR_NOISE
+        assert np.all(Fs[k][z[f"test{k}_fixed"]] == 0)
+    # one by one through predict_structure: the same numbers
+    E1, F1, _, s1, fs1 = gp.predict_structure(strucs[2], stress=False, return_std=True)
+    assert abs(E1 - Es[2]) < 1e-9 and np.abs(F1 - Fs[2]).max() < 1e-9 and abs(s1 - Es_std[2]) < 1e-9
+    # the log-marginal likelihood of the weight-space route against the reference's dense evaluation
+    lml = gp.log_marginal_likelihood(np.array([2.0, 2.0]))
+    assert abs(lml - float(z["lml"])) < 1e-7 * abs(float(z["lml"]))
+    # dense quantities, factored lazily: alpha and the diagonal of L against the reference's scipy factorisation
+    assert np.abs(np.diag(gp.L_) - z["L_diag"]).max() < 1e-7 * np.abs(z["L_diag"]).max()
+    assert np.abs(gp.alpha_ - z["alpha"]).max() < 1e-4 * np.abs(z["alpha"]).max()
+    rows = z["K_probe_rows"]
+    K = gp.kernel.k_total(gp.train_x)
+    assert np.abs(K[rows] - z["K_probe"]).max() < 1e-12 * np.abs(z["K_probe"]).max()
+    # and the dense prediction route (K_trans alpha, triangular variance) agrees with the reference too
+    gp.weight_space_fit = False
+    gp.fit(show=False, opt=False)
+    gp.native_batch = False
+    Ed, Fd, Ed_std, Fd_std = gp.predict_structures(strucs[:1], return_std=True)
+    assert abs(Ed[0] - float(z["test0_E"])) < E_TOL and np.abs(Fd[0] - z["test0_F"]).max() < F_TOL
+    assert abs(Ed_std[0] - Es_std[0]) < E_TOL and np.abs(Fd_std[0] - Fs_std[0]).max() < F_TOL
+
+
+def test_cfg2_rbf_fit_predict_lml_match_the_reference_at_its_own_size():
+    z = np.load(os.path.join(GOLD, "gp_cfg2_rbf.npz"))
+    gp = build("RBF", int(z["n_train"]))
+    assert len(gp.y_train) == int(z["N"]) == 1516
+    gp.fit(show=False, opt=False)
+    assert np.abs(np.diag(gp.L_) - z["L_diag"]).max() < 1e-7 * np.abs(z["L_diag"]).max()
+    assert np.abs(gp.alpha_ - z["alpha"]).max() < 1e-4 * np.abs(z["alpha"]).max()
+    for k, a in enumerate(images(z)):
+        E, F, _, E_std, F_std = gp.predict_structure(a, stress=False, return_std=True, f_tol=1e-12)
+        assert abs(E - float(z[f"test{k}_E"])) < E_TOL and np.abs(F - z[f"test{k}_F"]).max() < F_TOL
+        assert abs(E_std ** 2 - float(z[f"test{k}_E_std"]) ** 2) < VAR_NOISE
+        assert np.abs(F_std ** 2 - z[f"test{k}_F_std"] ** 2).max() < VAR_NOISE
+    for k in range(2):
+        if f"lml{k}" not in z.files:
+            continue
+        lml, g = gp.log_marginal_likelihood(z[f"lml{k}_theta"].copy(), eval_gradient=True)
+        assert abs(lml - float(z[f"lml{k}"])) < 1e-7 * abs(float(z[f"lml{k}"]))
+        assert np.abs(g - z[f"lml{k}_grad"]).max() < 1e-5 * np.abs(z[f"lml{k}_grad"]).max()
+    # the refit the calculator triggers: L-BFGS-B on the device-evaluated objective must not make it worse
+    gp.kernel.update([2.5, 1.3])
+    lml0 = gp.log_marginal_likelihood(np.array([2.5, 1.3]))
+    gp.fit(show=False, opt=True, maxiter=10)
+    lml1 = gp.log_marginal_likelihood(np.array(gp.kernel.parameters()))
+    assert lml1 >= lml0 and gp.N_queue == 0
+    E, F, _, E_std, F_std = gp.predict_structure(images(z)[0], stress=False, return_std=True)
+    assert np.isfinite(E) and np.isfinite(F).all() and E_std >= 0

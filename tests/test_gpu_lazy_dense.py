@@ -1,0 +1,59 @@
+"""GPU: state that is formed lazily or polled must not depend on when it is asked for.
+  * a weight-space fit (Dot, zeta = 2) leaves the N x N factorisation to the first access of L_ / alpha_ / _K_inv /
+    the stress route; points queued by add_structure in between must not leak into it;
+  * the batched prediction polls status words in host memory; the stream-synchronising fallback gives the same bits."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(weight_space, stress=True):
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    gp = GP(kernel=Dot_mb(para=[2.0, 2.0], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0, stress=stress),
+            noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+    gp.weight_space_fit = weight_space
+    rows = []
+    for s in range(4):
+        a = fcc_cell(seed=s, reps=1, species=(46, 78), sigma=0.08)
+        E, F = lj_energy_forces(a)
+        rows.append((a, E, F, True, [0, 2, 3]))
+    gp.fit(gp.points_from_structures(rows), show=False, opt=False)
+    return gp
+
+
+def test_lazy_dense_factor_ignores_points_queued_after_the_fit():
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    dense, lazy = _model(False), _model(True)
+    assert lazy._dense_pending and not dense._dense_pending
+    new = fcc_cell(seed=70, reps=1, species=(46, 78), sigma=0.2)
+    E, F = lj_energy_forces(new)
+    for gp in (dense, lazy):
+        gp.add_structure((new, E, F.copy()))
+        assert gp.N_queue > 0
+    # first touch of the dense quantities happens AFTER the queue grew
+    assert lazy.alpha_.shape == dense.alpha_.shape == (len(dense._fit_y), 1)
+    assert np.abs(lazy.alpha_ - dense.alpha_).max() <= 1e-9 * np.abs(dense.alpha_).max()
+    assert np.abs(lazy.L_ - dense.L_).max() <= 1e-11 * np.abs(dense.L_).max()
+    t = fcc_cell(seed=71, reps=1, species=(46, 78), sigma=0.08)
+    E1, F1, S1 = dense.predict_structure(t, stress=True, return_std=False, f_tol=1e-12)
+    E2, F2, S2 = lazy.predict_structure(t, stress=True, return_std=False, f_tol=1e-12)
+    assert abs(E1 - E2) < 1e-7 and np.abs(F1 - F2).max() < 1e-7 and np.abs(S1 - S2).max() < 1e-7
+    assert lazy.N_queue > 0                                     # nothing refitted behind the caller's back
+
+
+def test_polled_and_synchronised_results_are_identical():
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model(True, stress=False)                             # the one-call native batch route
+    batch = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(5)]
+    batch[2].fixed = np.array([1])
+    a = gp.predict_structures(batch, return_std=True)
+    gp._poll_results = False
+    b = gp.predict_structures(batch, return_std=True)
+    gp._poll_results = True
+    for x, y in zip(a, b):
+        for u, v in zip(x, y):
+            assert np.array_equal(np.asarray(u), np.asarray(v))
