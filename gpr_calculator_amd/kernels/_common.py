@@ -63,7 +63,7 @@ class PackCache:
         if len(self._items) >= self.capacity:
             dead = [k for k, v in self._items.items() if v[0]() is None]
             for k in dead or list(self._items)[:1]:
-                self._items.pop(k)
+                self._items.pop(k, None)
         self._items[key] = (ref, packed)
         return packed
 
