@@ -14,9 +14,11 @@ back on the host.
 
 One JSON line on stdout (rank 0).  Extra objects: "roofline" for the kernel with the largest summed HIP-event
 time of the timed region (plus the same figures for every profiled kernel of the step under "per_kernel" and,
-for the Dot run, the same step through the row-pair kernels under "pair_route") and "cpu_baseline" (the
-reference's CPU natives -- oracle/_ref if present, else the oracle's C port -- timed on a bounded sample of
-the same predict workload on the host cores).
+for the Dot run, the same step through the row-pair kernels under "pair_route") and "cpu_baseline" (one structure of
+the same predict workload through the reference's CPU path -- oracle descriptor, the reference's C++ natives from
+oracle/_ref if present (else the oracle's C port) on a bounded sample, numpy mean / variance -- on the host cores,
+oracle/cpu_baseline.py, run in child processes before this process touches the GPU).
+`--mode fit` times fit(opt=False) instead (strong scaling over ranks).
 """
 import argparse
 import json
@@ -77,55 +79,66 @@ def same_species_pairs(ele1, ele2):
     return float(sum(c * d2.get(z, 0) for z, c in zip(z1.tolist(), c1.tolist())))
 
 
-def cpu_baseline(gp, batch, budget_s=20.0):
-    """Reference CPU path on a bounded sample: one structure of the batch against a slice of the training
-    force rows sized for ~budget_s of single-core rbf/dot_kff_many work, one process per host core on
-    disjoint slices of the predicted structure's rows (the reference's MPI row chunking,
-    RBF_mb.py:471-481).  Extrapolated by pair count to structures/s of the full predict workload."""
-    import multiprocessing as mp
-    from oracle.natives import NativeSet
-    kind = "reference" if NativeSet.available("ref") else "port"
+def cpu_baseline(kernel, n_train, budget_s=20.0):
+    """The reference's CPU path on this box's host cores for one predicted structure of the same workload: oracle
+    descriptor + the reference's C++ natives of K_trans (force-force block on a bounded sample, extrapolated by pair
+    count) + mean / explicit-inverse variance in numpy (oracle/cpu_baseline.py).  Runs as a child process that never
+    loads HIP, started BEFORE this process touches the GPU."""
+    import subprocess
     cores = max(1, min(16, os.cpu_count() or 1))
-    d = gp.descriptor.calculate(batch[0])
-    from gpr_calculator_amd.utilities import species_numbers
-    ele = species_numbers(d["elements"])
-    data, _ = gp._structure_data(batch[0], d)
-    Xf, dXf, Ef, cntf = data["force"]
-    tX, tdX, tE, tcnt = gp.train_x["force"]
-    is_dot = gp.kernel.name == "Dot"
-    rate_guess = 0.26e6                                   # row pairs / s / core (BASELINE.md section 2)
-    n_rows2 = int(min(len(tX), max(64, budget_s * rate_guess * cores / len(Xf))))
-    full_pairs = float(len(Xf)) * len(tX) + len(d["x"]) * len(tX) + len(Xf) * len(gp.train_x["energy"][0])
-    chunks = np.array_split(np.arange(len(Xf)), cores)
-    jobs = [(kind, is_dot, Xf[c], dXf[c], Ef[c], tX[:n_rows2], tdX[:n_rows2], tE[:n_rows2]) for c in chunks if len(c)]
-    t0 = time.perf_counter()
-    with mp.get_context("fork").Pool(len(jobs)) as pool:
-        pool.map(_cpu_job, jobs)
-    wall = time.perf_counter() - t0
-    sample_pairs = float(len(Xf)) * n_rows2
-    per_struct = wall * full_pairs / sample_pairs
-    return {"value": 1.0 / per_struct, "unit": "structures/s", "cores": len(jobs), "kind": kind,
-            "sample": f"force-force block of 1 structure ({len(Xf)} rows) x {n_rows2} of {len(tX)} training force rows "
-                      f"({sample_pairs:.3g} row pairs in {wall:.1f} s wall on {len(jobs)} processes), extrapolated by "
-                      f"pair count to the full K_trans of one structure ({full_pairs:.3g} pairs); descriptor, "
-                      f"Cholesky solve and variance excluded (they favour the CPU figure)"}
+    cmd = [sys.executable, "-m", "oracle.cpu_baseline", "--kernel", kernel, "--n-train", str(n_train), "--procs", str(cores),
+           "--budget", str(budget_s)]
+    try:
+        res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as exc:                                  # the baseline must never take the GPU measurement down
+        return {"value": None, "unit": "structures/s", "cores": cores, "kind": "unavailable", "sample": repr(exc)}
 
 
-def _cpu_job(job):
-    kind, is_dot, x1, dx1, e1, x2, dx2, e2 = job
-    from oracle.natives import NativeSet
-    ns = NativeSet("ref" if kind == "reference" else "port")
-    n1, n2, d = len(x1), len(x2), x1.shape[1]
-    i1, i2 = np.zeros(n1, np.int32), np.zeros(n2, np.int32)
-    out = np.zeros((1, 3, 1, 3))
-    c = np.ascontiguousarray
-    if is_dot:
-        ns.call("dot_kff_many", n1, n2, 0, n2, d, 1, 2.0, c(x1), c(dx1), c(e1, np.int32), i1, c(x2), c(dx2),
-                c(e2, np.int32), i2, out)
-    else:
-        ns.call("rbf_kff_many", n1, n2, 0, n2, d, 1, 2.0, 6.25, 1.69, 1e-8, c(x1), c(dx1), c(e1, np.int32), i1,
-                c(x2), c(dx2), c(e2, np.int32), i2, out)
-    return float(out.sum())
+def fit_mode(args, comm, gp, dev):
+    """--mode fit: the fit itself as the timed step (strong scaling: the same training set on N ranks).  One step =
+    fit(opt=False): covariance row slabs of the rank's point shard + all-gather + Cholesky (block-cyclic over the ranks
+    from GP.dist_chol_min_n rows on) + alpha on the dense route; per-rank feature rows + all-reduce of the F x F system
+    on the weight-space route of the Dot kernel at zeta = 2."""
+    rank, world = comm.rank, comm.size
+    results = {}
+    for route, ws in (("dense", False), ("weight_space", True)):
+        if ws and args.kernel != "Dot":
+            continue
+        gp.weight_space_fit = ws
+        for _ in range(args.warmup):
+            gp.fit(show=False, opt=False)
+        comm.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            gp.fit(show=False, opt=False)
+        torch.cuda.synchronize(); comm.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            el = float(t.item())
+        results[route] = el / args.steps * 1e3
+    if rank == 0:
+        N = len(gp.y_train)
+        R = len(gp.train_x["force"][0])
+        head = "weight_space" if "weight_space" in results else "dense"
+        pairs = 0.5 * float(R) * R
+        line = {"metric": "GPR fit ms at N_train=%d" % args.n_train, "value": results[head], "unit": "ms", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": results[head], "higher_is_better": False,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"fit(opt=False) of the cfg3-shaped training set: N_train={args.n_train} force environments "
+                                       f"(N={N}, {R} force rows), {args.kernel} kernel", "kernel": args.kernel, "N": N,
+                           "fit_ms": results, "parallelism": f"training points sharded x{world}: row slabs + all-gather"
+                                                             f"{'; block-cyclic Cholesky' if world > 1 and N >= gp.dist_chol_min_n else ''}"},
+                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
+                             "achieved": (pairs * FLOP_PER_PAIR_FF + N ** 3 / 3.0) / (results["dense"] * 1e-3) / 1e12 / world,
+                             "frac": (pairs * FLOP_PER_PAIR_FF + N ** 3 / 3.0) / (results["dense"] * 1e-3) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS,
+                             "traffic": None, "kernel": "dense fit: kblock_kernel<FF> (lower triangle of the force-force block) + Cholesky",
+                             "work_unit": "1.10 kflop per row pair of the lower triangle + N^3 / 3, per GPU"},
+                "cpu_baseline": None}
+        print(json.dumps(line))
 
 
 def main():
@@ -138,7 +151,12 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-route", action="store_true", help="skip the extra pair-kernel measurement of the Dot run")
+    ap.add_argument("--mode", default="predict", choices=["predict", "fit"])
     args = ap.parse_args()
+    # the CPU baseline first, in child processes, before this process loads the HIP runtime (N = 1, rank 0 only)
+    cpu = None
+    if args.mode == "predict" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.kernel, args.n_train)
 
     from gpr_calculator_amd import _lib, device as dev
     from gpr_calculator_amd.parallel import init_from_env
@@ -150,6 +168,11 @@ def main():
     _lib.require_gpu()
 
     gp = build_model(args.kernel, args.n_train, comm)
+    if args.mode == "fit":
+        fit_mode(args, comm, gp, dev)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
     # fit(opt=False): with the Dot kernel at zeta = 2 the model is fitted in weight space (F x F system); the dense
     # route (K assembly sharded over ranks + N x N Cholesky + alpha) is what every other kernel takes and what
     # L_ / alpha_ / _K_inv trigger lazily -- both are timed
@@ -278,9 +301,6 @@ def main():
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                                           "ms_per_step": pr_ms, "structures_per_s": args.batch / (pr_ms * 1e-3),
                                           "work_unit": "1.10 kflop per same-species row pair (SURVEY.md section 8d)"}
-        cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(gp, batch)
         line = {"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": value,
                 "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

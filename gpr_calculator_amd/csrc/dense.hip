@@ -565,6 +565,7 @@ __global__ void __launch_bounds__(256) ws_tail_combine_kernel(int m, int npart, 
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (s_last && threadIdx.x < 4) status_dst[threadIdx.x] = (double)status_src[threadIdx.x];
+    if (s_last && threadIdx.x == 0) *done = 0;      // ready for the next launch: no memset (a 5 us fill kernel) per call
 }
 
 __global__ void ws_status_kernel(const int *src, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)src[threadIdx.x]; }
@@ -959,13 +960,14 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
         }
         const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
         void *wsp;
-        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double) + 16, st);
+        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double), st);
         if (rc) return rc;
         double *part = (double *)wsp, *mn = part + (size_t)npart * m;
-        int *done = (int *)(mn + 2 * (size_t)m);
-        if (status_dst) {
-            const hipError_t me = hipMemsetAsync(done, 0, sizeof(int), st);
-            if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
+        // arrival counter of the combine launch: one device int per process, zeroed once, reset by the last arriver
+        static int *done = nullptr;
+        if (!done) {
+            GPR_HIP_TRY(hipMalloc((void **)&done, sizeof(int)));
+            GPR_HIP_TRY(hipMemset(done, 0, sizeof(int)));
         }
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R2, 2>), dim3(npart, nrb2), dim3(256), wt_lds_bytes<R2>(), st, m, n, P, ldp, Cinv, ldc, w, diag,

@@ -4,6 +4,7 @@
 // from one host call.  It only composes the library's own entry points (nbr.hip, so3.hip, features.hip, dense.hip);
 // the single synchronisation is the size download inside gpr_nbr_build_device, and none with guessed capacities.
 #include <algorithm>
+#include <cmath>
 #include "gpr_internal.h"
 
 extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
@@ -108,4 +109,137 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     }
     if ((rc = gpr_nbr_info_to(nb, out_dev + (want_std ? 2 : 1) * m))) return cleanup(rc);
     return cleanup(GPR_OK);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Host-in / host-out form of the same prediction: the model stays in the session, the caller hands over the structures
+// as host arrays and gets E, F, E_std, F_std back as host arrays -- what GP.predict_structure returns per structure
+// (gaussianprocess.py:880-911), for a whole batch.  The session owns the page-locked result buffer the device writes
+// into, polls its status words instead of blocking on the stream, guesses the neighbour-table capacities from the
+// densest batch it has seen and repeats a call whose guess was too small.
+struct gpr_dot2_session {
+    hipStream_t st;
+    int nmax, lmax, nseg, ncheb, weight_on, ns, want_std;
+    double rcut, alpha, sigma, sigma0;
+    const double *table, *w, *M, *Cinv;
+    std::vector<int> species;
+    double *pin = nullptr;          // page-locked [2 m + 4]
+    double *pin_dev = nullptr;      // its device address
+    long long pin_cap = 0;
+    double pairs_per_atom = 0.0, rows_per_atom = 0.0;
+    std::vector<unsigned char> mask;
+};
+
+extern "C" int gpr_dot2_session_create(gpr_dot2_session **out, void *stream, int nmax, int lmax, double rcut, double alpha,
+                                       int nseg, int ncheb, const double *so3_table, int weight_on, int ns,
+                                       const int *species_host, double sigma, double sigma0, const double *w_dev,
+                                       const double *M_dev, const double *Cinv_dev, int want_std) {
+    GPR_REQUIRE(out && so3_table && species_host && ns > 0 && w_dev && (!want_std || M_dev || Cinv_dev),
+                "gpr_dot2_session_create: null pointer");
+    gpr_dot2_session *s = new gpr_dot2_session();
+    s->st = (hipStream_t)stream; s->nmax = nmax; s->lmax = lmax; s->rcut = rcut; s->alpha = alpha; s->nseg = nseg; s->ncheb = ncheb;
+    s->table = so3_table; s->weight_on = weight_on; s->ns = ns; s->species.assign(species_host, species_host + ns);
+    s->sigma = sigma; s->sigma0 = sigma0; s->w = w_dev; s->M = M_dev; s->Cinv = Cinv_dev; s->want_std = want_std;
+    *out = s;
+    return GPR_OK;
+}
+
+// pairs / seq rows per atom the next call sizes its neighbour tables from (normally learnt from the calls themselves)
+extern "C" int gpr_dot2_session_set_hint(gpr_dot2_session *s, double pairs_per_atom, double rows_per_atom) {
+    GPR_REQUIRE(s, "gpr_dot2_session_set_hint: null session");
+    s->pairs_per_atom = pairs_per_atom; s->rows_per_atom = rows_per_atom;
+    return GPR_OK;
+}
+
+extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
+    if (!s) return GPR_OK;
+    if (s->pin) (void)hipHostFree(s->pin);
+    delete s;
+    return GPR_OK;
+}
+
+// fixed[natoms] (may be NULL): non-zero marks atoms held by FixAtoms -- F = F_std = 0 there, no force rows.
+// E[nstruct] total energies, F[natoms, 3], E_std[nstruct] (per atom, as upstream), F_std[natoms, 3]; the two std
+// outputs may be NULL when the session was created without want_std.  info[4] (may be NULL): status words of the call.
+extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
+                                        const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
+                                        double *E, double *F, double *E_std, double *F_std, double *info) {
+    GPR_REQUIRE(s && nstruct >= 0 && atom0 && E && F && (!s->want_std || (E_std && F_std)), "gpr_dot2_session_predict: null pointer");
+    if (nstruct == 0) return GPR_OK;
+    const int natoms = atom0[nstruct];
+    const unsigned char *free_mask = nullptr;
+    int nfree = natoms;
+    if (fixed) {
+        bool any = false;
+        for (int a = 0; a < natoms && !any; a++) any = fixed[a] != 0;
+        if (any) {
+            s->mask.resize((size_t)natoms);
+            nfree = 0;
+            for (int a = 0; a < natoms; a++) { s->mask[a] = fixed[a] ? 0 : 1; nfree += s->mask[a]; }
+            free_mask = s->mask.data();
+        }
+    }
+    const long long m = (long long)nstruct + 3LL * nfree, nout = (s->want_std ? 2 : 1) * m;
+    if (s->pin_cap < nout + 4) {
+        if (s->pin) (void)hipHostFree(s->pin);
+        s->pin = nullptr; s->pin_cap = 0;
+        const long long want = std::max<long long>(2 * (nout + 4), 4096);
+        GPR_HIP_TRY(hipHostMalloc((void **)&s->pin, (size_t)want * sizeof(double), hipHostMallocDefault));
+        GPR_HIP_TRY(hipHostGetDevicePointer((void **)&s->pin_dev, s->pin, 0));
+        s->pin_cap = want;
+    }
+    volatile double *tail = s->pin + nout;
+    int cap_pairs = 0, cap_rows = 0;
+    if (s->pairs_per_atom > 0.0) {
+        cap_pairs = (int)(s->pairs_per_atom * natoms * 1.125) + 64;
+        cap_rows = (int)(s->rows_per_atom * natoms * 1.125) + 64;
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int k = 0; k < 4; k++) tail[k] = __builtin_nan("");
+        int rc = gpr_predict_dot2_batch(s->st, s->nmax, s->lmax, s->rcut, s->alpha, s->nseg, s->ncheb, s->table, nstruct, atom0,
+                                        positions, cells, pbc, numbers, s->weight_on, free_mask, s->ns, s->species.data(), s->sigma,
+                                        s->sigma0, s->w, s->M, s->Cinv, s->want_std, cap_pairs, cap_rows, s->pin_dev, nout + 4);
+        if (rc) return rc;
+        // the status words are the last thing the last kernel writes (system-scope fence before them): spin on them in
+        // host memory; fall back to a blocking synchronisation if they do not show up within seconds
+        bool seen = false;
+        for (long long spin = 0; spin < (1LL << 33); spin++) {
+            if (tail[0] == tail[0] && tail[1] == tail[1] && tail[2] == tail[2] && tail[3] == tail[3]) { seen = true; break; }
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s->st) == hipSuccess) break;
+        }
+        if (!seen) GPR_HIP_TRY(hipStreamSynchronize(s->st));
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        if (tail[1] == 0.0) break;                       // no overflow
+        GPR_REQUIRE(attempt == 0, "gpr_dot2_session_predict: neighbour table overflow with exact sizes");
+        cap_pairs = cap_rows = 0;
+    }
+    if (info) for (int k = 0; k < 4; k++) info[k] = tail[k];
+    if (natoms > 0) {
+        s->pairs_per_atom = std::max(s->pairs_per_atom, tail[2] / natoms);
+        s->rows_per_atom = std::max(s->rows_per_atom, tail[3] / natoms);
+    }
+    GPR_REQUIRE(tail[0] == 0.0, "neighbour table is not symmetric: %d force rows missing", (int)tail[0]);
+    // unpack [mean | var]: energies per atom -> total energies, force rows -> [natoms, 3] with zeros at fixed atoms
+    const double *mean = s->pin, *var = s->pin + m;
+    for (int k = 0; k < nstruct; k++) {
+        E[k] = mean[k] * (atom0[k + 1] - atom0[k]);
+        if (s->want_std) E_std[k] = sqrt(var[k]);
+    }
+    const double *mf = mean + nstruct, *vf = var + nstruct;
+    if (!free_mask) {
+        memcpy(F, mf, (size_t)3 * natoms * sizeof(double));
+        if (s->want_std) for (long long i = 0; i < 3LL * natoms; i++) F_std[i] = sqrt(vf[i]);
+    } else {
+        long long r = 0;
+        for (int a = 0; a < natoms; a++) {
+            if (free_mask[a]) {
+                for (int c = 0; c < 3; c++) { F[3 * a + c] = mf[r + c]; if (s->want_std) F_std[3 * a + c] = sqrt(vf[r + c]); }
+                r += 3;
+            } else {
+                for (int c = 0; c < 3; c++) { F[3 * a + c] = 0.0; if (s->want_std) F_std[3 * a + c] = 0.0; }
+            }
+        }
+    }
+    return GPR_OK;
 }

@@ -871,6 +871,9 @@ class GP():
         otherwise.  Same kernels as the generic route, queued from one host call."""
         if not self.native_batch or not hasattr(self.descriptor, "_device_tables"):
             return None
+        tr = self._trace
+        if tr is not None:
+            tr.append(("native:enter", time.perf_counter_ns()))
         ws = self._weight_space()
         if ws is None or not self.weight_space_mean or getattr(self.descriptor, "_stress", False):
             return None
@@ -936,6 +939,8 @@ class GP():
         # and the batch is repeated with exact sizes
         hint = self._nbr_hint
         caps = (0, 0) if hint is None else (int(hint[0] * natoms * 1.125) + 64, int(hint[1] * natoms * 1.125) + 64)
+        if tr is not None:
+            tr.append(("native:marshalled", time.perf_counter_ns()))
         for attempt in range(2):
             tailw[:] = np.nan
             dev.check(_lib.lib().gpr_predict_dot2_batch(
@@ -947,6 +952,8 @@ class GP():
             # the status words are written by the last kernel of the call: poll them in host memory (a blocking stream
             # synchronisation sleeps and wakes tens of microseconds late); everything queued before that kernel has
             # completed, in stream order, when they appear
+            if tr is not None:
+                tr.append(("native:queued", time.perf_counter_ns()))
             polled = self._poll_results
             if polled:
                 deadline = None
@@ -962,6 +969,8 @@ class GP():
                         break
             if not polled:
                 torch.cuda.current_stream().synchronize()
+            if tr is not None:
+                tr.append(("native:results", time.perf_counter_ns()))
             host = view.copy()                        # the pinned buffer is reused by the next call
             if host[nout + 1] == 0.0:
                 break
@@ -975,8 +984,70 @@ class GP():
                              and bool((np.diff(atom0) == atom0[1] - atom0[0]).all()) else -1)
         # for the caller's scatter of the force rows: atom offsets and the global indices of the moving atoms
         self._last_layout = (atom0, None if mask is None else np.flatnonzero(mask))
-        return host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
+        res = host[:m], (np.sqrt(host[m:2 * m]) if return_std else None), frees
+        if tr is not None:
+            tr.append(("native:exit", time.perf_counter_ns()))
+        return res
 
+    def _predict_batch_session(self, strucs, return_std):
+        """(E, F, E_std, F_std) lists of a batch through the host-in / host-out session call gpr_dot2_session_predict
+        (csrc/predict.hip): gather the structures' arrays in one C pass, one native call that queues the device chain,
+        waits for the results in page-locked memory and unpacks them into per-atom arrays.  None when the model or the
+        structures do not fit that route (the other routes take over)."""
+        if (not self.native_batch or _pygather is None or self.base_potential is not None
+                or not hasattr(self.descriptor, "_device_tables")):
+            return None
+        ws = self._weight_space()
+        des = self.descriptor
+        if ws is None or not self.weight_space_mean or getattr(des, "_stress", False) or not des.derivative:
+            return None
+        got = _pygather.gather(strucs)
+        if got is None:
+            return None
+        from . import _lib
+        import ctypes as C
+        key = (id(ws), bool(return_std), float(self.kernel.sigma), float(self.kernel.sigma0))
+        ses = self._session
+        if ses is None or ses[0] != key:
+            if ses is not None:
+                _lib.lib().gpr_dot2_session_destroy(ses[1])
+            table, nseg, ncheb = des._device_tables()[:3]
+            species, w = ws[0], ws[2]
+            Cinv = ws[3] if len(ws) > 3 else None
+            M = None if (Cinv is not None or not return_std) else self._ws_M(ws)
+            sp = np.ascontiguousarray(np.asarray(species, dtype=np.int32))
+            h = C.c_void_p()
+            dev.check(_lib.lib().gpr_dot2_session_create(
+                C.byref(h), dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
+                int(bool(des.weight_on)), len(sp), sp.ctypes.data_as(_lib.c_int_p), float(self.kernel.sigma),
+                float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std))), "gpr_dot2_session_create")
+            ses = self._session = (key, h, (table, w, M, Cinv))          # the tuple keeps the device arrays alive
+        a0 = np.frombuffer(got[0], dtype=np.int32)
+        nS, natoms = len(strucs), int(a0[-1])
+        fixed = None
+        if got[5]:                                                       # some structure carries fixed atoms
+            free = np.frombuffer(got[6], dtype=np.uint8)
+            if not free.all():
+                fixed = np.ascontiguousarray(free == 0).view(np.uint8)
+        E, F = np.empty(nS), np.empty((natoms, 3))
+        Es, Fs = (np.empty(nS), np.empty((natoms, 3))) if return_std else (None, None)
+        vp = lambda a: None if a is None else a.ctypes.data
+        dev.check(_lib.lib().gpr_dot2_session_predict(
+            ses[1], nS, a0.ctypes.data, np.frombuffer(got[2], dtype=np.float64).ctypes.data,
+            np.frombuffer(got[3], dtype=np.float64).ctypes.data, np.frombuffer(got[4], dtype=np.int32).ctypes.data,
+            np.frombuffer(got[1], dtype=np.int32).ctypes.data, vp(fixed), E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None),
+            "gpr_dot2_session_predict")
+        n0 = int(a0[1]) if nS else 0
+        if natoms == nS * n0:                                            # same size everywhere (an NEB band): one reshape
+            Fl = list(F.reshape(nS, n0, 3))
+            Fsl = list(Fs.reshape(nS, n0, 3)) if return_std else [None] * nS
+        else:
+            Fl = [F[a0[k]:a0[k + 1]] for k in range(nS)]
+            Fsl = [Fs[a0[k]:a0[k + 1]] for k in range(nS)] if return_std else [None] * nS
+        return list(E), Fl, (list(Es) if return_std else [None] * nS), Fsl
+
+    _session = None
+    _trace = None               # a list: host timestamps (label, ns) of the native batch call are appended (tools/native_split.py)
     _nbr_hint = None
     _pinned_out = None
     _last_counts = None
@@ -985,6 +1056,7 @@ class GP():
     _poll_warned = False
 
     native_batch = True
+    session_batch = True        # one rank: the host-in / host-out session call (False: the Python-side unpacking route)
     device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
@@ -994,6 +1066,10 @@ class GP():
         Returns lists (E, F, E_std, F_std) ordered like `strucs` (identical on every rank)."""
         nb = len(strucs)
         size, rank = self.comm.size, self.comm.rank
+        if size == 1 and nb and self.session_batch:
+            fast = self._predict_batch_session(strucs, return_std)
+            if fast is not None:
+                return fast
         mine = list(range(rank, nb, size)) if size > 1 else list(range(nb))
         results = {}
         if mine:

@@ -179,6 +179,23 @@ int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double
                            double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev, int want_std,
                            int cap_pairs, int cap_rows, double *out_dev, long long out_len);
 
+/* The same prediction with host arrays on both sides (one call per batch, what an ASE NEB loop needs per force call):
+ * a session keeps the device-resident model (pointers as in gpr_predict_dot2_batch; they must stay valid), owns the
+ * page-locked buffer the device writes the results into, waits for them by polling their status words, sizes the
+ * neighbour tables from the densest batch seen so far and repeats a call whose guess was too small.
+ *   gpr_dot2_session_predict: fixed[natoms] (may be NULL) marks FixAtoms atoms; E[nstruct] total energies, F[natoms, 3]
+ *   (zero rows for fixed atoms), E_std[nstruct] per atom, F_std[natoms, 3]: the values GP.predict_structure returns
+ *   (gaussianprocess.py:880-911) for every structure; info[4] (may be NULL) = the status words of the call. */
+typedef struct gpr_dot2_session gpr_dot2_session;
+int gpr_dot2_session_create(gpr_dot2_session **out, void *stream, int nmax, int lmax, double rcut, double alpha, int nseg,
+                            int ncheb, const double *so3_table, int weight_on, int ns, const int *species_host, double sigma,
+                            double sigma0, const double *w_dev, const double *M_dev, const double *Cinv_dev, int want_std);
+int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions, const double *cells,
+                             const int *pbc, const int *numbers, const unsigned char *fixed, double *E, double *F,
+                             double *E_std, double *F_std, double *info);
+int gpr_dot2_session_set_hint(gpr_dot2_session *s, double pairs_per_atom, double rows_per_atom);   /* tests / tuning */
+int gpr_dot2_session_destroy(gpr_dot2_session *s);
+
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
  * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 10 entries

