@@ -80,6 +80,19 @@ class SO3:
         return {"nmax": self.nmax, "lmax": self.lmax, "rcut": self.rcut, "alpha": self.alpha,
                 "derivative": self.derivative, "stress": self.stress, "_type": "SO3"}
 
+    @staticmethod
+    def _check_device_limits(nmax, lmax):
+        """The device descriptor kernel (csrc/so3.hip) holds nmax (lmax + 1) <= 16 radial-angular channels and
+        ncoef <= 32 power-spectrum components (the MFMA operand planes of the covariance kernels are 32 columns wide):
+        say so when the object is configured, not deep inside a launch (the reference allows nmax <= 11, SO3.py:76-77)."""
+        if nmax is None or lmax is None:
+            return
+        ncoef = nmax * (nmax + 1) // 2 * (lmax + 1)
+        if nmax > 4 or lmax > 6 or nmax * (lmax + 1) > 16 or ncoef > 32:
+            raise NotImplementedError(
+                f"SO3(nmax={nmax}, lmax={lmax}) gives ncoef = {ncoef}; this build's device kernels cover nmax <= 4, "
+                f"lmax <= 6, nmax (lmax + 1) <= 16 and ncoef <= 32 (e.g. the reference's default nmax=3, lmax=4)")
+
     # -- validated attributes (gpr_calc/SO3.py:67-182)
     @property
     def nmax(self):
@@ -93,6 +106,7 @@ class SO3:
             raise ValueError('nmax must be greater than or equal to 1')
         if nmax > 11:
             raise ValueError('nmax > 11 yields complex eigenvalues which will mess up the calculation')
+        self._check_device_limits(nmax, getattr(self, "_lmax", None))
         self._nmax = nmax
         self._tables = None
 
@@ -108,6 +122,7 @@ class SO3:
             raise ValueError('lmax must be greater than or equal to zero')
         if lmax > 32:
             raise NotImplementedError('lmax up to 32 only')
+        self._check_device_limits(getattr(self, "_nmax", None), lmax)
         self._lmax = lmax
         self._tables = None
 
@@ -271,8 +286,6 @@ class SO3:
         x [sum n, d], dxdr [sum S, d, 3] plus `nbr` (the NeighborBatch the rows refer to) and the host
         offsets atom0 / row0 / numbers_all.  With host_index=True the neighbour search runs on the host
         (gpr_nbr_build) and the per-structure `seq` lists are returned as numpy arrays as well."""
-        if not self.derivative:
-            raise NotImplementedError("derivative=False is not used on the GPR hot path")
         table, nseg, ncheb = self._device_tables()[:3]
         D = dev.device()
         d = self.ncoefs
@@ -324,14 +337,25 @@ class SO3:
         gpr_calc.SO3.SO3.calculate (SO3.py:186-323), as numpy arrays.  `use_mpi` is accepted for
         signature compatibility; the work is already one GPU launch.
         '''
-        if atom_ids is not None:
-            raise NotImplementedError("atom_ids subsets are not used on the GPR hot path")
         out = self.calculate_batch_dev([atoms], host_index=True)
         numbers = out["numbers"][0]
-        symbols = list(atoms.symbols) if hasattr(atoms, "symbols") else [symbol_of(z) for z in numbers]
-        return {'x': out["x"].cpu().numpy(), 'dxdr': out["dxdr"].cpu().numpy(),
-                'rdxdr': None if out["rdxdr"] is None else out["rdxdr"].cpu().numpy(),
-                'elements': [str(s) for s in symbols], 'seq': out["seq"][0]}
+        symbols = [str(s) for s in (atoms.symbols if hasattr(atoms, "symbols") else [symbol_of(z) for z in numbers])]
+        x = out["x"].cpu().numpy()
+        if atom_ids is not None:
+            # only the listed centres (SO3.py:353-399): x keeps its [n, ncoef] shape with the other rows zero; seq / dxdr
+            # hold the rows of the listed centres, centre by centre in the order given
+            ids = [int(i) for i in atom_ids]
+            full, x = x, np.zeros_like(x)
+            x[ids] = full[ids]
+        if not self.derivative:                       # SO3.py:309-320: no seq, no derivative rows
+            return {'x': x, 'dxdr': None, 'rdxdr': None, 'elements': symbols}
+        seq, dxdr = out["seq"][0], out["dxdr"].cpu().numpy()
+        rdxdr = None if out["rdxdr"] is None else out["rdxdr"].cpu().numpy()
+        if atom_ids is not None:
+            rows = np.concatenate([np.flatnonzero(seq[:, 0] == i) for i in ids] or [np.zeros(0, dtype=np.int64)])
+            seq, dxdr = seq[rows], dxdr[rows]
+            rdxdr = None if rdxdr is None else rdxdr[rows]
+        return {'x': x, 'dxdr': dxdr, 'rdxdr': rdxdr, 'elements': symbols, 'seq': seq}
 
 
 class NeighborBatch:

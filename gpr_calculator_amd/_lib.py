@@ -33,6 +33,7 @@ _L1_SIGNATURES = {
     "gpr_last_error": ([], C.c_char_p),
     "gpr_build_info": ([], C.c_char_p),
     "gpr_device_count": ([], _i),
+    "gpr_l0_last_status": ([], _i),
     "gpr_memcpy_dtod": ([_vp, _vp, _vp, _ll], _i),
     "gpr_set_create": ([C.POINTER(_vp), _vp, _i, _i, _i, _i, _i, _i, c_int_p, _vp, _vp, _vp, _i], _i),
     "gpr_set_destroy": ([_vp, _vp], _i),

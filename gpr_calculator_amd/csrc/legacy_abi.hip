@@ -1,17 +1,24 @@
 // legacy_abi.hip -- L0: the 13 natives of the reference (gpr_calc/kernels/rbf_kernel.h:4-38,
 // dot_kernel.h:4-27) with their exact signatures and semantics, executed on the GPU.
 // Host pointers in/out; results are ACCUMULATED into the caller's (zeroed) buffers exactly as
-// the reference does.  No CPU fallback: any failure prints the reason and aborts.
+// the reference does.  No CPU fallback: a call that cannot be executed on the device (an unsupported shape such as a
+// descriptor longer than this build packs, a HIP error) prints the reason to stderr and RETURNS with the caller's
+// output buffers untouched -- the natives are `void` (rbf_kernel.h:4-38), so the status is also kept for
+// gpr_l0_last_status(); a library entry never takes the host process down.
 #include <algorithm>
 #include <numeric>
 #include "gpr_internal.h"
 
 namespace {
 
+struct l0_failure { int rc; };
+thread_local int g_l0_status = GPR_OK;
+
 [[noreturn]] void die(const char *who, int rc) {
-    fprintf(stderr, "libgprhip: %s failed (status %d): %s\n", who, rc, gpr_last_error());
+    fprintf(stderr, "libgprhip: %s failed (status %d): %s; the output buffers are left untouched\n", who, rc, gpr_last_error());
     fflush(stderr);
-    abort();
+    g_l0_status = rc;
+    throw l0_failure{rc};
 }
 
 #define L0_TRY(expr) do { int _rc = (expr); if (_rc) die(who, _rc); } while (0)
@@ -25,6 +32,12 @@ struct Side {
     std::vector<int> counts;     // rows per point id (length = number of point ids)
     std::vector<gpr_set *> sets; // one per derivative triplet
     int nrows = 0;
+    ~Side() {                    // also on the unwinding path of a failed call
+        for (gpr_set *p : sets) gpr_set_destroy(p, nullptr);
+        if (x) (void)hipFree(x);
+        if (dx) (void)hipFree(dx);
+        if (ele) (void)hipFree(ele);
+    }
 };
 
 // inds need not be sorted in principle (the reference only ever passes sorted ones,
@@ -83,16 +96,12 @@ void build_side(const char *who, Side &s, int role, int d, int width, int r0, in
     }
 }
 
-void free_side(Side &s) {
-    for (gpr_set *p : s.sets) gpr_set_destroy(p, nullptr);
-    if (s.x) (void)hipFree(s.x);
-    if (s.dx) (void)hipFree(s.dx);
-    if (s.ele) (void)hipFree(s.ele);
-}
+void free_side(Side &) {}       // the destructor releases everything
 
 struct DevOut {
     double *d = nullptr;
     size_t n = 0;
+    ~DevOut() { if (d) (void)hipFree(d); }
     void alloc(const char *who, size_t count) {
         n = count;
         if (n == 0) return;
@@ -106,6 +115,7 @@ struct DevOut {
         L0_HIP(hipMemcpy(tmp.data(), d, n * 8, hipMemcpyDeviceToHost));
         for (size_t k = 0; k < n; k++) host[k] += tmp[k];
         (void)hipFree(d);
+        d = nullptr;
     }
 };
 
@@ -125,50 +135,56 @@ gpr_block_call base_call(int mode, int kind, double zeta, double sigma2, double 
 void ee_native(const char *who, int kind, bool grad, int n1, int n2, int d, int x2i, double zeta,
                double sigma2, double l2_or_s02, double *x1, int *ele1, int *i1, double *x2, int *ele2,
                int *i2, double *pout, double *dpout) {
-    if (n1 <= 0 || n2 <= 0) return;
-    Side a, b;
-    build_side(who, a, GPR_ROLE_STREAM, d, 0, 0, n1, 0, x1, nullptr, ele1, i1);
-    build_side(who, b, GPR_ROLE_RESIDENT, d, 0, 0, n2, x2i, x2, nullptr, ele2, i2);
-    if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
-    const size_t m1 = a.counts.size();
-    DevOut o, o2;
-    o.alloc(who, m1 * x2i);
-    if (grad) o2.alloc(who, m1 * x2i);
-    gpr_block_call c = base_call(GPR_MODE_EE, kind, zeta, sigma2,
-                                 kind == GPR_KERNEL_RBF ? l2_or_s02 : 1.0, false,
-                                 kind == GPR_KERNEL_DOT ? l2_or_s02 : 0.0, 0.0);
-    c.s1 = a.sets[0]; c.s2 = b.sets[0];
-    c.scale = (kind == GPR_KERNEL_DOT) ? sigma2 : 1.0;
-    c.out = o.d; c.s_i = x2i; c.s_j = 1;
-    if (grad) { c.grad = 1; c.dl = o2.d; c.d_i = x2i; c.d_j = 1; }
-    L0_TRY(gpr_launch_block(nullptr, c));
-    o.add_into(who, pout);
-    if (grad) o2.add_into(who, dpout);
-    free_side(a); free_side(b);
+    g_l0_status = GPR_OK;
+    try {
+        if (n1 <= 0 || n2 <= 0) return;
+        Side a, b;
+        build_side(who, a, GPR_ROLE_STREAM, d, 0, 0, n1, 0, x1, nullptr, ele1, i1);
+        build_side(who, b, GPR_ROLE_RESIDENT, d, 0, 0, n2, x2i, x2, nullptr, ele2, i2);
+        if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
+        const size_t m1 = a.counts.size();
+        DevOut o, o2;
+        o.alloc(who, m1 * x2i);
+        if (grad) o2.alloc(who, m1 * x2i);
+        gpr_block_call c = base_call(GPR_MODE_EE, kind, zeta, sigma2,
+                                     kind == GPR_KERNEL_RBF ? l2_or_s02 : 1.0, false,
+                                     kind == GPR_KERNEL_DOT ? l2_or_s02 : 0.0, 0.0);
+        c.s1 = a.sets[0]; c.s2 = b.sets[0];
+        c.scale = (kind == GPR_KERNEL_DOT) ? sigma2 : 1.0;
+        c.out = o.d; c.s_i = x2i; c.s_j = 1;
+        if (grad) { c.grad = 1; c.dl = o2.d; c.d_i = x2i; c.d_j = 1; }
+        L0_TRY(gpr_launch_block(nullptr, c));
+        o.add_into(who, pout);
+        if (grad) o2.add_into(who, dpout);
+        free_side(a); free_side(b);
+    } catch (const l0_failure &) {}      // reported by die(); outputs untouched
 }
 
 // ---- energy-force (w = 3 or 9 derivative columns on set 2)
 void ef_native(const char *who, int kind, bool grad, int w, int n1, int n2, int d, int x2i, double zeta,
                double sigma2, double lpar, double *x1, int *ele1, int *i1, double *x2, double *dx2dr,
                int *ele2, int *i2, double *pout) {
-    if (n1 <= 0 || n2 <= 0) return;
-    Side a, b;
-    build_side(who, a, GPR_ROLE_STREAM, d, 0, 0, n1, 0, x1, nullptr, ele1, i1);
-    build_side(who, b, GPR_ROLE_RESIDENT, d, w, 0, n2, x2i, x2, dx2dr, ele2, i2);
-    if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
-    const size_t m1 = a.counts.size();
-    const int ow = grad ? 6 : w;
-    DevOut o;
-    o.alloc(who, m1 * x2i * ow);
-    for (size_t t = 0; t < b.sets.size(); t++) {
-        gpr_block_call c = base_call(GPR_MODE_EF, kind, zeta, sigma2, lpar, grad, 0.0, 0.0);
-        c.s1 = a.sets[0]; c.s2 = b.sets[t];
-        c.out = o.d + 3 * t; c.s_i = (long long)x2i * ow; c.s_j = ow; c.s_b = 1;
-        if (grad) { c.grad = 1; c.dl = o.d + 3; c.d_i = c.s_i; c.d_j = ow; c.d_b = 1; }
-        L0_TRY(gpr_launch_block(nullptr, c));
-    }
-    o.add_into(who, pout);
-    free_side(a); free_side(b);
+    g_l0_status = GPR_OK;
+    try {
+        if (n1 <= 0 || n2 <= 0) return;
+        Side a, b;
+        build_side(who, a, GPR_ROLE_STREAM, d, 0, 0, n1, 0, x1, nullptr, ele1, i1);
+        build_side(who, b, GPR_ROLE_RESIDENT, d, w, 0, n2, x2i, x2, dx2dr, ele2, i2);
+        if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
+        const size_t m1 = a.counts.size();
+        const int ow = grad ? 6 : w;
+        DevOut o;
+        o.alloc(who, m1 * x2i * ow);
+        for (size_t t = 0; t < b.sets.size(); t++) {
+            gpr_block_call c = base_call(GPR_MODE_EF, kind, zeta, sigma2, lpar, grad, 0.0, 0.0);
+            c.s1 = a.sets[0]; c.s2 = b.sets[t];
+            c.out = o.d + 3 * t; c.s_i = (long long)x2i * ow; c.s_j = ow; c.s_b = 1;
+            if (grad) { c.grad = 1; c.dl = o.d + 3; c.d_i = c.s_i; c.d_j = ow; c.d_b = 1; }
+            L0_TRY(gpr_launch_block(nullptr, c));
+        }
+        o.add_into(who, pout);
+        free_side(a); free_side(b);
+    } catch (const l0_failure &) {}      // reported by die(); outputs untouched
 }
 
 // ---- force-force (w1 = 3 or 9 derivative columns on set 1)
@@ -176,28 +192,31 @@ void ff_native(const char *who, int kind, bool grad, int w1, int n1, int n2, int
                int x2i, double zeta, double sigma2, double lpar, double tol, double *x1, double *dx1dr,
                int *ele1, int *i1, double *x2, double *dx2dr, int *ele2, int *i2, double *pout,
                double *dpout) {
-    n2s = std::max(n2s, 0); n2e = std::min(n2e, n2);
-    if (n1 <= 0 || n2e <= n2s) return;
-    Side a, b;
-    build_side(who, a, GPR_ROLE_STREAM, d, w1, 0, n1, 0, x1, dx1dr, ele1, i1);
-    build_side(who, b, GPR_ROLE_RESIDENT, d, 3, n2s, n2e, x2i, x2, dx2dr, ele2, i2);
-    if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
-    const size_t m1 = a.counts.size();
-    DevOut o, o2;
-    o.alloc(who, m1 * w1 * x2i * 3);
-    if (grad) o2.alloc(who, m1 * w1 * x2i * 3);
-    for (size_t t = 0; t < a.sets.size(); t++) {
-        gpr_block_call c = base_call(GPR_MODE_FF, kind, zeta, sigma2, lpar, grad, 0.0, grad ? -1.0 : tol);
-        c.s1 = a.sets[t]; c.s2 = b.sets[0];
-        // pout[((q + i*w1)*x2i + j)*3 + b], q = 3t + a
-        c.out = o.d + (size_t)3 * t * x2i * 3;
-        c.s_i = (long long)w1 * x2i * 3; c.s_a = (long long)x2i * 3; c.s_j = 3; c.s_b = 1;
-        if (grad) { c.grad = 1; c.dl = o2.d; c.d_i = c.s_i; c.d_a = c.s_a; c.d_j = 3; c.d_b = 1; }
-        L0_TRY(gpr_launch_block(nullptr, c));
-    }
-    o.add_into(who, pout);
-    if (grad) o2.add_into(who, dpout);
-    free_side(a); free_side(b);
+    g_l0_status = GPR_OK;
+    try {
+        n2s = std::max(n2s, 0); n2e = std::min(n2e, n2);
+        if (n1 <= 0 || n2e <= n2s) return;
+        Side a, b;
+        build_side(who, a, GPR_ROLE_STREAM, d, w1, 0, n1, 0, x1, dx1dr, ele1, i1);
+        build_side(who, b, GPR_ROLE_RESIDENT, d, 3, n2s, n2e, x2i, x2, dx2dr, ele2, i2);
+        if ((int)b.counts.size() != x2i) { gpr_set_error("x2_inds exceed x2i"); die(who, GPR_ERR_ARG); }
+        const size_t m1 = a.counts.size();
+        DevOut o, o2;
+        o.alloc(who, m1 * w1 * x2i * 3);
+        if (grad) o2.alloc(who, m1 * w1 * x2i * 3);
+        for (size_t t = 0; t < a.sets.size(); t++) {
+            gpr_block_call c = base_call(GPR_MODE_FF, kind, zeta, sigma2, lpar, grad, 0.0, grad ? -1.0 : tol);
+            c.s1 = a.sets[t]; c.s2 = b.sets[0];
+            // pout[((q + i*w1)*x2i + j)*3 + b], q = 3t + a
+            c.out = o.d + (size_t)3 * t * x2i * 3;
+            c.s_i = (long long)w1 * x2i * 3; c.s_a = (long long)x2i * 3; c.s_j = 3; c.s_b = 1;
+            if (grad) { c.grad = 1; c.dl = o2.d; c.d_i = c.s_i; c.d_a = c.s_a; c.d_j = 3; c.d_b = 1; }
+            L0_TRY(gpr_launch_block(nullptr, c));
+        }
+        o.add_into(who, pout);
+        if (grad) o2.add_into(who, dpout);
+        free_side(a); free_side(b);
+    } catch (const l0_failure &) {}      // reported by die(); outputs untouched
 }
 
 }  // namespace
@@ -281,5 +300,8 @@ void dot_kff_many_stress(int n1, int n2, int n2_start, int n2_end, int d, int x2
     ff_native("dot_kff_many_stress", GPR_KERNEL_DOT, false, 9, n1, n2, n2_start, n2_end, d, x2i, zeta, 1.0,
               1.0, 0.0, x1, dx1dr, ele1, x1_inds, x2, dx2dr, ele2, x2_inds, pout, nullptr);
 }
+
+// status of the last L0 native on this thread (GPR_OK, or why it returned without touching its outputs)
+int gpr_l0_last_status(void) { return g_l0_status; }
 
 }  // extern "C"

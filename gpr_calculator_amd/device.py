@@ -273,6 +273,15 @@ def potrf_lower_(a, want_dinv=False):
     return (info, dinv) if want_dinv else info
 
 
+def tri_inv64(l):
+    """inverses of the 64 x 64 diagonal blocks of a lower-triangular factor (the `dinv` of potrf_lower_), for a factor
+    that was put together block-wise; also zeroes the strict upper triangle of l"""
+    n = l.shape[0]
+    dinv = torch.empty(((n + 63) // 64) * 4096, dtype=F64, device=l.device)
+    check(_lib.lib().gpr_potrf_finish(stream_ptr(), n, ptr(l), int(l.stride(0)) if n > 1 else n, ptr(dinv)), "gpr_potrf_finish")
+    return dinv
+
+
 def trsm_lower_(l, b, trans=False, dinv=None):
     """b <- L^-1 b (trans False) or L^-T b (trans True); b is [n, nrhs] row-major, in place"""
     n, nrhs = b.shape

@@ -89,6 +89,8 @@ class GP():
 
         # device-resident model state
         self._dense = {"L": None, "alpha": None, "dinv": None}   # Cholesky factor of K + noise [N, N], (K + noise)^-1 y
+        self._perm_dev = None       # after an appended fit: row order of the factor (position -> reference row), else None
+        self._dense_params = None   # (hyper-parameters, noise) the dense factor was built with
         self._dense_pending = False  # a weight-space fit leaves the N x N factorisation until somebody asks for it
         self._fitted = False
         self._K_inv_dev = None
@@ -149,6 +151,8 @@ class GP():
         if not self._fitted:
             return None
         if "L" not in self._host:
+            if self._perm_dev is not None:        # the appended factor is the Cholesky factor of a row permutation of
+                self._factor_dense(lazy=True)     # K + noise: the reference's L_ is refactored when somebody asks for it
             self._host["L"] = self._L_dev.cpu().numpy()
         return self._host["L"]
 
@@ -183,7 +187,12 @@ class GP():
         """K^-1 = L^-T L^-1 (gaussianprocess.py:128-131), formed on the device only when asked for."""
         if self._K_inv_dev is None and self._L_dev is not None:
             Linv = self._Linv()
-            self._K_inv_dev = dev.gemm(Linv, Linv, transa=True)
+            Kinv = dev.gemm(Linv, Linv, transa=True)
+            if self._perm_dev is not None:        # back to the reference's row order
+                full = torch.empty_like(Kinv)
+                full[self._perm_dev[:, None], self._perm_dev[None, :]] = Kinv
+                Kinv = full
+            self._K_inv_dev = Kinv
 
     # ------------------------------------------------------------------ covariance of the training set
     def _n_energy_points(self, train_x):
@@ -359,7 +368,15 @@ class GP():
             else:
                 self.kernel.update(params)
 
+        if not opt and self._try_append_dense():
+            self._fit_train_x, self._fit_y = dict(self.train_x), self.y_train
+            self.logging.info("Cholesky factor extended by the queued points")
+            self.comm.barrier()
+            self.N_energy_queue = self.N_forces_queue = self.N_queue = 0
+            self.fits += 1
+            return
         self._dense = {"L": None, "alpha": None, "dinv": None}
+        self._perm_dev = None
         self._dense_pending = False
         self._K_inv_dev = None
         self._Linv_dev = None
@@ -403,6 +420,92 @@ class GP():
         dev.trsm_lower_(K, alpha, dinv=dinv)
         dev.trsm_lower_(K, alpha, trans=True, dinv=dinv)
         self._dense = {"L": K, "alpha": alpha, "dinv": dinv}
+        self._perm_dev = None
+        self._dense_params = (tuple(float(v) for v in self.kernel.parameters()), float(self.noise_e), float(self.noise_f))
+        if lazy:
+            self._Linv_dev = self._K_inv_dev = None
+            self._host.pop("L", None)
+
+    # fit(opt=False) after add_structure with unchanged hyper-parameters (gaussianprocess.py:381-425 appends the points,
+    # :286-317 then rebuilds all of K and refactors it): K + noise only grows by the rows / columns of the queued points.
+    # With the new rows ordered LAST,  K' = [[K, B], [B^T, C]]  has the factor  L' = [[L, 0], [X, L_s]],
+    #   X^T = L^-1 B,   L_s L_s^T = C - X X^T,   L'^-1 = [[L^-1, 0], [-L_s^-1 X L^-1, L_s^-1]]:
+    # k new columns cost N^2 k instead of N^3 / 3 + the N^2 covariance entries.  The reference orders rows as
+    # [energies | forces], so new energy rows sit in the middle there: the factor is kept in "old rows, then new rows" order
+    # with the permutation next to it (_perm_dev); alpha_ and _K_inv are handed out in the reference's order, L_ -- whose
+    # definition depends on the order -- is refactored if somebody asks for it.
+    incremental_fit = True
+
+    def _try_append_dense(self):
+        d = self._dense
+        if (not self.incremental_fit or not self._fitted or self._dense_pending or d["L"] is None or self.N_queue <= 0
+                or self.comm.size > 1 or getattr(self, "_fit_train_x", None) is None):
+            return False
+        if hasattr(self.kernel, "_feature_path") and self.kernel._feature_path(self.train_x, None, self.kernel.zeta) is not None:
+            return False            # explicit feature map (Dot, zeta = 2): the F x F weight-space system is refitted anyway
+        now = (tuple(float(v) for v in self.kernel.parameters()), float(self.noise_e), float(self.noise_f))
+        if self._dense_params != now:
+            return False
+        old = self._fit_train_x
+        nE0, nF0 = self._n_energy_points(old), (n_points(old["force"]) if len(old.get("force", [])) else 0)
+        E, F = self.train_x["energy"], self.train_x["force"]
+        nE1, nF1 = len(E[-1]), len(F[-1])
+        if nE1 - nE0 != self.N_energy_queue or nF1 - nF0 != self.N_forces_queue or nE1 + nF1 == nE0 + nF0:
+            return False
+        from .distributed import slice_energy, slice_force
+        new = {}
+        if nE1 > nE0:
+            new["energy"] = slice_energy(E, nE0, nE1)
+        if nF1 > nF0:
+            new["force"] = slice_force(F, nF0, nF1)
+        old_view = {"energy": slice_energy(E, 0, nE0), "force": slice_force(F, 0, nF0)} if nE0 and nF0 else \
+            ({"energy": slice_energy(E, 0, nE0)} if nE0 else {"force": slice_force(F, 0, nF0)})
+        kern = self.kernel
+        kt = (lambda a, b, **kw: kern.k_total_dev(a, b, 1e-10, **kw)) if kern.name == "RBF" else (lambda a, b, **kw: kern.k_total_dev(a, b, **kw))
+        N0, k = nE0 + 3 * nF0, (nE1 - nE0) + 3 * (nF1 - nF0)
+        D = d["L"].device
+        B = kt(new, old_view, transpose=True)                            # K(old, new), old rows in reference order
+        C = kt(new, None)
+        dev.add_diag_(C, nE1 - nE0, self.noise_e ** 2, self.noise_f ** 2)
+        perm0 = self._perm_dev if self._perm_dev is not None else torch.arange(N0, device=D)
+        Xt = B.index_select(0, perm0).contiguous()                       # rows in the factor's order
+        dev.trsm_lower_(d["L"], Xt, dinv=d["dinv"])                      # X^T = L^-1 B
+        S = C - dev.gemm(Xt, Xt, transa=True)
+        info, _ = dev.potrf_lower_(S, want_dinv=True)
+        if int(info.item()) != 0:
+            return False                                                 # not positive definite in finite precision: refit
+        L1 = torch.zeros((N0 + k, N0 + k), dtype=dev.F64, device=D)
+        L1[:N0, :N0] = d["L"]
+        L1[N0:, :N0] = Xt.T
+        L1[N0:, N0:] = S
+        dinv = dev.tri_inv64(L1)
+        # reference rows: [E_old | E_new | F_old | F_new]; old force rows move up by the new energies
+        shift = nE1 - nE0
+        p_old = torch.where(perm0 < nE0, perm0, perm0 + shift)
+        p_new = torch.cat((torch.arange(nE0, nE1, device=D), torch.arange(nE1 + 3 * nF0, nE1 + 3 * nF1, device=D)))
+        perm = torch.cat((p_old, p_new))
+        y = dev.to_dev(self.y_train).index_select(0, perm).clone()
+        dev.trsm_lower_(L1, y, dinv=dinv)
+        dev.trsm_lower_(L1, y, trans=True, dinv=dinv)
+        alpha = torch.empty_like(y)
+        alpha[perm] = y
+        Linv0 = self._Linv_dev
+        self._dense = {"L": L1, "alpha": alpha, "dinv": dinv}
+        self._perm_dev = perm
+        self._K_inv_dev = None
+        self._host = {}
+        self._ws_cache = None
+        if Linv0 is not None:                                            # extend L^-1 too: -L_s^-1 X L^-1 | L_s^-1
+            Ls_inv = torch.eye(k, dtype=dev.F64, device=D)
+            dev.trsm_lower_(S, Ls_inv)
+            Linv1 = torch.zeros_like(L1)
+            Linv1[:N0, :N0] = Linv0
+            Linv1[N0:, :N0] = -dev.gemm(Ls_inv, dev.gemm(Xt, Linv0, transa=True))
+            Linv1[N0:, N0:] = Ls_inv
+            self._Linv_dev = Linv1
+        else:
+            self._Linv_dev = None
+        return True
 
     # kernels with an explicit feature map (Dot_mb at zeta = 2): K + D = Psi' Psi'^T + D with Psi' = sigma Psi [N, F],
     # F = 466 per species << N, so by the Woodbury identity everything a prediction needs comes from the F x F matrix
@@ -525,7 +628,8 @@ class GP():
         else:
             if Kt is None:
                 Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
-            V = dev.trmm_lower(self._Linv(), Kt)                                  # V = L^-1 K_trans^T
+            Ktp = Kt if self._perm_dev is None else Kt.index_select(0, self._perm_dev)
+            V = dev.trmm_lower(self._Linv(), Ktp)                                 # V = L^-1 K_trans^T
             var = var - dev.colsumsq(V)
         var = torch.clamp_min(var, 0.0)
         return (mean, var, None) if want_flat else (mean, var)
@@ -547,6 +651,8 @@ class GP():
                 Psi = self.kernel._psi(train_x, species)
                 w = dev.gemm(Psi, self._alpha_dev, transa=True, alpha=self.kernel.sigma ** 2)     # [F, 1]
                 W = Psi * (self.kernel.sigma ** 2)
+                if self._perm_dev is not None:
+                    W = W.index_select(0, self._perm_dev)
                 dev.trsm_lower_(self._L_dev, W, dinv=self._dinv_dev)
                 self._ws_cache = (species, dev.gemm(W, W, transa=True), w)
         return self._ws_cache or None

@@ -214,6 +214,9 @@ int gpr_profile_counts(int *launches_seen_by_kind);
  * shards (one RCCL all-reduce) gives the full block exactly, because every element is produced by
  * exactly one shard.  (1, 0) restores the default.  Role of the reference's MPI row chunking,
  * RBF_mb.py:257-269, 471-481. */
+/* The L0 natives are `void` like the reference's: one that cannot run on the device (descriptor longer than this build
+ * packs, HIP error) prints the reason, leaves its output buffers untouched and returns; this reports why (GPR_OK = it ran). */
+int gpr_l0_last_status(void);
 int gpr_set_shard(int nshards, int shard);
 
 /* ------------------------------------------------------------------ neighbour bookkeeping (host) */

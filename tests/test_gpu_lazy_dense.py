@@ -83,3 +83,51 @@ def test_session_call_matches_the_python_unpacking_route():
     gp.fit(show=False, opt=False)
     c = gp.predict_structures(uniform, return_std=True)
     assert np.allclose(c[0], a[0][:0] or c[0])
+
+
+def test_appended_fit_matches_a_full_refit():
+    """fit(opt=False) after add_structure with unchanged hyper-parameters extends the Cholesky factor by the queued
+    rows (trsm + a small potrf) instead of rebuilding K: same alpha_, _K_inv, predictions and std as the full refit, twice
+    in a row (the second append starts from an already permuted factor), and L_ still has the reference's definition"""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+
+    def model(incremental):
+        gp = GP(kernel=RBF_mb(para=[2.5, 1.3], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002,
+                noise_f=0.1, log_file="/tmp/gpr_test.log")
+        gp.incremental_fit = incremental
+        rows = []
+        for s in range(4):
+            a = fcc_cell(seed=s, reps=1, species=(46, 78), sigma=0.08)
+            E, F = lj_energy_forces(a)
+            rows.append((a, E, F, True, [0, 2, 3]))
+        gp.fit(gp.points_from_structures(rows), show=False, opt=False)
+        return gp
+    inc, full = model(True), model(False)
+    test = fcc_cell(seed=71, reps=1, species=(46, 78), sigma=0.08)
+    inc.predict_structure(test, stress=False, return_std=True)           # forms L^-1: the append must extend it too
+    for step, seed in enumerate((60, 61)):
+        new = fcc_cell(seed=seed, reps=1, species=(46, 78), sigma=0.25)
+        E, F = lj_energy_forces(new)
+        for gp in (inc, full):
+            gp.add_structure((new, E, F.copy()))
+            assert gp.N_queue > 0
+            gp.fit(show=False, opt=False)
+            assert gp.N_queue == 0
+        assert inc._perm_dev is not None and full._perm_dev is None
+        # two different elimination orders of a matrix with cond ~1e7: alpha agrees to cond * eps, predictions to 1e-9
+        assert np.abs(inc.alpha_ - full.alpha_).max() <= 1e-8 * np.abs(full.alpha_).max()
+        assert np.abs(inc.y_train - full.y_train).max() == 0.0
+        a = inc.predict_structure(test, stress=False, return_std=True, f_tol=1e-12)
+        b = full.predict_structure(test, stress=False, return_std=True, f_tol=1e-12)
+        assert abs(a[0] - b[0]) < 1e-9 and np.abs(a[1] - b[1]).max() < 1e-9
+        assert abs(a[3] - b[3]) < 1e-9 and np.abs(a[4] - b[4]).max() < 1e-9
+        assert np.abs(inc._K_inv - full._K_inv).max() <= 1e-8 * np.abs(full._K_inv).max()
+    assert np.abs(inc.L_ - full.L_).max() <= 1e-10 * np.abs(full.L_).max()       # refactored in the reference's order
+    # changed hyper-parameters: no append
+    inc.add_structure((fcc_cell(seed=62, reps=1, species=(46, 78), sigma=0.2), *lj_energy_forces(fcc_cell(seed=62, reps=1, species=(46, 78), sigma=0.2))))
+    inc.kernel.update([2.0, 1.0])
+    inc.fit(show=False, opt=False)
+    assert inc._perm_dev is None

@@ -181,3 +181,23 @@ def test_so3_other_configurations_match_oracle(cfg):
         assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
         if stress:
             assert rel(out["rdxdr"], ref["rdxdr"]) < REL
+
+
+def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
+    """SO3.calculate(atoms, atom_ids=...) and SO3(derivative=False) (gpr_calc/SO3.py:186-323, 353-399): x keeps its
+    [n, ncoef] shape with the rows of the other centres zero, seq / dxdr list only the rows of the chosen centres in
+    the order given; without derivatives the dictionary has no seq and dxdr is None"""
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.synthetic import fcc_cell
+    a = fcc_cell(seed=4, reps=1, species=(46, 78), sigma=0.1)
+    des = SO3(nmax=3, lmax=4, rcut=5.0)
+    full = des.calculate(a)
+    sub = des.calculate(a, atom_ids=[2, 0])
+    assert sub["x"].shape == full["x"].shape and np.array_equal(sub["x"][[0, 2]], full["x"][[0, 2]])
+    assert not sub["x"][[1, 3]].any()
+    rows = np.concatenate([np.flatnonzero(full["seq"][:, 0] == i) for i in (2, 0)])
+    assert np.array_equal(sub["seq"], full["seq"][rows]) and np.array_equal(sub["dxdr"], full["dxdr"][rows])
+    nod = SO3(nmax=3, lmax=4, rcut=5.0, derivative=False).calculate(a)
+    assert nod["dxdr"] is None and nod["rdxdr"] is None and "seq" not in nod and np.array_equal(nod["x"], full["x"])
+    with pytest.raises(NotImplementedError):
+        SO3(nmax=4, lmax=4, rcut=5.0)             # ncoef = 50: beyond the device kernels, said at construction
