@@ -209,3 +209,45 @@ def write_db(filename, records, append=False):
         con.commit()
     finally:
         con.close()
+
+
+def read_traj(path):
+    """Frames of an ASE trajectory file (.traj, the "ULM" container: 48-byte header, one JSON record per frame with
+    ndarray payloads referenced by file offset) without ASE: a list of dictionaries
+    {atoms: SimpleAtoms (FixAtoms indices in .fixed), energy, forces} -- energy / forces None when the frame carries
+    no calculator results.  Header fields of the first frame (numbers, cell, pbc, constraints) apply to later frames
+    that omit them, as in ase.io.trajectory."""
+    import struct
+    from .neighbors import SimpleAtoms
+    with open(path, "rb") as fh:
+        b = fh.read()
+    if b[:8] != b"- of Ulm":
+        raise ValueError(f"{path}: not an ASE trajectory (ULM) file")
+    _, nitems, pos0 = struct.unpack("<3q", b[24:48])
+    offsets = np.frombuffer(b, dtype="<i8", count=nitems, offset=pos0)
+
+    def arr(spec):
+        shape, dtype, off = spec["ndarray"]
+        return np.frombuffer(b, dtype=dtype, count=int(np.prod(shape)), offset=off).reshape(shape).copy()
+
+    def field(meta, key, default=None):
+        if key + "." in meta:
+            return arr(meta[key + "."])
+        return np.asarray(meta[key]) if key in meta else default
+    frames, head = [], {}
+    for off in offsets:
+        off = int(off)
+        n = struct.unpack("<q", b[off:off + 8])[0]
+        meta = json.loads(b[off + 8:off + 8 + n].decode())
+        for key in ("numbers", "cell", "pbc"):
+            v = field(meta, key)
+            if v is not None:
+                head[key] = v
+        if "constraints" in meta:
+            cons = json.loads(meta["constraints"]) if isinstance(meta["constraints"], str) else meta["constraints"]
+            head["fixed"] = [i for c in cons if c.get("name") == "FixAtoms" for i in c["kwargs"]["indices"]]
+        atoms = SimpleAtoms(head["numbers"], field(meta, "positions"), head.get("cell"), head.get("pbc", False),
+                            fixed=head.get("fixed", ()))
+        calc = meta.get("calculator.", meta.get("calculator", {})) or {}
+        frames.append({"atoms": atoms, "energy": calc.get("energy"), "forces": field(calc, "forces")})
+    return frames

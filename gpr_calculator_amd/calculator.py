@@ -43,12 +43,21 @@ except Exception:                               # ASE absent: minimal protocol s
             if atoms is not None:
                 self.atoms = atoms.copy()
 
+        def _stale(self, atoms, prop):
+            """ase: a property is recomputed only when the atoms changed since the last calculation"""
+            old = self.atoms
+            return (prop not in self.results or old is None or atoms is None or len(old) != len(atoms)
+                    or not np.array_equal(old.positions, atoms.positions) or not np.array_equal(old.cell, atoms.cell)
+                    or not np.array_equal(old.numbers, atoms.numbers))
+
         def get_potential_energy(self, atoms=None):
-            self.calculate(atoms)
+            if self._stale(atoms, 'energy'):
+                self.calculate(atoms)
             return self.results['energy']
 
         def get_forces(self, atoms=None):
-            self.calculate(atoms)
+            if self._stale(atoms, 'forces'):
+                self.calculate(atoms)
             return self.results['forces']
 
 
