@@ -57,6 +57,7 @@ _L1_SIGNATURES = {
     "gpr_potrf_panel_rows": ([_vp, _i, _vp, _vp, _ll, _i], _i),
     "gpr_gemm_nt_cyclic_lower": ([_vp, _i, _i, _i, _d, _vp, _ll, _vp, _ll, _d, _vp, _ll, _i, _i, _i, _i, _i], _i),
     "gpr_potrf_finish": ([_vp, _i, _vp, _ll, _vp], _i),
+    "gpr_trtri_lower": ([_vp, _i, _vp, _ll, _vp, _ll], _i),
     "gpr_mirror_lower": ([_vp, _i, _vp, _ll], _i),
     "gpr_trmm_lower": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll], _i),
     "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),

@@ -281,12 +281,13 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
     }
 }
 
-// inverse of one 64 x 64 lower-triangular diagonal block of L -> dinv block (zero padded); one workgroup per block.
-// Column c of the inverse by forward substitution in thread c; the block and the running solution live in LDS.
+// inverse of one 64 x 64 lower-triangular diagonal block of L -> dinv block (zero padded); one wavefront per block,
+// lane c = column c of the inverse.  Right-looking forward substitution with the 64 partial right-hand sides of a column
+// in registers: finishing x[q] updates acc[r] -= T[r][q] x[q] for r > q with independent multiply-adds (T[r][q] is a
+// broadcast LDS read), so the 64-step dependency chain carries one multiply per step instead of a dot product.
 __global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict__ a, long long lda, int n,
                                                         double *__restrict__ dinv) {
     __shared__ double T[64][65];
-    __shared__ double X[64][65];
     const int b = blockIdx.x, k0 = b * 64, kb = min(64, n - k0), c = threadIdx.x;
     for (int i = 0; i < 64; i++) {
         double v = (i == c) ? 1.0 : 0.0;
@@ -294,19 +295,19 @@ __global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict_
         T[i][c] = v;
     }
     __syncthreads();
-    for (int r = 0; r < 64; r++) {
-        double v0 = (r == c) ? 1.0 : 0.0, v1 = 0.0;
-        int q = c;                                            // X[q][c] = 0 for q < c
-        for (; q + 1 < r; q += 2) {
-            v0 = __builtin_fma(-T[r][q], X[q][c], v0);
-            v1 = __builtin_fma(-T[r][q + 1], X[q + 1][c], v1);
-        }
-        if (q < r) v0 = __builtin_fma(-T[r][q], X[q][c], v0);
-        X[r][c] = (r >= c) ? (v0 + v1) / T[r][r] : 0.0;
+    double acc[64];
+#pragma unroll
+    for (int r = 0; r < 64; r++) acc[r] = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int q = 0; q < 64; q++) {
+        const double x = acc[q] / T[q][q];
+        acc[q] = x;
+#pragma unroll
+        for (int r = q + 1; r < 64; r++) acc[r] = __builtin_fma(-T[r][q], x, acc[r]);
     }
-    __syncthreads();
     double *out = dinv + (size_t)b * 4096;
-    for (int i = 0; i < 64; i++) out[i * 64 + c] = (i < kb && c < kb) ? X[i][c] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 64; i++) out[i * 64 + c] = (i < kb && c < kb && i >= c) ? acc[i] : 0.0;
 }
 
 __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
@@ -442,6 +443,93 @@ extern "C" int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, d
     if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, n, l, ldl);
     LAUNCH_CHECK("potrf_finish");
     return GPR_OK;
+}
+
+// X = L^-1 for a lower-triangular L (n x n, e.g. from gpr_potrf_lower), X lower triangular with zeros above the
+// diagonal.  Block rows of 256: the inverse of a diagonal block is the panel kernel applied to the identity
+// (I L_kk^-T, transposed while it is stored), the blocks to its left are  X[k, :k] = -L_kk^-1 (L[k, :k] X[:k, :k])  --
+// two products on the matrix cores per block row instead of a 64-wide substitution sweep over all n columns.
+__global__ void __launch_bounds__(256) trtri_store_kernel(int kb, const double *__restrict__ t, double *__restrict__ x, long long ldx) {
+    // x[i][j] = t[j][i] (t = L_kk^-T, kb x kb, ld DB); zero above the diagonal
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), j = blockIdx.y * 16 + (threadIdx.x & 15);
+    if (i < kb && j < kb) x[(long long)i * ldx + j] = (j <= i) ? t[(size_t)j * DB + i] : 0.0;
+}
+// operand tiles (as the diagonal kernel emits them) of an already factored kb x kb lower-triangular block: W_k = inverse of
+// its k-th 16 x 16 diagonal tile (one wavefront per tile: the tiles are independent), L_jk copied into operand order
+__global__ void __launch_bounds__(1024) tri_tiles256_kernel(const double *__restrict__ l, long long ldl, int kb,
+                                                             double *__restrict__ wop, double *__restrict__ lop) {
+    __shared__ double W[16][16][17];
+    const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6, lr = lane & 15, lq = lane >> 4;
+    const int nt = (kb + DT - 1) / DT;
+    if (k < nt && lane < 16) {
+        double t[16], acc[16];                                   // row `lane` of the tile; column `lane` of its inverse
+#pragma unroll
+        for (int c = 0; c < 16; c++) {
+            const int row = k * DT + lane, col = k * DT + c;
+            t[c] = (row < kb && col < kb) ? (c <= lane ? l[(long long)row * ldl + col] : 0.0) : (row == col ? 1.0 : 0.0);
+            acc[c] = (c == lane) ? 1.0 : 0.0;
+        }
+#pragma unroll
+        for (int q = 0; q < 16; q++) {                           // T[r][q] lives in lane r: wave-uniform through v_readlane
+            const double x = acc[q] / readlane_d(t[q], q);
+            acc[q] = x;
+#pragma unroll
+            for (int r = q + 1; r < 16; r++) acc[r] = __builtin_fma(-readlane_d(t[q], r), x, acc[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) W[k][r][lane] = (r >= lane) ? acc[r] : 0.0;
+    }
+    __syncthreads();
+    if (k < nt) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) wop[(size_t)k * TILE_DOUBLES + q * 64 + lane] = W[k][lr][lq + 4 * q];
+    }
+    for (int t = k; t < NTILE; t += 16) {                        // tiles (j, kk), j > kk, in operand order
+        const int j = c_tiles.i[t], kk = c_tiles.j[t];
+        if (j == kk || j >= nt) continue;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int row = j * DT + lr, col = kk * DT + lq + 4 * q;
+            lop[(size_t)t * TILE_DOUBLES + q * 64 + lane] = (row < kb && col < kb) ? l[(long long)row * ldl + col] : 0.0;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) trtri_eye_kernel(double *t) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e < DB * DB) t[e] = (e / DB == e % DB) ? 1.0 : 0.0;
+}
+
+extern "C" int gpr_trtri_lower(void *stream, int n, const double *l, long long ldl, double *x, long long ldx) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(n >= 0 && (n == 0 || (l && x)) && ldl >= n && ldx >= n, "gpr_trtri_lower: bad arguments");
+    if (n == 0) return GPR_OK;
+    void *scratch;
+    const size_t ops = (size_t)(16 + NTILE) * TILE_DOUBLES;
+    int rc = gpr_dev_alloc(&scratch, (ops + (size_t)DB * DB + (size_t)DB * n) * sizeof(double), st);
+    if (rc) return rc;
+    double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES, *eye = wop + ops, *tmp = eye + DB * DB;
+    for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
+        const int KB = (n - K0 < DB) ? n - K0 : DB;
+        hipLaunchKernelGGL(tri_tiles256_kernel, dim3(1), dim3(1024), 0, st, l + (long long)K0 * ldl + K0, ldl, KB, wop, lop);
+        hipLaunchKernelGGL(trtri_eye_kernel, dim3(DB), dim3(256), 0, st, eye);
+        if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3(DB / DT), dim3(256), 0, st, eye, (long long)DB, DB, KB, wop, lop);
+        else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3(DB / DT), dim3(256), 0, st, eye, (long long)DB, DB, KB, wop, lop);
+        // eye now holds L_kk^-T (rows / columns < KB); X[k, k] = its transpose
+        double *xkk = x + (long long)K0 * ldx + K0;
+        hipLaunchKernelGGL(trtri_store_kernel, dim3((KB + 15) / 16, (KB + 15) / 16), dim3(256), 0, st, KB, eye, xkk, ldx);
+        if (K0 > 0) {
+            // tmp[KB, K0] = L[k, :k] X[:k, :k] (X lower triangular: k range of a column block starts at its own rows; the
+            // tiled product simply runs over all of them), then X[k, :k] = -X[k, k] tmp
+            rc = gpr_gemm_internal(st, 0, 0, KB, K0, K0, 1.0, l + (long long)K0 * ldl, ldl, x, ldx, 0.0, tmp, n, 0);
+            if (rc) break;
+            rc = gpr_gemm_internal(st, 0, 0, KB, K0, KB, -1.0, xkk, ldx, tmp, n, 0.0, x + (long long)K0 * ldx, ldx, 0);
+        }
+    }
+    const hipError_t e = hipGetLastError();
+    const int rc2 = gpr_dev_free(scratch, st);
+    if (e != hipSuccess) { gpr_set_error("gpr_trtri_lower launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return rc ? rc : rc2;
 }
 
 extern "C" int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev) {

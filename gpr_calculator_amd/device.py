@@ -282,6 +282,14 @@ def tri_inv64(l):
     return dinv
 
 
+def trtri_lower(l):
+    """L^-1 of a lower-triangular device matrix (zeros above the diagonal), 256-row blocks on the matrix cores"""
+    n = l.shape[0]
+    x = torch.zeros((n, n), dtype=F64, device=l.device)
+    check(_lib.lib().gpr_trtri_lower(stream_ptr(), n, ptr(l), int(l.stride(0)) if n > 1 else n, ptr(x), n), "gpr_trtri_lower")
+    return x
+
+
 def trsm_lower_(l, b, trans=False, dinv=None):
     """b <- L^-1 b (trans False) or L^-T b (trans True); b is [n, nrhs] row-major, in place"""
     n, nrhs = b.shape

@@ -246,8 +246,7 @@ class GP():
         if not eval_gradient:
             return MLL
         # gradient: 0.5 * tr((alpha alpha^T - K^-1) dK/dtheta)   (GPML eq. 5.9; gaussianprocess.py:188-200)
-        Linv = torch.eye(N, dtype=dev.F64, device=L.device)
-        dev.trsm_lower_(L, Linv, dinv=dinv)
+        Linv = dev.trtri_lower(L)
         Kinv = dev.gemm(Linv, Linv, transa=True)
         grads = []
         for dK in (dK0, dK1):
@@ -298,8 +297,7 @@ class GP():
             return (MLL,)
         # every G^-1 quadratic form goes through C^-1 (G = C C^T): x^T G^-1 x = |C^-1 x|^2 keeps the cancellations below
         # (N_E / noise_e^2 - ..., 1 - ...) at working precision, which an explicit G^-1 (cond ~ 1e10) does not
-        Ci = torch.eye(F, dtype=dev.F64, device=S.device)
-        dev.trsm_lower_(G, Ci, dinv=dinv)                                   # C^-1
+        Ci = dev.trtri_lower(G)                                             # C^-1
         tr_Ginv = dev.frob_dot(Ci, Ci).item()
         g_sigma = (dev.frob_dot(u, u).item() - (F - tr_Ginv)) / sig
         # row sums over this rank's rows, then over ranks: Psi'^T D^-1 1_E, sum of alpha over the energy rows, and the
@@ -577,8 +575,7 @@ class GP():
             return False
         dev.trsm_lower_(G, b, dinv=dinv)
         dev.trsm_lower_(G, b, trans=True, dinv=dinv)                              # G^-1 b
-        Ci = torch.eye(F, dtype=dev.F64, device=G.device)
-        dev.trsm_lower_(G, Ci, dinv=dinv)                                         # C^-1, G = C C^T
+        Ci = dev.trtri_lower(G)                                                    # C^-1, G = C C^T
         # M = sigma^2 (I - G^-1) is formed from C^-1 only when the unfactored variance form asks for it (_ws_M)
         self._ws_cache = [species, None, b * sig, Ci]                     # Ci = C^-1 feeds the factored variance form
         return True
@@ -661,10 +658,7 @@ class GP():
         """L^-1 on the device (lower triangular), built once per fit: the variance of every later
         prediction is then one triangular matrix product instead of a substitution sweep"""
         if self._Linv_dev is None:
-            n = self._L_dev.shape[0]
-            Linv = torch.eye(n, dtype=dev.F64, device=self._L_dev.device)
-            dev.trsm_lower_(self._L_dev, Linv, dinv=getattr(self, "_dinv_dev", None))
-            self._Linv_dev = Linv
+            self._Linv_dev = dev.trtri_lower(self._L_dev)
         return self._Linv_dev
 
     def predict(self, X, stress=False, total_E=False, return_std=False, return_cov=False):

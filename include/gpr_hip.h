@@ -343,6 +343,8 @@ int gpr_gemm_nt_cyclic_lower(void *stream, int m, int n, int k, double alpha, co
                              const double *b, long long ldb, double beta, double *c, long long ldc, int nb, int nranks,
                              int rank, int lb0, int col0);
 int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, double *dinv);
+/* X = L^-1 of a lower-triangular L (zeros above the diagonal of X), 256-row blocks on the matrix cores */
+int gpr_trtri_lower(void *stream, int n, const double *l, long long ldl, double *x, long long ldx);
 int gpr_mirror_lower(void *stream, int n, double *a, long long lda);
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
 int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,

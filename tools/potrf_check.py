@@ -24,6 +24,17 @@ for n in sizes:
         k0, kb = b * 64, min(64, n - b * 64)
         W = dinv[b * 4096:(b + 1) * 4096].reshape(64, 64)[:kb, :kb]
         derr = max(derr, float((W @ L[k0:k0 + kb, k0:k0 + kb] - torch.eye(kb, dtype=torch.float64, device=d)).abs().max()))
+    X = dev.trtri_lower(L)
+    ierr = float((X @ L - torch.eye(n, dtype=torch.float64, device=d)).abs().max())
+    terr = float(torch.triu(X, 1).abs().max())
+    tt = []
+    for _ in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); dev.trtri_lower(L); torch.cuda.synchronize(); tt.append(time.perf_counter() - t0)
+    to = []
+    for _ in range(2):
+        I = torch.eye(n, dtype=torch.float64, device=d); torch.cuda.synchronize(); t0 = time.perf_counter()
+        dev.trsm_lower_(L, I, dinv=dinv); torch.cuda.synchronize(); to.append(time.perf_counter() - t0)
+    derr = max(derr, 0.0 if (ierr < 1e-9 and terr == 0.0) else 1.0)
     ts = []
     for _ in range(5 if n > 256 else 2):
         L2 = A.clone(); torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -31,7 +42,7 @@ for n in sizes:
     flag = "ok" if (err < 1e-11 and rec < 1e-12 and derr < 1e-9 and int(info.item()) == 0) else "FAIL"
     ok &= flag == "ok"
     print(f"n={n:6d} |L-ref|/|ref|={err:.2e} |LL^T-A|/|A|={rec:.2e} dinv={derr:.2e} info={int(info.item())} "
-          f"{min(ts) * 1e3:8.3f} ms  {n ** 3 / 3 / min(ts) / 1e12:6.2f} TF  {flag}", flush=True)
+          f"{min(ts) * 1e3:8.3f} ms  {n ** 3 / 3 / min(ts) / 1e12:6.2f} TF  trtri |XL-I|={ierr:.1e} {min(tt) * 1e3:7.3f} ms (trsm on I: {min(to) * 1e3:7.3f} ms)  {flag}", flush=True)
 # not positive definite: info = first bad leading minor
 A = torch.eye(300, dtype=torch.float64, device=d); A[200, 200] = -1.0
 info = dev.potrf_lower_(A)
