@@ -496,6 +496,7 @@ __global__ void __launch_bounds__(256) dot2_features_ef_kernel(dfeat_args AF, df
 extern "C" int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const int *species_host, double sigma0,
                                  double *out, long long ld) {
     hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(!set || set->ks == GPR_KSTEPS, "gpr_dot2_features: the degree-2 feature map covers descriptors of length <= %d", GPR_KPAD);
     GPR_REQUIRE(set && set->role == GPR_ROLE_STREAM, "gpr_dot2_features: needs a STREAM-packed set");
     GPR_REQUIRE(ns >= 1 && ns <= FEAT_MAX_SPECIES, "gpr_dot2_features: 1..%d species supported (got %d)", FEAT_MAX_SPECIES, ns);
     GPR_REQUIRE(!(set->flags & GPR_SET_NUMPY_EPS), "gpr_dot2_features: native (no-eps) sets only");

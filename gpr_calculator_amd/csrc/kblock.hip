@@ -62,18 +62,19 @@ __device__ __forceinline__ void pair_scalars(double c, const kb_args &P, double 
     } else { Kv = 0.0; g = 1.0; }
 }
 
-template <int MODE, int KIND, bool Z2, bool GRAD, int NW>
+// KS: k-steps per operand plane, 8 (d <= 32) or 16 (d <= 64; four stream tiles per staged chunk instead of eight)
+template <int MODE, int KIND, bool Z2, bool GRAD, int NW, int KS>
 __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
-    constexpr int KS = GPR_KSTEPS;
+    constexpr int PLANE = KS * GPR_WAVE, CTILES = GPR_CHUNK_TILES * GPR_KSTEPS / KS;
     constexpr int NCB = (MODE == GPR_MODE_EE) ? 1 : 4;            // resident planes per group
     constexpr int NOUT = (MODE == GPR_MODE_FF) ? 9 : (MODE == GPR_MODE_EF ? 3 : 1);
     constexpr int AROWS = (MODE == GPR_MODE_FF) ? 4 : 16;         // stream rows per tile
     constexpr int NTHREADS = NW * 64;
-    constexpr int CHUNK_BYTES = GPR_CHUNK_TILES * GPR_PLANE * 8;
+    constexpr int CHUNK_BYTES = CTILES * PLANE * 8;
     constexpr int NLD = CHUNK_BYTES / (NTHREADS * 16);
     static_assert(NLD * NTHREADS * 16 == CHUNK_BYTES, "chunk must divide evenly");
 
-    __shared__ __attribute__((aligned(16))) double sA[2][GPR_CHUNK_TILES * GPR_PLANE];
+    __shared__ __attribute__((aligned(16))) double sA[2][CTILES * PLANE];
     __shared__ int sEle[2][GPR_CHUNK_TILES * 16];
     __shared__ double sNorm[2][GPR_CHUNK_TILES * 16];
 
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
         double normB = 0.0;
         int my_pt = -1;                                // packed resident point of this lane's column (-1: padding)
         if (has) {
-            const double *bp = P.b_ops + (size_t)(pj.group0 + g) * NCB * GPR_PLANE;
+            const double *bp = P.b_ops + (size_t)(pj.group0 + g) * NCB * PLANE;
 #pragma unroll
             for (int t = 0; t < NCB; t++)
 #pragma unroll
@@ -151,8 +152,8 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
         // than lambdas so that the staging registers are never address-taken (no scratch)
 #define GPR_STAGE_LOAD(C_)                                                                              \
         {   const gpr_chunk ch_ = P.a_chunks[(C_)];                                                      \
-            const char *src_ = (const char *)(P.a_ops + (size_t)ch_.tile0 * GPR_PLANE);                  \
-            const int bytes_ = ch_.ntiles * GPR_PLANE * 8;                                               \
+            const char *src_ = (const char *)(P.a_ops + (size_t)ch_.tile0 * PLANE);                      \
+            const int bytes_ = ch_.ntiles * PLANE * 8;                                                   \
             _Pragma("unroll") for (int i_ = 0; i_ < NLD; i_++) {                                         \
                 const int off_ = (i_ * NTHREADS + tid) * 16;                                             \
                 regs[i_] = (off_ < bytes_) ? *(const float4 *)(src_ + off_) : make_float4(0.f, 0.f, 0.f, 0.f); } \
@@ -161,7 +162,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                 if (MODE == GPR_MODE_EE) nreg = P.a_norm[ch_.tile0 * AROWS + tid]; } }
 #define GPR_STAGE_STORE(C_, BUF_)                                                                       \
         {   const gpr_chunk ch_ = P.a_chunks[(C_)];                                                      \
-            const int bytes_ = ch_.ntiles * GPR_PLANE * 8;                                               \
+            const int bytes_ = ch_.ntiles * PLANE * 8;                                                   \
             char *dst_ = (char *)sA[(BUF_)];                                                             \
             _Pragma("unroll") for (int i_ = 0; i_ < NLD; i_++) {                                         \
                 const int off_ = (i_ * NTHREADS + tid) * 16;                                             \
@@ -183,7 +184,7 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
             if (P.diag_only && (ch.pt < pt_lo || ch.pt > pt_hi)) mine = false;
             if (mine) {
                 for (int tile = 0; tile < ch.ntiles; ++tile) {
-                    const double *At = sA[buf] + tile * GPR_PLANE;
+                    const double *At = sA[buf] + tile * PLANE;
                     d4 acc[NCB];
 #pragma unroll
                     for (int t = 0; t < NCB; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
@@ -343,15 +344,17 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
 
 // ---------------------------------------------------------------- host launcher
 template <int MODE, int KIND, bool Z2, bool GRAD>
-static void launch_nw(hipStream_t st, int nw, int nblocks, const kb_args &a) {
-    if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8>), dim3(nblocks), dim3(512), 0, st, a);
-    else         hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4>), dim3(nblocks), dim3(256), 0, st, a);
+static void launch_nw(hipStream_t st, int nw, int ks, int nblocks, const kb_args &a) {
+    if (ks == GPR_KSTEPS_MAX)       // long descriptors: four wavefronts (the resident operands alone are 128 VGPRs per lane)
+        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_MAX>), dim3(nblocks), dim3(256), 0, st, a);
+    else if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8, GPR_KSTEPS>), dim3(nblocks), dim3(512), 0, st, a);
+    else              hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS>), dim3(nblocks), dim3(256), 0, st, a);
 }
 
 template <int MODE, int KIND>
-static void launch_zg(hipStream_t st, bool z2, bool grad, int nw, int nblocks, const kb_args &a) {
-    if (z2) { if (grad) launch_nw<MODE, KIND, true, true>(st, nw, nblocks, a); else launch_nw<MODE, KIND, true, false>(st, nw, nblocks, a); }
-    else    { if (grad) launch_nw<MODE, KIND, false, true>(st, nw, nblocks, a); else launch_nw<MODE, KIND, false, false>(st, nw, nblocks, a); }
+static void launch_zg(hipStream_t st, bool z2, bool grad, int nw, int ks, int nblocks, const kb_args &a) {
+    if (z2) { if (grad) launch_nw<MODE, KIND, true, true>(st, nw, ks, nblocks, a); else launch_nw<MODE, KIND, true, false>(st, nw, ks, nblocks, a); }
+    else    { if (grad) launch_nw<MODE, KIND, false, true>(st, nw, ks, nblocks, a); else launch_nw<MODE, KIND, false, false>(st, nw, ks, nblocks, a); }
 }
 
 static thread_local int g_shard_mod = 1, g_shard_rem = 0;
@@ -382,8 +385,9 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     if (s1->npts == 0 || s2->npts == 0 || s1->nchunks == 0 || s2->maxgroups == 0) return GPR_OK;
 
     // workgroup width: 8 wavefronts when that still leaves >= 2 blocks per CU, else 4
+    GPR_REQUIRE(s1->ks == s2->ks, "block: sets packed with different plane widths");
     int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
-    if (c.diag_only) nw = 4;
+    if (c.diag_only || s1->ks == GPR_KSTEPS_MAX) nw = 4;
     const int njb = c.diag_only ? s2->nwu : (s2->nwu + nw - 1) / nw;
 
     // stream ranges (consecutive packed points, ~128 tiles each) were laid out at pack time
@@ -414,12 +418,12 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     const int nblocks = c.diag_only ? njb : njb * nir;
     const bool grad = c.grad != 0;
     switch (c.mode * 2 + c.kind) {
-        case GPR_MODE_FF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_FF, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
-        case GPR_MODE_FF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_FF, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
-        case GPR_MODE_EF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EF, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
-        case GPR_MODE_EF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EF, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
-        case GPR_MODE_EE * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EE, GPR_KERNEL_RBF>(st, z2, grad, nw, nblocks, a); break;
-        case GPR_MODE_EE * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EE, GPR_KERNEL_DOT>(st, z2, false, nw, nblocks, a); break;
+        case GPR_MODE_FF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_FF, GPR_KERNEL_RBF>(st, z2, grad, nw, s1->ks, nblocks, a); break;
+        case GPR_MODE_FF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_FF, GPR_KERNEL_DOT>(st, z2, false, nw, s1->ks, nblocks, a); break;
+        case GPR_MODE_EF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EF, GPR_KERNEL_RBF>(st, z2, grad, nw, s1->ks, nblocks, a); break;
+        case GPR_MODE_EF * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EF, GPR_KERNEL_DOT>(st, z2, false, nw, s1->ks, nblocks, a); break;
+        case GPR_MODE_EE * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_EE, GPR_KERNEL_RBF>(st, z2, grad, nw, s1->ks, nblocks, a); break;
+        case GPR_MODE_EE * 2 + GPR_KERNEL_DOT: launch_zg<GPR_MODE_EE, GPR_KERNEL_DOT>(st, z2, false, nw, s1->ks, nblocks, a); break;
         default: gpr_set_error("block: bad mode/kind"); return GPR_ERR_ARG;
     }
     hipError_t e = hipGetLastError();

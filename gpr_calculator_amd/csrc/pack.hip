@@ -83,6 +83,7 @@ struct pack_args {
     int *ele_out;
     int d, width, col0, nc, role, rpad, tile_rows;
     int numpy_eps, pad_code;
+    int plane, kpad;                // doubles per operand plane (64 k-steps), padded descriptor length (4 k-steps)
 };
 
 // one thread per padded row
@@ -95,17 +96,17 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
     size_t base;
     int slot_row;
     if (a.role == GPR_ROLE_STREAM && a.nc == 4) {
-        base = (size_t)(r >> 2) * GPR_PLANE;            // tile of 4 rows, comps share the plane
+        base = (size_t)(r >> 2) * a.plane;              // tile of 4 rows, comps share the plane
         slot_row = r & 3;
     } else {
-        base = (size_t)(r >> 4) * nplanes * GPR_PLANE;  // 16 rows per plane, nc planes (resident)
+        base = (size_t)(r >> 4) * nplanes * a.plane;    // 16 rows per plane, nc planes (resident)
         slot_row = r & 15;
     }
     auto slot = [&](int comp, int k) -> size_t {
         int s = k >> 2, kk = k & 3;
         if (a.role == GPR_ROLE_STREAM && a.nc == 4)
             return base + (size_t)s * GPR_WAVE + slot_row + 4 * comp + 16 * kk;
-        return base + (size_t)comp * GPR_PLANE + (size_t)s * GPR_WAVE + slot_row + 16 * kk;
+        return base + (size_t)comp * a.plane + (size_t)s * GPR_WAVE + slot_row + 16 * kk;
     };
 
     double n = 0.0;
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
     }
     if (!live) {
         for (int c = 0; c < a.nc; c++)
-            for (int k = 0; k < GPR_KPAD; k++) a.ops[slot(c, k)] = 0.0;
+            for (int k = 0; k < a.kpad; k++) a.ops[slot(c, k)] = 0.0;
         a.ele_out[r] = a.pad_code;
         a.norms[r] = 0.0;
         return;
@@ -145,10 +146,10 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
                 a.ops[slot(c, k)] = D[(size_t)k * a.width + c] * inv - ak * proj[c];
         }
         for (int c = 0; c < 3; c++)
-            for (int k = a.d; k < GPR_KPAD; k++) a.ops[slot(c, k)] = 0.0;
+            for (int k = a.d; k < a.kpad; k++) a.ops[slot(c, k)] = 0.0;
     }
     for (int k = 0; k < a.d; k++) a.ops[slot(row_comp, k)] = xr[k] * inv;
-    for (int k = a.d; k < GPR_KPAD; k++) a.ops[slot(row_comp, k)] = 0.0;
+    for (int k = a.d; k < a.kpad; k++) a.ops[slot(row_comp, k)] = 0.0;
     a.ele_out[r] = a.ele[xsrc];
     a.norms[r] = n;
 }
@@ -184,8 +185,8 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     GPR_REQUIRE(width == 0 || width == 3 || width == 9, "gpr_set_create: width must be 0, 3 or 9 (got %d)", width);
     GPR_REQUIRE(width == 0 || (col0 >= 0 && col0 + 3 <= width), "gpr_set_create: col0=%d outside width=%d", col0, width);
     GPR_REQUIRE(npts >= 0 && nrows >= 0, "gpr_set_create: negative sizes");
-    if (d < 1 || d > GPR_KPAD) {
-        gpr_set_error("gpr_set_create: descriptor length d=%d unsupported by this build (1..%d)", d, GPR_KPAD);
+    if (d < 1 || d > GPR_KPAD_MAX) {
+        gpr_set_error("gpr_set_create: descriptor length d=%d unsupported by this build (1..%d)", d, GPR_KPAD_MAX);
         return GPR_ERR_UNSUPPORTED;
     }
     GPR_REQUIRE(nrows == 0 || (x_dev && ele_dev && (width == 0 || dxdr_dev)), "gpr_set_create: null device pointer");
@@ -199,6 +200,9 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     gpr_set *s = new gpr_set();
     s->role = role; s->d = d; s->width = width; s->col0 = col0; s->flags = flags;
     s->nc = (width == 0) ? 1 : 4;
+    s->ks = (d <= GPR_KPAD) ? GPR_KSTEPS : GPR_KSTEPS_MAX;
+    const int chunk_tiles = GPR_CHUNK_TILES * GPR_KSTEPS / s->ks;          // same bytes per staged chunk
+    const size_t plane = (size_t)s->ks * GPR_WAVE;
     s->npts = npts; s->nrows = nrows;
     s->tile_rows = (role == GPR_ROLE_STREAM && s->nc == 4) ? 4 : 16;
 
@@ -235,8 +239,8 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
                 src_row.push_back(r < cnt ? (int)(row0[o] + r) : -1);
             s->h_pt_tiles[p] = units;
             s->h_pt_chunk0[p] = (int)chunks.size();
-            for (int t = 0; t < units; t += GPR_CHUNK_TILES) {
-                int nt = std::min(GPR_CHUNK_TILES, units - t);
+            for (int t = 0; t < units; t += chunk_tiles) {
+                int nt = std::min(chunk_tiles, units - t);
                 chunks.push_back(gpr_chunk{unit + t, nt, p, (t + nt >= units) ? 1 : 0});
             }
             unit += units;
@@ -306,7 +310,7 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
         if ((rc = upload(&s->rowpt, rowpt, st, &bytes))) return fail(rc);
     }
     size_t planes = (size_t)s->nunits * (role == GPR_ROLE_RESIDENT ? s->nc : 1);
-    size_t ops_bytes = planes * GPR_PLANE * sizeof(double);
+    size_t ops_bytes = planes * plane * sizeof(double);
     void *p;
     if ((rc = gpr_dev_alloc(&p, ops_bytes, st))) return fail(rc);
     s->ops = (double *)p; bytes += (long long)ops_bytes;
@@ -324,6 +328,7 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
         a.d = d; a.width = width; a.col0 = col0; a.nc = s->nc; a.role = role;
         a.rpad = s->rpad; a.tile_rows = s->tile_rows;
         a.numpy_eps = (flags & GPR_SET_NUMPY_EPS) ? 1 : 0;
+        a.plane = (int)plane; a.kpad = 4 * s->ks;
         a.pad_code = (role == GPR_ROLE_STREAM) ? GPR_ELE_PAD_STREAM : GPR_ELE_PAD_RESIDENT;
         const int pid = gpr_prof_begin(st, GPR_PROF_PACK);
         hipLaunchKernelGGL(pack_rows_kernel, dim3((s->rpad + 255) / 256), dim3(256), 0, st, a);

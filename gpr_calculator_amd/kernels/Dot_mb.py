@@ -63,8 +63,12 @@ class Dot_mb(DeviceKernel):
 
     def feature_dim(self, data):
         """features per species of the zeta = 2 map: d (d + 1) / 2 quadratic monomials + the constant"""
-        ent = data["force"] if "force" in data and n_points(data["force"]) > 0 else data["energy"]
-        X = ent.x if isinstance(ent, dev.SetPair) else ent[0]
+        if "force" in data and n_points(data["force"]) > 0:
+            ent = data["force"]
+            X = ent.x if isinstance(ent, dev.SetPair) else as_force_tuple(ent)[0]
+        else:
+            ent = data["energy"]
+            X = ent.x if isinstance(ent, dev.SetPair) else as_energy_tuple(ent)[0]
         d = int(X.shape[1])
         return d * (d + 1) // 2 + 1
 
@@ -115,6 +119,8 @@ class Dot_mb(DeviceKernel):
 
     def _feature_path(self, data1, data2, zeta_ee):
         if not self.use_feature_map or float(zeta_ee) != 2.0:
+            return None
+        if self.feature_dim(data1) > 32 * 33 // 2 + 1:                 # d > 32: the feature kernels pack 32 columns
             return None
         species = self._species_of(data1, data2 if data2 is not None else data1)
         return species if 1 <= len(species) <= 4 else None

@@ -24,12 +24,19 @@ CASES = {
                          tol=2e-3, n2_range=(5, 23)),
     "pd4_params":   dict(seed=5, d=30, counts1=[21, 19], counts2=[18, 23, 16], species=(8, 12, 46),
                          sigma=24.99290767873284, l=3.107283211515612),
+    # longer descriptors: SO3(nmax=4, lmax=4) has d = 50; 64 is the widest plane of the device kernels
+    "d50_mixed":    dict(seed=6, d=50, counts1=[5, 11, 3], counts2=[9, 4, 13, 6], species=(8, 46)),
+    "d64_zeta3":    dict(seed=7, d=64, counts1=[7, 6], counts2=[5, 10, 8], species=(13, 79), zeta=3.0, sigma=1.7,
+                         l=0.9, sigma0=1.5),
 }
 
 if __name__ == "__main__":
     ref = NativeSet("ref")
     port = NativeSet("port")
+    only = sys.argv[1:]
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         c = make_case(**kw)
         out = run_all_natives(ref, c)
         chk = run_all_natives(port, c)
