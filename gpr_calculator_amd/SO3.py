@@ -82,16 +82,17 @@ class SO3:
 
     @staticmethod
     def _check_device_limits(nmax, lmax):
-        """The device descriptor kernel (csrc/so3.hip) holds nmax (lmax + 1) <= 16 radial-angular channels and
-        ncoef <= 32 power-spectrum components (the MFMA operand planes of the covariance kernels are 32 columns wide):
-        say so when the object is configured, not deep inside a launch (the reference allows nmax <= 11, SO3.py:76-77)."""
+        """The device kernels cover nmax <= 4, lmax <= 6 and ncoef <= 64 power-spectrum components (the widest MFMA
+        operand plane of the covariance kernels is 64 columns; csrc/so3.hip, csrc/pack.hip): say so when the object is
+        configured, not deep inside a launch (the reference allows nmax <= 11, SO3.py:76-77).  Stress rows
+        (stress=True) additionally need nmax (lmax + 1) <= 16 and ncoef <= 32, checked at the launch."""
         if nmax is None or lmax is None:
             return
         ncoef = nmax * (nmax + 1) // 2 * (lmax + 1)
-        if nmax > 4 or lmax > 6 or nmax * (lmax + 1) > 16 or ncoef > 32:
+        if nmax > 4 or lmax > 6 or ncoef > 64:
             raise NotImplementedError(
                 f"SO3(nmax={nmax}, lmax={lmax}) gives ncoef = {ncoef}; this build's device kernels cover nmax <= 4, "
-                f"lmax <= 6, nmax (lmax + 1) <= 16 and ncoef <= 32 (e.g. the reference's default nmax=3, lmax=4)")
+                f"lmax <= 6 and ncoef <= 64 (the reference's default is nmax=3, lmax=4: ncoef = 30)")
 
     # -- validated attributes (gpr_calc/SO3.py:67-182)
     @property

@@ -258,7 +258,10 @@ struct so3_args {
 
 constexpr int SO3_PC = 44;       // pairs whose tables are resident in LDS at a time (with the tables below: < 40 KB,
                                  // four workgroups per CU)
-constexpr int SO3_NLP = 16;      // padded nmax (lmax+1)
+constexpr int SO3_NLP = 16;      // padded number of radial-angular channels nmax (lmax+1) when there are at most 16
+constexpr int SO3_NLP_BIG = 32;  // ... when there are more (nmax <= 4, lmax <= 6: up to 28)
+constexpr int SO3_SELFW = 192;   // stride of the (i, i)-row partial sums: 3 d <= 192
+__host__ __device__ inline int so3_nlp(int nmax, int lmax) { return nmax * (lmax + 1) <= SO3_NLP ? SO3_NLP : SO3_NLP_BIG; }
 
 // dynamic LDS layout (doubles).  Per-centre tables: NY | RI | NL constants, c_tot [NLM] cplx, Rf [NL][L] cplx
 // (c_tot folded onto m >= 0), Tf [NL][3][2][LT+1] cplx (gradient coefficients contracted with c_tot, folded onto
@@ -289,10 +292,11 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
     o.oII = off; if (stress) off += 96 * 4;   // stress only: dP sum and R (x) dP sum of the (i, i) image pairs
     o.oRS = off; if (stress) off += SO3_WAVES * 64;
     o.tri = (LT + 1) * (LT + 2) / 2;
-    o.rec = 8 + 2 * SO3_NLP + 2 * o.tri;
+    o.rec = 8 + 2 * so3_nlp(nmax, lmax) + 2 * o.tri;
     o.pc = stress ? SO3_PC : (SO3_PC < 256 / L ? SO3_PC : 256 / L);
     o.oRec = off;
-    const int area_rec = o.pc * o.rec + o.pc, area_rows = (o.pc + 1) * ne;    // records + pair->row map | row staging
+    int area_rec = o.pc * o.rec + o.pc, area_rows = (o.pc + 1) * ne;    // records + pair->row map | row staging
+    if (!stress && area_rec < 2 * SO3_SELFW) area_rec = 2 * SO3_SELFW;   // the (i, i)-row partial sums end up here
     off += stress ? o.pc * o.rec : (area_rec > area_rows ? area_rec : area_rows);
     o.oSelf = o.oRec;                         // the records are dead when the self sums are formed
     o.total = off;
@@ -305,6 +309,8 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
 template <int LC, int NM, bool STRESS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))) so3_centre_kernel(so3_args P) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    // record stride of the channel tables: a constant 16 in the instance of the usual configurations (nmax (lmax+1) <= 15)
+    const int NLP = (NM <= 3 && LC <= 5) ? SO3_NLP : so3_nlp(P.nmax, P.lmax);
     const int L = P.lmax + 1, M = 2 * P.lmax + 1, NLM = P.nmax * L * M, NL = P.nmax * L;
     const int YW = P.lmax + 3, LT = P.lmax + 1;
     const so3_lds lay = so3_layout(P.nmax, P.lmax, STRESS);
@@ -345,7 +351,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                     cheb_eval2(P.table, P.nseg, tab.NF, P.rcut, r, 2 * nl, F0, F1);
                     const double norm = sNL[nl % L] * w;                 // SO3.py:206, 221
                     rec[8 + nl] = norm * (fc * F1 + dfc * F0);
-                    rec[8 + SO3_NLP + nl] = norm * fc * F0;
+                    rec[8 + NLP + nl] = norm * fc * F0;
                 }
             }
         } else if (lane < npc) {
@@ -357,7 +363,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
             rec[0] = ux; rec[1] = uy; rec[2] = ct; rec[3] = inv_r; rec[4] = r;
             const double rho = sqrt(ux * ux + uy * uy);
             const double cphi = rho > 0.0 ? ux / rho : 1.0, sphi = rho > 0.0 ? uy / rho : 0.0;
-            cplx *Y = (cplx *)(rec + 8 + 2 * SO3_NLP);
+            cplx *Y = (cplx *)(rec + 8 + 2 * NLP);
             double cm = 1.0, sm = 0.0, pmm = 1.0;            // cos(m phi), sin(m phi), P_m^m (Condon-Shortley)
             for (int m = 0; m <= LT; m++) {
                 if (m > 0) {
@@ -401,8 +407,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
             if (mine)
                 for (int q = grp; q < npc; q += G) {
                     const double *rec = recs + q * REC;
-                    const cplx y = ((const cplx *)(rec + 8 + 2 * SO3_NLP))[l * (l + 1) / 2 + m];
-                    const double b = rec[8 + SO3_NLP + nl];
+                    const cplx y = ((const cplx *)(rec + 8 + 2 * NLP))[l * (l + 1) / 2 + m];
+                    const double b = rec[8 + NLP + nl];
                     acc.re += b * y.re; acc.im += b * y.im;
                 }
             if (nchunks > 1) __syncthreads();            // records are rebuilt by the next chunk
@@ -490,7 +496,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
         constexpr int NPI = NM * (NM + 1) / 2;
         int *sMap = (int *)(recs + PC * REC);                // [PC] row of the pair (centre-local), [PC] index in its row, max
         double *rowOut = recs;
-        const int spart = tid / ne, scol = tid - spart * ne;  // (i, i) row: column sums in two interleaved halves
+        const int nsp = 256 / ne >= 2 ? 2 : 1;                // (i, i) row: column sums, in two interleaved halves when
+        const int spart = tid / ne, scol = tid - spart * ne;  // the block has two threads per column
         double selfacc = 0.0;
         for (int c0 = p0; c0 < p1; c0 += PC) {
             const int npc = min(PC, p1 - c0), c1 = c0 + npc;
@@ -510,7 +517,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
             double outv[NPI * 3];
             if (active) {
                 const double *rec = recs + q * REC;
-                const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
+                const cplx *Y = (const cplx *)(rec + 8 + 2 * NLP);
                 double Rn[NM], Sn[NM][3];
 #pragma unroll
                 for (int n = 0; n < NM; n++) { Rn[n] = 0.0; Sn[n][0] = 0.0; Sn[n][1] = 0.0; Sn[n][2] = 0.0; }
@@ -561,7 +568,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
 #pragma unroll
                 for (int n = 0; n < NM; n++) {
                     An[n] = n < P.nmax ? rec[8 + n * L + l] : 0.0;
-                    Bn[n] = n < P.nmax ? rec[8 + SO3_NLP + n * L + l] * inv_r : 0.0;
+                    Bn[n] = n < P.nmax ? rec[8 + NLP + n * L + l] * inv_r : 0.0;
                 }
 #pragma unroll
                 for (int n1 = 0; n1 < NM; n1++)
@@ -601,14 +608,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 double *o = P.dxdr + (size_t)(r0 + rowb) * ne + f;
                 *o = (cont && rl == 0) ? *o + rowOut[f] : rowOut[f];
             }
-            if (spart < 2)
-                for (int rl = spart; rl < nrows_c; rl += 2)
+            if (spart < nsp)
+                for (int rl = spart; rl < nrows_c; rl += nsp)
                     if (r0 + rowb + rl != rself) selfacc += rowOut[rl * ne + scol];
             __syncthreads();                                  // row buffer consumed (the next chunk rebuilds the records)
         }
-        if (spart < 2) sSelf[spart * 96 + scol] = selfacc;
+        if (spart < nsp) sSelf[spart * SO3_SELFW + scol] = selfacc;
         __syncthreads();
-        for (int e = tid; e < ne; e += 256) P.dxdr[(size_t)rself * ne + e] = -(sSelf[e] + sSelf[96 + e]);
+        for (int e = tid; e < ne; e += 256) P.dxdr[(size_t)rself * ne + e] = -(sSelf[e] + (nsp == 2 ? sSelf[SO3_SELFW + e] : 0.0));
     } else {
         int t_nl = 0, t_k = -1;                       // task of this lane: k = -1 -> R, 0..2 -> S
         if (lane < NL) t_nl = lane;
@@ -657,7 +664,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 double rs[2][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};       // sum over pairs of R_j[a] * dP[c, k]
                 for (int p = a; p < b; p++) {
                     const double *rec = recs + (p - c0) * REC;
-                    const cplx *Y = (const cplx *)(rec + 8 + 2 * SO3_NLP);
+                    const cplx *Y = (const cplx *)(rec + 8 + 2 * NLP);
                     if (has_task) {
                         // one code path for R and S lanes: two fixed-length, predicated segments Re[Y conj(c)]; every LDS
                         // load of the task is issued before the first add
@@ -676,7 +683,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                     for (int rnd = 0; rnd < 2; rnd++) {
                         if (lane + 64 * rnd < ne) {
                             const int a1 = iA1[rnd], a2 = iA2[rnd], k = e_k[rnd];
-                            const double *A = rec + 8, *B = rec + 8 + SO3_NLP;
+                            const double *A = rec + 8, *B = rec + 8 + NLP;
                             const double term = rec[k] * (A[a1] * sR[a2] + A[a2] * sR[a1]) + B[a1] * sS[a2 * 3 + k] + B[a2] * sS[a1 * 3 + k];
                             s[rnd] += term;
                             if (stress) {                       // R_j = R_i + r u (SO3.py:225-226, 254)
@@ -734,11 +741,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
 }
 
 int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char *who) {
-    const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1, M = 2 * lmax + 1;
-    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > 4 || nq > SO3_NQCAP || nmax * L > 16 || d * 3 > 96 ||
-        nmax * L * M > 192 || nseg < 1 || ncheb != SO3_NCHEB) {
+    const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1;
+    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > 4 || nq > SO3_NQCAP || nmax * L > so3_nlp(nmax, lmax) ||
+        d * 3 > SO3_SELFW || nmax * L * (L + 1) / 2 > 256 || nseg < 1 || ncheb != SO3_NCHEB) {
         gpr_set_error("%s: (nmax=%d, lmax=%d, nq=%d, nseg=%d, ncheb=%d) outside this build's limits "
-                      "(nmax <= 4, lmax <= %d, nq <= %d, nmax (lmax+1) <= 16, ncoef <= 32, ncheb == %d)",
+                      "(nmax <= 4, lmax <= %d, nq <= %d, ncoef <= 64, ncheb == %d)",
                       who, nmax, lmax, nq, nseg, ncheb, SO3_LCAP - 1, SO3_NQCAP, SO3_NCHEB);
         return GPR_ERR_UNSUPPORTED;
     }
@@ -819,6 +826,10 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(!rdxdr || (positions && inv_vol), "gpr_so3_power_spectrum_stress: rdxdr needs positions and inv_vol");
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1);
+    if (rdxdr && (nmax * (lmax + 1) > 16 || d * 3 > 96)) {     // the stress rows keep the narrower lane layout
+        gpr_set_error("gpr_so3_power_spectrum_stress: stress rows need nmax (lmax + 1) <= 16 and ncoef <= 32 (nmax=%d, lmax=%d)", nmax, lmax);
+        return GPR_ERR_UNSUPPORTED;
+    }
     int rc = so3_check_limits(nmax, lmax, 1, nseg, ncheb, "gpr_so3_power_spectrum");
     if (rc) return rc;
     if (ncentres <= 0) return GPR_OK;

@@ -76,6 +76,11 @@ def structures():
                                 pbc=[False] * 3, nmax=3, lmax=4, rcut=5.0, alpha=2.0, stress=False)
     out["cluster_n2l3"] = dict(numbers=[46, 8, 12, 8, 46, 12], positions=clu, cell=np.zeros((3, 3)),
                                pbc=[False] * 3, nmax=2, lmax=3, rcut=4.0, alpha=1.5, stress=False)
+    # nmax = 4, lmax = 4: ncoef = 50 (beyond the 32-column operand plane of the usual configuration)
+    out["cluster_n4l4"] = dict(numbers=[46, 8, 12, 8, 46, 12], positions=clu, cell=np.zeros((3, 3)),
+                               pbc=[False] * 3, nmax=4, lmax=4, rcut=4.0, alpha=2.0, stress=False)
+    out["fcc4_n4l4"] = dict(numbers=[46, 78, 46, 46], positions=fcc + np.random.default_rng(5).normal(0, 0.1, (4, 3)),
+                            cell=np.eye(3) * a, pbc=[True] * 3, nmax=4, lmax=4, rcut=5.0, alpha=2.0, stress=False)
     # sheared periodic cell, two species
     cell = np.array([[4.2, 0, 0], [1.3, 3.9, 0], [0.4, 0.7, 4.4]])
     out["triclinic_mgo"] = dict(numbers=[12, 8, 12, 8], positions=rng.uniform(0, 1, (4, 3)) @ cell, cell=cell,

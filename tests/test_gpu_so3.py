@@ -178,9 +178,26 @@ def test_so3_other_configurations_match_oracle(cfg):
         out = des.calculate(s)
         ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, nmax, lmax, rcut, alpha, stress=stress)
         assert np.array_equal(out["seq"], ref["seq"])
-        assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL
+        assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL, (stress, rel(out["x"], ref["x"]), rel(out["dxdr"], ref["dxdr"]))
         if stress:
             assert rel(out["rdxdr"], ref["rdxdr"]) < REL
+
+
+@pytest.mark.parametrize("cfg", [(4, 4, 4.0, 2.0), (3, 6, 4.2, 1.5), (4, 5, 4.0, 2.0), (4, 3, 5.0, 2.0)],
+                         ids=["n4l4_d50", "n3l6_d42", "n4l5_d60", "n4l3_d40"])
+def test_so3_long_descriptors_match_oracle(cfg):
+    """more than 32 power-spectrum components (up to 64) and more than 16 radial-angular channels (up to 28): the wider
+    record layout of the general kernel instance, periodic cell; the reference's own SO3 pins the (4, 4) case through
+    tests/golden/so3_*_n4l4.npz"""
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.synthetic import fcc_cell
+    from oracle.so3_numpy import so3_calculate
+    nmax, lmax, rcut, alpha = cfg
+    s = fcc_cell(seed=4, reps=1 if rcut < 5 else 2, species=(46, 78), sigma=0.1)
+    out = SO3(nmax=nmax, lmax=lmax, rcut=rcut, alpha=alpha).calculate(s)
+    ref = so3_calculate(s.numbers, s.positions, s.cell, s.pbc, nmax, lmax, rcut, alpha)
+    assert out["x"].shape[1] == nmax * (nmax + 1) // 2 * (lmax + 1) and np.array_equal(out["seq"], ref["seq"])
+    assert rel(out["x"], ref["x"]) < REL and rel(out["dxdr"], ref["dxdr"]) < REL, (rel(out["x"], ref["x"]), rel(out["dxdr"], ref["dxdr"]))
 
 
 def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
@@ -200,4 +217,59 @@ def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
     nod = SO3(nmax=3, lmax=4, rcut=5.0, derivative=False).calculate(a)
     assert nod["dxdr"] is None and nod["rdxdr"] is None and "seq" not in nod and np.array_equal(nod["x"], full["x"])
     with pytest.raises(NotImplementedError):
-        SO3(nmax=4, lmax=4, rcut=5.0)             # ncoef = 50: beyond the device kernels, said at construction
+        SO3(nmax=4, lmax=6, rcut=5.0)             # ncoef = 70: beyond the device kernels, said at construction
+    assert SO3(nmax=4, lmax=4, rcut=5.0).ncoefs == 50
+
+
+def test_gp_end_to_end_with_a_50_component_descriptor(port_natives):
+    """SO3(nmax=4, lmax=4) -> 64-column operand planes of the covariance kernels -> fit -> predict, against the oracle
+    (numpy descriptor + plain-C natives + scipy) on the same structures; RBF and Dot (pair route: the degree-2 feature map
+    covers 32 columns)"""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    from gpr_calculator_amd.neighbors import symbol_of
+    from gpr_calculator_amd.utilities import species_numbers
+    from oracle import gp_numpy as og
+    from oracle.so3_numpy import so3_calculate
+    strucs = [fcc_cell(seed=s, reps=1, species=(46, 78), sigma=0.08) for s in range(3)]
+    labels = [lj_energy_forces(a) for a in strucs]
+    test = fcc_cell(seed=9, reps=1, species=(46, 78), sigma=0.08)
+
+    def odesc(a):
+        d = so3_calculate(a.numbers, a.positions, a.cell, a.pbc, 4, 4, 5.0, 2.0)
+        return d, species_numbers([symbol_of(z) for z in a.numbers])
+    for kern, okern in ((RBF_mb(para=[2.5, 1.3], zeta=2.0), og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=port_natives)),
+                        (Dot_mb(para=[2.0, 2.0], zeta=2.0), og.OracleDot(para=(2.0, 2.0), zeta=2.0, natives=port_natives))):
+        gp = GP(kernel=kern, descriptor=SO3(nmax=4, lmax=4, rcut=5.0), noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+        gp.fit(gp.points_from_structures([(a, E, F, True, [0, 2]) for a, (E, F) in zip(strucs, labels)]), show=False, opt=False)
+        assert gp.train_x["force"][0].shape[1] == 50
+        energy, force, y = [], [], []
+        for a, (E, F) in zip(strucs, labels):
+            d, ele = odesc(a)
+            energy.append((d["x"], ele)); y.append(E / len(a))
+        yF = []
+        for a, (E, F) in zip(strucs, labels):
+            d, ele = odesc(a)
+            for at in (0, 2):
+                ids = np.flatnonzero(d["seq"][:, 1] == at)
+                ci = d["seq"][ids, 0]
+                force.append((d["x"][ci], d["dxdr"][ids], ele[ci])); yF.append(F[at])
+        tx = {"energy": og.list_to_tuple(energy, mode="energy"), "force": og.list_to_tuple(force)}
+        yv = np.concatenate((np.array(y), np.array(yF).reshape(-1))).reshape(-1, 1)
+        K = okern.k_total(tx)
+        assert rel(gp.kernel.k_total(gp.train_x), K) < 1e-10
+        L, alpha, K_inv = og.fit_core(K, yv, 3, 0.002, 0.1)
+        d, ele = odesc(test)
+        data = {"energy": og.list_to_tuple([(d["x"], ele)], mode="energy"), "force": []}
+        for at in range(len(test)):
+            ids = np.flatnonzero(d["seq"][:, 1] == at)
+            ci = d["seq"][ids, 0]
+            data["force"].append((d["x"][ci], d["dxdr"][ids], ele[ci]))
+        Kt = okern.k_total(data, tx, 1e-12) if kern.name == "RBF" else okern.k_total(data, tx)
+        mean = Kt.dot(alpha)[:, 0]
+        E, F, _, E_std, F_std = gp.predict_structure(test, stress=False, return_std=True, f_tol=1e-12)
+        assert abs(E - mean[0] * len(test)) < 1e-6 and np.abs(F - mean[1:].reshape(-1, 3)).max() < 1e-5
+        assert np.isfinite(E_std) and np.isfinite(F_std).all()
