@@ -124,19 +124,31 @@ def fit_mode(args, comm, gp, dev):
         N = len(gp.y_train)
         R = len(gp.train_x["force"][0])
         head = "weight_space" if "weight_space" in results else "dense"
-        pairs = 0.5 * float(R) * R
+        tE = gp.train_x["force"][2]
+        pairs = 0.5 * same_species_pairs(tE, tE)
+        F = gp.kernel.feature_dim(gp.train_x) if args.kernel == "Dot" else None
+        # algorithmic flop of each route (per fit, all ranks together)
+        flop = {"dense": (pairs * FLOP_PER_PAIR_FF if F is None else float(N) * N * F) + N ** 3 / 3.0}
+        unit = {"dense": ("1.10 kflop per same-species row pair of the lower triangle" if F is None else
+                          "N^2 F (lower triangle of Psi Psi^T on the matrix cores)") + " + N^3 / 3 (Cholesky), all ranks"}
+        if "weight_space" in results:
+            flop["weight_space"] = float(N) * F * (F + 1) + F ** 3 / 3.0 + F ** 3 / 3.0
+            unit["weight_space"] = "N F (F + 1) (Gram matrix Psi^T D Psi and right-hand side) + F^3 / 3 (Cholesky) + F^3 / 3 (triangular inverse)"
+        roof = {r: {"ms": results[r], "flop": flop[r], "achieved": flop[r] / (results[r] * 1e-3) / 1e12 / world,
+                    "frac": flop[r] / (results[r] * 1e-3) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS, "work_unit": unit[r]} for r in results}
         line = {"metric": "GPR fit ms at N_train=%d" % args.n_train, "value": results[head], "unit": "ms", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": results[head], "higher_is_better": False,
                 "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"fit(opt=False) of the cfg3-shaped training set: N_train={args.n_train} force environments "
                                        f"(N={N}, {R} force rows), {args.kernel} kernel", "kernel": args.kernel, "N": N,
-                           "fit_ms": results, "parallelism": f"training points sharded x{world}: row slabs + all-gather"
-                                                             f"{'; block-cyclic Cholesky' if world > 1 and N >= gp.dist_chol_min_n else ''}"},
-                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS,
-                             "achieved": (pairs * FLOP_PER_PAIR_FF + N ** 3 / 3.0) / (results["dense"] * 1e-3) / 1e12 / world,
-                             "frac": (pairs * FLOP_PER_PAIR_FF + N ** 3 / 3.0) / (results["dense"] * 1e-3) / 1e12 / world / FP64_MFMA_PEAK_TFLOPS,
-                             "traffic": None, "kernel": "dense fit: kblock_kernel<FF> (lower triangle of the force-force block) + Cholesky",
-                             "work_unit": "1.10 kflop per row pair of the lower triangle + N^3 / 3, per GPU"},
+                           "route": head, "fit_ms": results,
+                           "parallelism": f"training points sharded x{world}: row slabs + all-gather"
+                                          f"{'; block-cyclic Cholesky' if world > 1 and N >= gp.dist_chol_min_n else ''}"
+                                          + ("; weight space: feature rows sharded, all-reduce of the F x F system" if head == "weight_space" else "")},
+                "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": FP64_MFMA_PEAK_TFLOPS, "achieved": roof[head]["achieved"],
+                             "frac": roof[head]["frac"], "traffic": None,
+                             "kernel": f"whole fit on the {head} route (wall time of fit(), not one kernel: launches, host work "
+                                       f"and collectives included)", "work_unit": unit[head], "routes": roof},
                 "cpu_baseline": None}
         print(json.dumps(line))
 

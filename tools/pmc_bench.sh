@@ -21,7 +21,8 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     agg, cnt = collections.defaultdict(float), collections.Counter()
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != c: continue
-        k = r["Kernel_Name"]
+        g = r.get("Grid_Size") or str(int(r.get("Grid_Size_X", 0) or 0) * int(r.get("Grid_Size_Y", 1) or 1) * int(r.get("Grid_Size_Z", 1) or 1))
+        k = (r["Kernel_Name"], int(g))
         agg[k] += float(r["Counter_Value"]); cnt[k] += 1
     for k in agg: res[k][c] = (agg[k], cnt[k])
 rows = []
@@ -30,8 +31,8 @@ for k, v in res.items():
     rows.append((f + w, k, f / max(nf, 1), w / max(nw, 1), nf))
 rows.sort(reverse=True)
 with open(f"{out}/traffic_summary.csv", "w") as fh:
-    fh.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch\n")
-    for _, k, f, w, n in rows[:25]:
-        fh.write(f"\"{k[:120]}\",{n},{f:.1f},{w:.1f}\n")
-        print(f"{k[:70]:70s} n={n:4d} fetch/launch={f:12.1f} KB write/launch={w:12.1f} KB")
+    fh.write("kernel,grid_threads,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch\n")
+    for _, (k, g), f, w, n in rows[:40]:
+        fh.write(f"\"{k[:120]}\",{g},{n},{f:.1f},{w:.1f}\n")
+        print(f"{k[:60]:60s} grid={g:9d} n={n:4d} fetch/launch={f:12.1f} KB write/launch={w:12.1f} KB")
 PY
