@@ -85,10 +85,27 @@ __device__ __forceinline__ int chol16_inv(double (&v)[16]) {
 constexpr int TWAVES = DWAVES - 3;                  // 9 tile wavefronts
 constexpr int TSLOTS = (NTILE + TWAVES - 1) / TWAVES;   // 16 tiles per wavefront at most
 
+// ---- hand-over of the operand tiles between two kernels that run AT THE SAME TIME (the diagonal block and the first
+// rows of its panel, gpr_potrf_lower_dinv): the producer stores tiles with agent-scope atomic stores (they go through
+// to where the other XCDs' loads see them, no cache write-back needed), waits for its own stores (vmcnt) before the
+// stage's barrier, and one lane then raises a counter; the consumer polls the counter and reads with agent-scope
+// atomic loads.  `seq` grows by one per diagonal block for the life of the process; the counter holds seq * 32 + stages done.
+__device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+constexpr int PIPE_MAX_POLLS = 1 << 20;                  // ~1 s: a consumer whose producer never ran gives up instead of hanging the GPU
+
+// TRACE: debug instance (tools/potrf_stage_trace.py) that stamps the phases of every stage with the 100 MHz clock
+// PUB:   the operand tiles are published stage by stage through `flag` (see above)
+__device__ long long *g_diag_trace = nullptr;
+template <bool TRACE, bool PUB>
 __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__restrict__ a, long long lda, int kb, int k0,
                                                              int *info, double *__restrict__ wop,
-                                                             double *__restrict__ lop) {
+                                                             double *__restrict__ lop, int *flag, int base) {
     __shared__ diag_lds S;
+    auto stamp = [&](int who, int k, int slot) {
+        if (TRACE && (threadIdx.x & 63) == 0) g_diag_trace[(who * 16 + k) * 8 + slot] = wall_clock64();
+    };
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
@@ -96,19 +113,26 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
         __builtin_amdgcn_s_setprio(3);
         for (int k = 0; k < nt; k++) {
             __syncthreads();                                 // B1: tile (k, k), row-major, in S.dg
+            stamp(0, k, 0);
             double v[16];
             const bool wl = (lane & 48) == 16;               // lanes 16..31: columns of W
 #pragma unroll
             for (int c = 0; c < 16; c++) v[c] = wl ? ((c == lr) ? 1.0 : 0.0) : S.dg[lr][c];
             const int bad = chol16_inv(v);
+            stamp(0, k, 1);
             if (bad && lane == 0 && info) atomicCAS(info, 0, k0 + k * DT + bad);
             if (wl) {                                        // W[r][c = lr] straight into operand order:
 #pragma unroll                                               //   (q, lane') = W[lane' & 15][(lane' >> 4) + 4 q]
                 for (int r = 0; r < 16; r++) S.wt[(lr >> 2) * 64 + 16 * (lr & 3) + r] = v[r];
             }
+            stamp(0, k, 2);
             __syncthreads();                                 // B2: W_k in S.wt
+            stamp(0, k, 3);
 #pragma unroll
-            for (int q = 0; q < 4; q++) wop[(size_t)k * TILE_DOUBLES + q * 64 + lane] = S.wt[q * 64 + lane];
+            for (int q = 0; q < 4; q++) {
+                if (PUB) coherent_store(&wop[(size_t)k * TILE_DOUBLES + q * 64 + lane], S.wt[q * 64 + lane]);
+                else wop[(size_t)k * TILE_DOUBLES + q * 64 + lane] = S.wt[q * 64 + lane];
+            }
             if (lane < 16) {                                 // L_kk to global, zeros above the diagonal
                 const int row = k * DT + lr;
 #pragma unroll
@@ -117,15 +141,25 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
                     if (row < kb && col < kb) a[(long long)row * lda + col] = (c <= lr) ? v[c] : 0.0;
                 }
             }
+            stamp(0, k, 4);
+            if (PUB) wait_own_stores();                      // W_k is out before B3 (this wavefront is early there anyway)
             __syncthreads();                                 // B3
+            stamp(0, k, 5);
         }
         return;
     }
     if (wave == 4 || wave == 8) {
-        for (int k = 0; k < nt; k++) { __syncthreads(); __syncthreads(); __syncthreads(); }
+        // the publisher: after B1 of stage k every store of stage k - 1 has been waited for by the wavefront that issued it
+        for (int k = 0; k < nt; k++) {
+            __syncthreads();
+            if (PUB && wave == 4 && lane == 0 && k > 0) __hip_atomic_store(flag, base + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads(); __syncthreads();
+        }
+        if (PUB && wave == 4 && lane == 0) __hip_atomic_store(flag, base + nt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
     const int tw = wave - 1 - (wave > 4) - (wave > 8);      // 0..8
+    __builtin_amdgcn_s_setprio(2);
     // ---- tile wavefronts.  Register tiles, transposed storage: reg r of lane l = A[16 i + (l & 15)][16 j + (l >> 4) + 4 r]
     d4 acc[TSLOTS];
     int tij[TSLOTS];                                         // i | j << 8, or -1
@@ -164,7 +198,10 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
     };
     hand_over_diag(0);
     for (int k = 0; k < nt; k++) {
+        if (tw == 0) stamp(1, k, 0);
+        if (PUB) wait_own_stores();                          // the L tiles of stage k - 1 (issued a trailing update ago)
         __syncthreads();                                     // B1
+        if (tw == 0) stamp(1, k, 1);
         if (k > 0) {                                         // rest of the trailing update of stage k - 1
 #pragma unroll
             for (int s = 0; s < TSLOTS; s++) {
@@ -172,7 +209,9 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
                 if (v >= 0 && (v >> 8) > k - 1 && v != (k | (k << 8))) update(s, v);
             }
         }
+        if (tw == 0) stamp(1, k, 2);
         __syncthreads();                                     // B2
+        if (tw == 0) stamp(1, k, 3);
         // panel tiles (i, k), i > k:  X^T = W A_ik^T  (A operand W from LDS, B operand = the register tile)
 #pragma unroll
         for (int s = 0; s < TSLOTS; s++) {
@@ -187,13 +226,16 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     S.lt[ti][r * 64 + lane] = d[r];          // register tile == operand order
-                    lop[(size_t)tile_index(ti, k) * TILE_DOUBLES + r * 64 + lane] = d[r];
+                    if (PUB) coherent_store(&lop[(size_t)tile_index(ti, k) * TILE_DOUBLES + r * 64 + lane], d[r]);
+                    else lop[(size_t)tile_index(ti, k) * TILE_DOUBLES + r * 64 + lane] = d[r];
                     const int col = k * DT + lq + 4 * r;
                     if (row < kb && col < kb) a[(long long)row * lda + col] = d[r];
                 }
             }
         }
+        if (tw == 0) stamp(1, k, 4);
         __syncthreads();                                     // B3
+        if (tw == 0) stamp(1, k, 5);
         if (k + 1 < nt) {                                    // next diagonal tile first, so that its factor can start
 #pragma unroll
             for (int s = 0; s < TSLOTS; s++) {
@@ -211,10 +253,13 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
 // through LDS in B-operand order (= the accumulator layout it is produced in).  The operand tiles of a stage (W_k and
 // L_jk, j > k) are staged through LDS, stage k + 1 loading while stage k computes.
 // FULL: kb == 256, every bound on the column tiles is a compile-time constant (the guarded form branches per tile).
-template <bool FULL>
+// PIPE: the diagonal block is being factored by another kernel right now; stage k may read the tiles of stage k once the
+// counter says so (see coherent_store above); the prefetch of stage k + 1 waits for that stage, so the slab runs two
+// stages behind the factorisation at most.
+template <bool FULL, bool PIPE>
 __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb_,
                                                               const double *__restrict__ wop,
-                                                              const double *__restrict__ lop) {
+                                                              const double *__restrict__ lop, const int *flag, int base, int *info) {
     __shared__ double ops[2][16 * TILE_DOUBLES];             // [buffer][slot = j - k][operand order]; slot 0 = W_k
     __shared__ double xk[2][TILE_DOUBLES];                   // X_k^T of the stage, B-operand order
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -223,6 +268,7 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
     const int nt = FULL ? 16 : (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
     const bool rok = r0 + lr < rows;
+    __builtin_amdgcn_s_setprio(2);                           // a link of the sequential chain: ahead of the bulk updates on its SIMD
     d4 t[4];                                                 // column tiles wave, wave + 4, wave + 8, wave + 12
 #pragma unroll
     for (int c = 0; c < 4; c++) {
@@ -234,16 +280,36 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
     }
     // tile u of stage k: u = 0 -> W_k, u >= 1 -> L_{k+u, k}
     auto src = [&](int k, int u) { return u == 0 ? wop + (size_t)k * TILE_DOUBLES : lop + (size_t)tile_index(k + u, k) * TILE_DOUBLES; };
-    for (int u = 0; u < nt; u++) ops[0][u * TILE_DOUBLES + tid] = src(0, u)[tid];
+    auto tile_elem = [&](int k, int u) { return PIPE ? coherent_load(src(k, u) + tid) : src(k, u)[tid]; };
+    __shared__ int gave_up;
+    auto await_stages = [&](int done) {                      // until `done` stages of the diagonal block are published
+        if (!PIPE) return;
+        if (tid == 0) {
+            int polls = 0;
+            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (base + done)) < 0 && polls < PIPE_MAX_POLLS) {
+                __builtin_amdgcn_s_sleep(4);
+                polls++;
+            }
+            gave_up = polls >= PIPE_MAX_POLLS;
+        }
+        __syncthreads();
+    };
+    await_stages(nt < 2 ? nt : 2);
+    if (PIPE && gave_up) { if (tid == 0 && info) atomicExch(info, -1); return; }
+    for (int u = 0; u < nt; u++) ops[0][u * TILE_DOUBLES + tid] = tile_elem(0, u);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 16; k++) {
         if (k < nt) {
+            if (PIPE && k > 0) {
+                await_stages(k + 2 < nt ? k + 2 : nt);
+                if (gave_up) { if (tid == 0 && info) atomicExch(info, -1); return; }
+            }
             const double *cur = ops[k & 1];
             double pf[15];
 #pragma unroll
             for (int u = 0; u < 15 - k; u++)                 // stage k + 1 has nt - k - 1 tiles
-                if (k + 1 + u < nt) pf[u] = src(k + 1, u)[tid];
+                if (k + 1 + u < nt) pf[u] = tile_elem(k + 1, u);
             if (wave == (k & 3)) {                           // X_k^T = W_k P_k^T
                 d4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -310,6 +376,65 @@ __global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict_
     for (int i = 0; i < 64; i++) out[i * 64 + c] = (i < kb && c < kb && i >= c) ? acc[i] : 0.0;
 }
 
+// Narrow trailing updates of the look-ahead, C[m x n] -= A[m x 256] B[n x 256]^T (n <= 256; A, B rows of the panel just
+// solved).  Both operands are stored with k contiguous, so a lane loads 4 consecutive k of ONE row straight into operand
+// registers (lane (r, q) takes k0 + 4 q .. + 3 and feeds them to four consecutive v_mfma_f64_16x16x4: the k order inside
+// a 16-chunk is permuted, identically for A and B).  No operand staging through LDS and no k loop to pipeline: a
+// workgroup owns a 32 x 32 tile of C and its four wavefronts take a quarter of k each (64 = four chunks, all of whose
+// loads are issued before the first MFMA, so the memory latency is paid once), then add their partial tiles through LDS.
+// The product is only 256 deep: a tiled GEMM spends its time filling and draining its pipeline (the 64 x 64-tile kernel
+// took 50 us for this shape whatever m; one wavefront per 32 x 32 tile running over all of k took 19 us).
+typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
+__global__ void __launch_bounds__(256) syrk_narrow_kernel(int m, int n, const double *__restrict__ A, long long lda,
+                                                           const double *__restrict__ B, long long ldb,
+                                                           double *__restrict__ C, long long ldc, int lower_only) {
+    __shared__ double part[4][4][256];                       // [wave][tile][reg * 64 + lane]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
+    if (lower_only && col0 > row0 + 31) return;              // tile strictly above the diagonal of C
+    __builtin_amdgcn_s_setprio(2);                           // a link of the sequential chain: ahead of the bulk updates on its SIMD
+    const int k0 = wave * 64 + 4 * q;
+    const double *a0 = A + (long long)min(row0 + r, m - 1) * lda + k0;
+    const double *a1 = A + (long long)min(row0 + 16 + r, m - 1) * lda + k0;
+    const double *b0 = B + (long long)min(col0 + r, n - 1) * ldb + k0;
+    const double *b1 = B + (long long)min(col0 + 16 + r, n - 1) * ldb + k0;
+    d4 xa[4][2], xb[4][2];                                   // [chunk][tile]
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        xa[c][0] = *(const d4u *)(a0 + 16 * c); xa[c][1] = *(const d4u *)(a1 + 16 * c);
+        xb[c][0] = *(const d4u *)(b0 + 16 * c); xb[c][1] = *(const d4u *)(b1 + 16 * c);
+    }
+    d4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int s = 0; s < 4; s++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[c][i][s], xb[c][j][s], acc[i][j], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) part[wave][2 * i + j][e * 64 + lane] = acc[i][j][e];
+    __syncthreads();
+    const int ti = wave >> 1, tj = wave & 1;                 // wavefront w finishes tile w
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        const int gm = row0 + 16 * ti + q + 4 * e, gn = col0 + 16 * tj + r;
+        const double v = (part[0][wave][e * 64 + lane] + part[1][wave][e * 64 + lane]) + (part[2][wave][e * 64 + lane] + part[3][wave][e * 64 + lane]);
+        if (gm < m && gn < n) C[(long long)gm * ldc + gn] -= v;
+    }
+}
+
 __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
     const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
     if (j < n && j > i) a[(long long)i * lda + j] = 0.0;
@@ -318,6 +443,7 @@ __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
 }  // namespace
 
 #include <cstdlib>
+#include <mutex>
 #define LAUNCH_CHECK(name)                                                                   \
     do { hipError_t _e = hipGetLastError();                                                  \
          if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
@@ -325,15 +451,20 @@ __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
 // second stream + events of the look-ahead (one set per process; the factorisation is not re-entrant anyway: it owns
 // the scratch of the diagonal kernel for the duration of the call)
 struct lookahead_ctx {
-    hipStream_t side = nullptr;
+    hipStream_t side = nullptr, mid = nullptr;
     std::vector<hipEvent_t> ev;
     size_t next = 0;
+    int *flag = nullptr;                 // stages published by the diagonal-block kernel in flight (see coherent_store)
+    unsigned seq = 0;                    // diagonal blocks launched so far
+    std::mutex mu;                       // one factorisation with look-ahead at a time per process
     int init() {
         if (side) return GPR_OK;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
-        ev.resize(128);
+        if (hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; return GPR_ERR_HIP; }
+        if (hipMalloc((void **)&flag, sizeof(int)) != hipSuccess || hipMemset(flag, 0, sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
+        ev.resize(256);
         for (auto &e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GPR_ERR_HIP;
         return GPR_OK;
@@ -342,65 +473,100 @@ struct lookahead_ctx {
 };
 static lookahead_ctx g_la;
 
-// Right-looking, 256 columns per step, with look-ahead: the caller's stream carries the sequential chain
-//   diag(K) -> panel(K) -> update of column block K + 1 by panel K                      (narrow, k = 256)
-// and a side stream the bulk of the trailing update by panel K, column block K + 2 first and the rest after it, so
-// that the chain of step K + 1 runs while the matrix cores are still busy with step K.  Who waits for whom:
-//   side:   bulk(K) after panel(K)                                  [event P_K recorded on the main stream]
-//   main:   the narrow update of step K + 1 (it writes column block K + 2) after bulk(K)'s first part [event B_K]
-//   main:   the end of the call after the last bulk update
-// The two narrow products run on 64 x 64 tiles (a 128 x 128 tile at k = 256 takes ~60 us however few there are).
-// Measured at N = 6063: 5.5 ms against 6.0 ms on one stream; updating every second step with two panels at once
-// (k = 512, half the read-modify-write traffic of the trailing matrix) was slower, 6.3 ms: the narrow products in
-// between cost more than the wider one saves.
-// Everything else is ordered by the streams themselves: bulk(K) reads column block K only, which the main stream
-// never touches again; diag / panel of step K + 1 touch column block K + 1 only, which no bulk update still writes.
+static void launch_panel(hipStream_t st, double *p, long long lda, int rows, int kb, const double *wop, const double *lop) {
+    if (kb == DB) hipLaunchKernelGGL((potrf_panel256_kernel<true, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr);
+    else hipLaunchKernelGGL((potrf_panel256_kernel<false, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr);
+}
+// C[m x n] -= A[m x 256] B[n x 256]^T
+static void launch_narrow(hipStream_t st, int m, int n, const double *A, const double *B, double *C, long long lda, int lower_only) {
+    hipLaunchKernelGGL(syrk_narrow_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, st, m, n, A, lda, B, lda, C, lda, lower_only);
+}
+
+// Right-looking, 256 columns per step, with look-ahead over three streams.  With D_K the diagonal block, P_K the panel
+// below it (its first 256 rows = "top": the rows of block K + 1) and U_K(J) the update of column block J by P_K:
+//   main (the caller's stream), the sequential chain:   D_K -> U_K(K + 1) top [= the next diagonal block]
+//   mid  (urgent):   P_K top, running WHILE D_K runs, two stages behind it (operand tiles handed over through
+//                    coherent stores and a counter) -> P_K rest -> U_K(K + 1) rest     [what the next panel needs]
+//   side (lowest):   U_K(K + 2) -> U_K(K + 3 ...)         the bulk of the flops (gemm128), beside the chain of step K + 1
+// Who waits for whom across streams (events):
+//   main U_K(K + 1) top      after  mid P_K top, and after side U_{K-1}(K + 1)
+//   mid  U_K(K + 1) rest     after  side U_{K-1}(K + 1)
+//   side U_K(K + 2)          after  mid U_K(K + 1) rest   (all of P_K is there)
+//   D_{K+2} re-uses the operand-tile buffer of D_K: its readers (P_K top, P_K rest) precede P_{K+1} top on mid, which main
+//   has waited for by then.
+// D_K is always enqueued before the P_K top that polls its counter, and depends on nothing enqueued after it, so the
+// polling kernel cannot starve its producer; if the producer never runs (a failed launch) the consumer gives up after
+// PIPE_MAX_POLLS and reports info = -1.
+// The narrow updates (n <= 256, k = 256) run on syrk_narrow_kernel, operands straight from global memory.
+// N = 6063: 14 ms (round 1: 64-wide steps) -> 5.4 ms (256-wide steps, two streams, tiled narrow GEMMs) -> 4.5 ms
+// (syrk_narrow_kernel) -> see DESIGN.md for the current figure.
 extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
     if (n == 0) return GPR_OK;
     if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
+    const size_t ops_doubles = (size_t)(16 + NTILE) * TILE_DOUBLES;
     void *scratch;
-    int rc = gpr_dev_alloc(&scratch, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double), st);
+    int rc = gpr_dev_alloc(&scratch, 2 * ops_doubles * sizeof(double), st);
     if (rc) return rc;
-    double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES;
+    std::unique_lock<std::mutex> lock(g_la.mu);
     const bool la = n > 3 * DB && !getenv("GPR_POTRF_NO_LOOKAHEAD") && g_la.init() == GPR_OK;
-    hipEvent_t bulk_first = nullptr, bulk_last = nullptr;       // B_{K-1}; the last event of the side stream
+    if (!la) lock.unlock();
+    const bool pipe = la && !getenv("GPR_POTRF_NO_PIPE");
+    hipEvent_t bulk_first = nullptr, bulk_last = nullptr, mid_last = nullptr;
     auto at = [&](int r, int c) { return a + (long long)r * lda + c; };
-    for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
+    int step = 0;
+    for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB, step++) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
-        hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop);
+        double *wop = (double *)scratch + (size_t)(step & 1) * ops_doubles, *lop = wop + 16 * TILE_DOUBLES;
         const int c1 = K0 + KB, R = n - c1;                      // first row / column after the block
+        const bool piped = pipe && R > 0 && KB == DB;
+        const int base = (int)(++g_la.seq * 32u);
+        if (piped) hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop, g_la.flag, base);
+        else hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop, (int *)nullptr, 0);
         if (R <= 0) break;
         double *p = at(c1, K0);
-        if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
-        else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((R + DT - 1) / DT), dim3(256), 0, st, p, lda, R, KB, wop, lop);
         if (!la) {
+            launch_panel(st, p, lda, R, KB, wop, lop);
             rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, at(c1, c1), lda, 1);
             continue;
         }
-        // narrow update: column block K + 1 (it was last written by the first part of bulk(K - 1))
-        const int KB1 = (n - c1 < DB) ? n - c1 : DB;
+        const int KB1 = (R < DB) ? R : DB, c2 = c1 + KB1, Rrest = n - c2;
+        if (piped) {                                                                           // P_K top beside D_K
+            hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
+                               (const int *)g_la.flag, base, info_dev);
+        } else {
+            hipEvent_t dk = g_la.take();
+            GPR_HIP_TRY(hipEventRecord(dk, st));
+            GPR_HIP_TRY(hipStreamWaitEvent(g_la.mid, dk, 0));
+            launch_panel(g_la.mid, p, lda, KB1, KB, wop, lop);
+        }
+        hipEvent_t top = g_la.take();
+        GPR_HIP_TRY(hipEventRecord(top, g_la.mid));
+        GPR_HIP_TRY(hipStreamWaitEvent(st, top, 0));
         if (bulk_first) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_first, 0));
-        rc = gpr_gemm_internal(st, 0, 1, R, KB1, KB, -1.0, p, lda, p, lda, 1.0, at(c1, c1), lda, 1 | 8);
-        const int c2 = c1 + KB1;
-        if (rc || c2 >= n) { bulk_first = nullptr; continue; }
-        hipEvent_t pk = g_la.take();
-        GPR_HIP_TRY(hipEventRecord(pk, st));
-        GPR_HIP_TRY(hipStreamWaitEvent(g_la.side, pk, 0));
-        // bulk, part 1: column block K + 2
-        const int KB2 = (n - c2 < DB) ? n - c2 : DB;
-        rc = gpr_gemm_internal(g_la.side, 0, 1, n - c2, KB2, KB, -1.0, at(c2, K0), lda, at(c2, K0), lda, 1.0, at(c2, c2), lda, 1 | 8);
+        launch_narrow(st, KB1, KB1, p, p, at(c1, c1), lda, 1);                                // U_K(K + 1) top
+        mid_last = top;
+        if (Rrest <= 0) { bulk_first = nullptr; continue; }
+        launch_panel(g_la.mid, at(c2, K0), lda, Rrest, KB, wop, lop);                          // P_K rest
+        if (bulk_first) GPR_HIP_TRY(hipStreamWaitEvent(g_la.mid, bulk_first, 0));
+        launch_narrow(g_la.mid, Rrest, KB1, at(c2, K0), p, at(c2, c1), lda, 0);               // U_K(K + 1) rest
+        mid_last = g_la.take();
+        GPR_HIP_TRY(hipEventRecord(mid_last, g_la.mid));
+        GPR_HIP_TRY(hipStreamWaitEvent(g_la.side, mid_last, 0));
+        const int KB2 = (Rrest < DB) ? Rrest : DB;
+        launch_narrow(g_la.side, Rrest, KB2, at(c2, K0), at(c2, K0), at(c2, c2), lda, 1);     // U_K(K + 2)
         bulk_first = g_la.take();
         GPR_HIP_TRY(hipEventRecord(bulk_first, g_la.side));
         bulk_last = bulk_first;
         const int c3 = c2 + KB2;
-        if (rc == GPR_OK && c3 < n) {                            // part 2: everything to the right of it
+        if (c3 < n) {                                                                          // U_K(K + 3 ...)
             rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, KB, -1.0, at(c3, K0), lda, at(c3, K0), lda, 1.0, at(c3, c3), lda, 1);
             bulk_last = g_la.take();
             GPR_HIP_TRY(hipEventRecord(bulk_last, g_la.side));
         }
     }
+    if (mid_last) GPR_HIP_TRY(hipStreamWaitEvent(st, mid_last, 0));
     if (bulk_last) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_last, 0));
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
     if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
@@ -417,8 +583,8 @@ extern "C" int gpr_potrf_ops_doubles(void) { return (16 + NTILE) * TILE_DOUBLES;
 
 extern "C" int gpr_potrf_diag_block(void *stream, int kb, double *a, long long lda, int k0, int *info_dev, double *ops) {
     GPR_REQUIRE(kb >= 1 && kb <= DB && a && ops && lda >= kb, "gpr_potrf_diag_block: bad arguments (kb=%d)", kb);
-    hipLaunchKernelGGL(potrf_diag256_kernel, dim3(1), dim3(64 * DWAVES), 0, (hipStream_t)stream, a, lda, kb, k0, info_dev, ops,
-                       ops + 16 * TILE_DOUBLES);
+    hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, (hipStream_t)stream, a, lda, kb, k0, info_dev, ops,
+                       ops + 16 * TILE_DOUBLES, (int *)nullptr, 0);
     LAUNCH_CHECK("potrf_diag256");
     return GPR_OK;
 }
@@ -428,9 +594,23 @@ extern "C" int gpr_potrf_panel_rows(void *stream, int kb, const double *ops, dou
     if (rows == 0) return GPR_OK;
     GPR_REQUIRE(ops && p && lda >= kb, "gpr_potrf_panel_rows: null pointer / short rows");
     const double *wop = ops, *lop = ops + 16 * TILE_DOUBLES;
-    if (kb == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3((rows + DT - 1) / DT), dim3(256), 0, (hipStream_t)stream, p, lda, rows, kb, wop, lop);
-    else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3((rows + DT - 1) / DT), dim3(256), 0, (hipStream_t)stream, p, lda, rows, kb, wop, lop);
+    launch_panel((hipStream_t)stream, p, lda, rows, kb, wop, lop);
     LAUNCH_CHECK("potrf_panel256");
+    return GPR_OK;
+}
+
+// debug: one diagonal block with phase stamps; trace_host[2][16][8] (factor wavefront, first tile wavefront) in 10 ns ticks
+extern "C" int gpr_potrf_diag_trace(void *stream, int kb, double *a, long long lda, long long *trace_host) {
+    hipStream_t st = (hipStream_t)stream;
+    long long *tr; double *ops;
+    GPR_HIP_TRY(hipMalloc(&tr, 256 * sizeof(long long)));
+    GPR_HIP_TRY(hipMalloc(&ops, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double)));
+    GPR_HIP_TRY(hipMemset(tr, 0, 256 * sizeof(long long)));
+    GPR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_trace), &tr, sizeof(tr)));
+    hipLaunchKernelGGL((potrf_diag256_kernel<true, false>), dim3(1), dim3(64 * DWAVES), 0, st, a, lda, kb, 0, (int *)nullptr, ops, ops + 16 * TILE_DOUBLES, (int *)nullptr, 0);
+    GPR_HIP_TRY(hipStreamSynchronize(st));
+    GPR_HIP_TRY(hipMemcpy(trace_host, tr, 256 * sizeof(long long), hipMemcpyDeviceToHost));
+    (void)hipFree(tr); (void)hipFree(ops);
     return GPR_OK;
 }
 
@@ -513,8 +693,7 @@ extern "C" int gpr_trtri_lower(void *stream, int n, const double *l, long long l
         const int KB = (n - K0 < DB) ? n - K0 : DB;
         hipLaunchKernelGGL(tri_tiles256_kernel, dim3(1), dim3(1024), 0, st, l + (long long)K0 * ldl + K0, ldl, KB, wop, lop);
         hipLaunchKernelGGL(trtri_eye_kernel, dim3(DB), dim3(256), 0, st, eye);
-        if (KB == DB) hipLaunchKernelGGL(potrf_panel256_kernel<true>, dim3(DB / DT), dim3(256), 0, st, eye, (long long)DB, DB, KB, wop, lop);
-        else hipLaunchKernelGGL(potrf_panel256_kernel<false>, dim3(DB / DT), dim3(256), 0, st, eye, (long long)DB, DB, KB, wop, lop);
+        launch_panel(st, eye, (long long)DB, DB, KB, wop, lop);
         // eye now holds L_kk^-T (rows / columns < KB); X[k, k] = its transpose
         double *xkk = x + (long long)K0 * ldx + K0;
         hipLaunchKernelGGL(trtri_store_kernel, dim3((KB + 15) / 16, (KB + 15) / 16), dim3(256), 0, st, KB, eye, xkk, ldx);
