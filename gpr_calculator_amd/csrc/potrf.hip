@@ -101,7 +101,8 @@ __device__ long long *g_diag_trace = nullptr;
 template <bool TRACE, bool PUB>
 __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__restrict__ a, long long lda, int kb, int k0,
                                                              int *info, double *__restrict__ wop,
-                                                             double *__restrict__ lop, int *flag, int base) {
+                                                             double *__restrict__ lop, int *flag, int base,
+                                                             const int *wait_ctr, int wait_target) {
     __shared__ diag_lds S;
     auto stamp = [&](int who, int k, int slot) {
         if (TRACE && (threadIdx.x & 63) == 0) g_diag_trace[(who * 16 + k) * 8 + slot] = wall_clock64();
@@ -109,6 +110,17 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nt = (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
+    if (PUB && wait_ctr) {       // the block is still receiving its last update from a kernel running beside this one
+        if (tid == 0) {
+            int polls = 0;
+            while ((int)(__hip_atomic_load(wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_target) < 0 && polls < PIPE_MAX_POLLS) {
+                __builtin_amdgcn_s_sleep(2);
+                polls++;
+            }
+            if (polls >= PIPE_MAX_POLLS && info) atomicExch(info, -1);
+        }
+        __syncthreads();
+    }
     if (wave == 0) {
         __builtin_amdgcn_s_setprio(3);
         for (int k = 0; k < nt; k++) {
@@ -175,7 +187,8 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int col = tj * DT + lq + 4 * r;
-                acc[s][r] = (row < kb && col < kb) ? a[(long long)row * lda + col] : ((row == col) ? 1.0 : 0.0);
+                acc[s][r] = (row < kb && col < kb) ? (PUB ? coherent_load(&a[(long long)row * lda + col]) : a[(long long)row * lda + col])
+                                                   : ((row == col) ? 1.0 : 0.0);
             }
         }
     }
@@ -387,12 +400,17 @@ __global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict_
 typedef double d4u __attribute__((ext_vector_type(4), aligned(8)));
 __global__ void __launch_bounds__(256) syrk_narrow_kernel(int m, int n, const double *__restrict__ A, long long lda,
                                                            const double *__restrict__ B, long long ldb,
-                                                           double *__restrict__ C, long long ldc, int lower_only) {
+                                                           double *__restrict__ C, long long ldc, int lower_only, int *done) {
+    // done: C is handed to a kernel that is already running and polls this counter (the next diagonal block): stores
+    // that go through to it, and one count per workgroup once they are out
     __shared__ double part[4][4][256];                       // [wave][tile][reg * 64 + lane]
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 32;
-    if (lower_only && col0 > row0 + 31) return;              // tile strictly above the diagonal of C
+    if (lower_only && col0 > row0 + 31) {                    // tile strictly above the diagonal of C
+        if (done && threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
     __builtin_amdgcn_s_setprio(2);                           // a link of the sequential chain: ahead of the bulk updates on its SIMD
     const int k0 = wave * 64 + 4 * q;
     const double *a0 = A + (long long)min(row0 + r, m - 1) * lda + k0;
@@ -431,7 +449,16 @@ __global__ void __launch_bounds__(256) syrk_narrow_kernel(int m, int n, const do
     for (int e = 0; e < 4; e++) {
         const int gm = row0 + 16 * ti + q + 4 * e, gn = col0 + 16 * tj + r;
         const double v = (part[0][wave][e * 64 + lane] + part[1][wave][e * 64 + lane]) + (part[2][wave][e * 64 + lane] + part[3][wave][e * 64 + lane]);
-        if (gm < m && gn < n) C[(long long)gm * ldc + gn] -= v;
+        if (gm < m && gn < n) {
+            double *c = C + (long long)gm * ldc + gn;
+            if (done) coherent_store(c, *c - v);
+            else *c -= v;
+        }
+    }
+    if (done) {
+        wait_own_stores();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -454,8 +481,10 @@ struct lookahead_ctx {
     hipStream_t side = nullptr, mid = nullptr;
     std::vector<hipEvent_t> ev;
     size_t next = 0;
-    int *flag = nullptr;                 // stages published by the diagonal-block kernel in flight (see coherent_store)
+    int *flag = nullptr;                 // [0] stages published by the diagonal-block kernel in flight (see coherent_store)
+                                         // [1] workgroups of the updates of diagonal blocks that have finished
     unsigned seq = 0;                    // diagonal blocks launched so far
+    unsigned done_total = 0;             // value flag[1] reaches when every update launched so far is through
     std::mutex mu;                       // one factorisation with look-ahead at a time per process
     int init() {
         if (side) return GPR_OK;
@@ -463,7 +492,7 @@ struct lookahead_ctx {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
         if (hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; return GPR_ERR_HIP; }
-        if (hipMalloc((void **)&flag, sizeof(int)) != hipSuccess || hipMemset(flag, 0, sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
+        if (hipMalloc((void **)&flag, 2 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 2 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
         ev.resize(256);
         for (auto &e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GPR_ERR_HIP;
@@ -478,28 +507,33 @@ static void launch_panel(hipStream_t st, double *p, long long lda, int rows, int
     else hipLaunchKernelGGL((potrf_panel256_kernel<false, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr);
 }
 // C[m x n] -= A[m x 256] B[n x 256]^T
-static void launch_narrow(hipStream_t st, int m, int n, const double *A, const double *B, double *C, long long lda, int lower_only) {
-    hipLaunchKernelGGL(syrk_narrow_kernel, dim3((n + 31) / 32, (m + 31) / 32), dim3(256), 0, st, m, n, A, lda, B, lda, C, lda, lower_only);
+static int launch_narrow(hipStream_t st, int m, int n, const double *A, const double *B, double *C, long long lda, int lower_only,
+                         int *done = nullptr) {
+    const dim3 grid((n + 31) / 32, (m + 31) / 32);
+    hipLaunchKernelGGL(syrk_narrow_kernel, grid, dim3(256), 0, st, m, n, A, lda, B, lda, C, lda, lower_only, done);
+    return (int)(grid.x * grid.y);                           // what `done` grows by
 }
 
-// Right-looking, 256 columns per step, with look-ahead over three streams.  With D_K the diagonal block, P_K the panel
-// below it (its first 256 rows = "top": the rows of block K + 1) and U_K(J) the update of column block J by P_K:
-//   main (the caller's stream), the sequential chain:   D_K -> U_K(K + 1) top [= the next diagonal block]
-//   mid  (urgent):   P_K top, running WHILE D_K runs, two stages behind it (operand tiles handed over through
-//                    coherent stores and a counter) -> P_K rest -> U_K(K + 1) rest     [what the next panel needs]
-//   side (lowest):   U_K(K + 2) -> U_K(K + 3 ...)         the bulk of the flops (gemm128), beside the chain of step K + 1
-// Who waits for whom across streams (events):
-//   main U_K(K + 1) top      after  mid P_K top, and after side U_{K-1}(K + 1)
-//   mid  U_K(K + 1) rest     after  side U_{K-1}(K + 1)
-//   side U_K(K + 2)          after  mid U_K(K + 1) rest   (all of P_K is there)
-//   D_{K+2} re-uses the operand-tile buffer of D_K: its readers (P_K top, P_K rest) precede P_{K+1} top on mid, which main
-//   has waited for by then.
-// D_K is always enqueued before the P_K top that polls its counter, and depends on nothing enqueued after it, so the
-// polling kernel cannot starve its producer; if the producer never runs (a failed launch) the consumer gives up after
+// Right-looking, 256 columns per step, with look-ahead.  D_K = diagonal block K; P_K = the panel below it, cut into
+// top (the rows of block K + 1) and rest; U_K(J) = update of column block J by P_K, cut the same way.
+//   main (the caller's stream)  D_K, D_{K+1}, ... back to back.  D_{K+1} polls a counter until U_K(K + 1) top, its last
+//                               update, is through: the chain D -> P top -> U top -> D crosses no stream event.
+//   mid  (urgent)               P_K top WHILE D_K runs, two stages behind it (operand tiles handed over by coherent stores
+//                               and a counter) -> U_K(K + 1) top (counted) -> P_K rest -> U_K(K + 1) rest
+//   side (lowest)               U_K(K + 2) -> U_K(K + 3 ...): the bulk of the flops (gemm128), beside the chain of step K + 1
+// Events:
+//   mid  U_K(K + 1) top / rest  after  side U_{K-1}(K + 1)
+//   side U_K(K + 2)             after  mid U_K(K + 1) rest       (all of P_K is there)
+//   the last, unpiped diagonal block and the end of the call wait for everything.
+// Operand-tile buffers: three, used in turn (D_{K+2} starts after U_{K+1} top, which follows P_K rest on mid; the third
+// is headroom).
+// D_K is always enqueued before the P_K top that polls its counter, and depends on nothing enqueued after it, so a
+// polling kernel cannot starve its producer; if a producer never runs (a failed launch) the consumer gives up after
 // PIPE_MAX_POLLS and reports info = -1.
-// The narrow updates (n <= 256, k = 256) run on syrk_narrow_kernel, operands straight from global memory.
 // N = 6063: 14 ms (round 1: 64-wide steps) -> 5.4 ms (256-wide steps, two streams, tiled narrow GEMMs) -> 4.5 ms
-// (syrk_narrow_kernel) -> see DESIGN.md for the current figure.
+// (syrk_narrow_kernel) -> 4.2 ms (top panel beside the diagonal block, polled hand-overs).  Tried on top of this and
+// slower (4.8 ms): the tail of the panel (rows beyond block K + 2) on a fourth stream -- every hop between streams costs
+// 15-20 us of event latency, and U_K(K + 1) top then waits for side <- fourth <- mid.
 extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(n >= 0 && (n == 0 || (a && dinv)) && lda >= n, "gpr_potrf_lower: bad arguments (n=%d lda=%lld)", n, lda);
@@ -507,67 +541,64 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
     const size_t ops_doubles = (size_t)(16 + NTILE) * TILE_DOUBLES;
     void *scratch;
-    int rc = gpr_dev_alloc(&scratch, 2 * ops_doubles * sizeof(double), st);
+    int rc = gpr_dev_alloc(&scratch, 3 * ops_doubles * sizeof(double), st);
     if (rc) return rc;
     std::unique_lock<std::mutex> lock(g_la.mu);
     const bool la = n > 3 * DB && !getenv("GPR_POTRF_NO_LOOKAHEAD") && g_la.init() == GPR_OK;
     if (!la) lock.unlock();
-    const bool pipe = la && !getenv("GPR_POTRF_NO_PIPE");
-    hipEvent_t bulk_first = nullptr, bulk_last = nullptr, mid_last = nullptr;
     auto at = [&](int r, int c) { return a + (long long)r * lda + c; };
+    auto wait = [&](hipStream_t s, hipEvent_t e) { return e ? hipStreamWaitEvent(s, e, 0) : hipSuccess; };
+    auto mark = [&](hipStream_t s) { hipEvent_t e = g_la.take(); return hipEventRecord(e, s) == hipSuccess ? e : nullptr; };
+    hipEvent_t bulk_first = nullptr, bulk_last = nullptr, mid_last = nullptr;
+    if (la) {                                                // the other streams start behind what the caller queued
+        hipEvent_t e0 = mark(st);
+        GPR_HIP_TRY(wait(g_la.mid, e0)); GPR_HIP_TRY(wait(g_la.side, e0));
+    }
     int step = 0;
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB, step++) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
-        double *wop = (double *)scratch + (size_t)(step & 1) * ops_doubles, *lop = wop + 16 * TILE_DOUBLES;
+        double *wop = (double *)scratch + (size_t)(step % 3) * ops_doubles, *lop = wop + 16 * TILE_DOUBLES;
         const int c1 = K0 + KB, R = n - c1;                      // first row / column after the block
-        const bool piped = pipe && R > 0 && KB == DB;
-        const int base = (int)(++g_la.seq * 32u);
-        if (piped) hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop, g_la.flag, base);
-        else hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop, (int *)nullptr, 0);
-        if (R <= 0) break;
-        double *p = at(c1, K0);
         if (!la) {
-            launch_panel(st, p, lda, R, KB, wop, lop);
-            rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, p, lda, p, lda, 1.0, at(c1, c1), lda, 1);
+            hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
+                               (int *)nullptr, 0, (const int *)nullptr, 0);
+            if (R <= 0) break;
+            launch_panel(st, at(c1, K0), lda, R, KB, wop, lop);
+            rc = gpr_gemm_internal(st, 0, 1, R, R, KB, -1.0, at(c1, K0), lda, at(c1, K0), lda, 1.0, at(c1, c1), lda, 1);
             continue;
         }
-        const int KB1 = (R < DB) ? R : DB, c2 = c1 + KB1, Rrest = n - c2;
-        if (piped) {                                                                           // P_K top beside D_K
-            hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
-                               (const int *)g_la.flag, base, info_dev);
-        } else {
-            hipEvent_t dk = g_la.take();
-            GPR_HIP_TRY(hipEventRecord(dk, st));
-            GPR_HIP_TRY(hipStreamWaitEvent(g_la.mid, dk, 0));
-            launch_panel(g_la.mid, p, lda, KB1, KB, wop, lop);
+        if (R <= 0) {                                            // last block: nothing polls, nothing is handed over
+            GPR_HIP_TRY(wait(st, mid_last)); GPR_HIP_TRY(wait(st, bulk_last));
+            hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
+                               (int *)nullptr, 0, (const int *)nullptr, 0);
+            break;
         }
-        hipEvent_t top = g_la.take();
-        GPR_HIP_TRY(hipEventRecord(top, g_la.mid));
-        GPR_HIP_TRY(hipStreamWaitEvent(st, top, 0));
-        if (bulk_first) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_first, 0));
-        launch_narrow(st, KB1, KB1, p, p, at(c1, c1), lda, 1);                                // U_K(K + 1) top
-        mid_last = top;
+        const int base = (int)(++g_la.seq * 32u);
+        hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
+                           g_la.flag, base, (const int *)(g_la.flag + 1), (int)g_la.done_total);
+        double *p = at(c1, K0);
+        const int KB1 = (R < DB) ? R : DB, c2 = c1 + KB1, Rrest = n - c2;   // top = rows of block K + 1
+        // mid: P top beside D, U top counted into flag[1]
+        hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
+                           (const int *)g_la.flag, base, info_dev);
+        GPR_HIP_TRY(wait(g_la.mid, bulk_first));
+        g_la.done_total += (unsigned)launch_narrow(g_la.mid, KB1, KB1, p, p, at(c1, c1), lda, 1, g_la.flag + 1);
+        mid_last = mark(g_la.mid);
         if (Rrest <= 0) { bulk_first = nullptr; continue; }
-        launch_panel(g_la.mid, at(c2, K0), lda, Rrest, KB, wop, lop);                          // P_K rest
-        if (bulk_first) GPR_HIP_TRY(hipStreamWaitEvent(g_la.mid, bulk_first, 0));
-        launch_narrow(g_la.mid, Rrest, KB1, at(c2, K0), p, at(c2, c1), lda, 0);               // U_K(K + 1) rest
-        mid_last = g_la.take();
-        GPR_HIP_TRY(hipEventRecord(mid_last, g_la.mid));
-        GPR_HIP_TRY(hipStreamWaitEvent(g_la.side, mid_last, 0));
-        const int KB2 = (Rrest < DB) ? Rrest : DB;
+        launch_panel(g_la.mid, at(c2, K0), lda, Rrest, KB, wop, lop);                          // P rest, U rest
+        launch_narrow(g_la.mid, Rrest, KB1, at(c2, K0), p, at(c2, c1), lda, 0);
+        mid_last = mark(g_la.mid);
+        // side: the bulk
+        GPR_HIP_TRY(wait(g_la.side, mid_last));
+        const int KB2 = (Rrest < DB) ? Rrest : DB, c3 = c2 + KB2;
         launch_narrow(g_la.side, Rrest, KB2, at(c2, K0), at(c2, K0), at(c2, c2), lda, 1);     // U_K(K + 2)
-        bulk_first = g_la.take();
-        GPR_HIP_TRY(hipEventRecord(bulk_first, g_la.side));
-        bulk_last = bulk_first;
-        const int c3 = c2 + KB2;
+        bulk_last = bulk_first = mark(g_la.side);
         if (c3 < n) {                                                                          // U_K(K + 3 ...)
             rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, KB, -1.0, at(c3, K0), lda, at(c3, K0), lda, 1.0, at(c3, c3), lda, 1);
-            bulk_last = g_la.take();
-            GPR_HIP_TRY(hipEventRecord(bulk_last, g_la.side));
+            bulk_last = mark(g_la.side);
         }
     }
-    if (mid_last) GPR_HIP_TRY(hipStreamWaitEvent(st, mid_last, 0));
-    if (bulk_last) GPR_HIP_TRY(hipStreamWaitEvent(st, bulk_last, 0));
+    if (la) { GPR_HIP_TRY(wait(st, mid_last)); GPR_HIP_TRY(wait(st, bulk_last)); }
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
     if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
     const hipError_t e = hipGetLastError();
@@ -584,7 +615,7 @@ extern "C" int gpr_potrf_ops_doubles(void) { return (16 + NTILE) * TILE_DOUBLES;
 extern "C" int gpr_potrf_diag_block(void *stream, int kb, double *a, long long lda, int k0, int *info_dev, double *ops) {
     GPR_REQUIRE(kb >= 1 && kb <= DB && a && ops && lda >= kb, "gpr_potrf_diag_block: bad arguments (kb=%d)", kb);
     hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, (hipStream_t)stream, a, lda, kb, k0, info_dev, ops,
-                       ops + 16 * TILE_DOUBLES, (int *)nullptr, 0);
+                       ops + 16 * TILE_DOUBLES, (int *)nullptr, 0, (const int *)nullptr, 0);
     LAUNCH_CHECK("potrf_diag256");
     return GPR_OK;
 }
@@ -607,7 +638,7 @@ extern "C" int gpr_potrf_diag_trace(void *stream, int kb, double *a, long long l
     GPR_HIP_TRY(hipMalloc(&ops, (size_t)(16 + NTILE) * TILE_DOUBLES * sizeof(double)));
     GPR_HIP_TRY(hipMemset(tr, 0, 256 * sizeof(long long)));
     GPR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_diag_trace), &tr, sizeof(tr)));
-    hipLaunchKernelGGL((potrf_diag256_kernel<true, false>), dim3(1), dim3(64 * DWAVES), 0, st, a, lda, kb, 0, (int *)nullptr, ops, ops + 16 * TILE_DOUBLES, (int *)nullptr, 0);
+    hipLaunchKernelGGL((potrf_diag256_kernel<true, false>), dim3(1), dim3(64 * DWAVES), 0, st, a, lda, kb, 0, (int *)nullptr, ops, ops + 16 * TILE_DOUBLES, (int *)nullptr, 0, (const int *)nullptr, 0);
     GPR_HIP_TRY(hipStreamSynchronize(st));
     GPR_HIP_TRY(hipMemcpy(trace_host, tr, 256 * sizeof(long long), hipMemcpyDeviceToHost));
     (void)hipFree(tr); (void)hipFree(ops);
