@@ -384,7 +384,7 @@ __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const doub
 #define WT_ROWS 32
 #endif
 constexpr int WT_C = 128, WT_K = 32, WT_LD = WT_K + 2;   // row stride 34: operand reads of a half-wave hit 32 distinct bank pairs
-template <int WT_R> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + 4 * WT_R) * sizeof(double); }
+template <int WT_R, int NW = 4> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + NW * WT_R) * sizeof(double); }
 
 // SPLIT = 1 (few rows, e.g. one structure): grid (column blocks, row blocks), a workgroup takes ONE column block so that
 // the k chains of a row block run side by side; it leaves its sums of Q^2 in part[cb][row] (the owner of the last
@@ -393,21 +393,24 @@ template <int WT_R> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R 
 // workgroup takes column blocks x and ncb - 1 - x; ws_tail_combine_kernel adds the parts (a device-scope fence per
 // workgroup, as the last-arriver scheme needs, costs more than that launch when there are hundreds of workgroups).
 // SPLIT = 0: one workgroup walks all column blocks (a single column block, or as a reference).
-template <int WT_R, int SPLIT>
-__global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double *__restrict__ P, long long ldp,
+// NW wavefronts per workgroup (4 or 8): with 8, two wavefronts share a SIMD and one multiplies while the other waits
+// for its tile loads or at the barrier -- same tiles, same traffic, half the columns per wavefront.
+template <int WT_R, int SPLIT, int NW = 4>
+__global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const double *__restrict__ P, long long ldp,
                                                        const double *__restrict__ Ci, long long ldc,
                                                        const double *__restrict__ w, const double *__restrict__ diag,
                                                        double *__restrict__ out, double vsq, double *__restrict__ part,
                                                        double *__restrict__ mn, int *__restrict__ cnt) {
-    constexpr int RT = WT_R / 16, AI = WT_R / 8;                 // 16-row MFMA tiles, A loads per thread and tile
+    constexpr int RT = WT_R / 16, AI = WT_R / (2 * NW);          // 16-row MFMA tiles, A loads per thread and tile
+    constexpr int NC = WT_C / (16 * NW), BI = WT_C / (2 * NW), LR = 2 * NW;   // column tiles per wavefront, B loads per thread and tile, rows per load pass
     __shared__ int s_last;
     extern __shared__ __attribute__((aligned(16))) double wt_smem[];
     double *As0 = wt_smem, *As1 = As0 + WT_R * WT_LD, *Bs0 = As1 + WT_R * WT_LD, *Bs1 = Bs0 + WT_C * WT_LD;
-    double *red = Bs1 + WT_C * WT_LD;                            // [4 wavefronts][WT_R]
+    double *red = Bs1 + WT_C * WT_LD;                            // [NW wavefronts][WT_R]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bm0 = (SPLIT ? blockIdx.y : blockIdx.x) * WT_R;
-    const int wj = wave * 32;                                    // this wavefront: all WT_R rows x columns wj .. wj + 31
-    const int lk = tid & 31, lr = tid >> 5;                      // tile loads: k offset, row / column offset (+ 8 i)
+    const int wj = wave * (WT_C / NW);                           // this wavefront: all WT_R rows x columns wj .. wj + WT_C / NW - 1
+    const int lk = tid & 31, lr = tid >> 5;                      // tile loads: k offset, row / column offset (+ LR i)
     double sq[RT][4];                                            // sum over columns of Q^2, rows 16 i + (lane >> 4) + 4 r
     double mean2[AI], norm2[AI];                                 // P w, |p|^2 partials of rows lr + 8 i
 #pragma unroll
@@ -423,31 +426,33 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
         const int bn0 = cb * WT_C;
         const int kend = min(n, bn0 + WT_C);                     // C^-1[j][k] = 0 for k > j
         const bool last = cb == ncb - 1;
-        d4 acc[RT][2];                                           // independent accumulation chains
+        d4 acc[RT][NC];                                          // independent accumulation chains
 #pragma unroll
-        for (int i = 0; i < RT; i++) { acc[i][0] = d4{0.0, 0.0, 0.0, 0.0}; acc[i][1] = d4{0.0, 0.0, 0.0, 0.0}; }
+        for (int i = 0; i < RT; i++)
+#pragma unroll
+            for (int j = 0; j < NC; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
         // two tiles ahead: the loads issued in step kt are stored at the end of step kt + 1; two register sets, the kt
         // loop is unrolled by two
-        double ra0[AI], rb0[16], ra1[AI], rb1[16], wv0 = 0.0, wv1 = 0.0;
+        double ra0[AI], rb0[BI], ra1[AI], rb1[BI], wv0 = 0.0, wv1 = 0.0;
         auto load_tile = [&](int k0, double *ra, double *rb, double &wv) {
             const int gk = k0 + lk;
             if (last) wv = gk < n ? w[gk] : 0.0;
 #pragma unroll
             for (int i = 0; i < AI; i++) {
-                const int gm = bm0 + lr + 8 * i;
+                const int gm = bm0 + lr + LR * i;
                 ra[i] = (gm < m && gk < kend) ? P[(long long)gm * ldp + gk] : 0.0;
             }
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const int gn = bn0 + lr + 8 * i;
+            for (int i = 0; i < BI; i++) {
+                const int gn = bn0 + lr + LR * i;
                 rb[i] = (gn < n && gk < kend) ? Ci[(long long)gn * ldc + gk] : 0.0;
             }
         };
         auto store_tile = [&](double *As, double *Bs, const double *ra, const double *rb, double wv) {
 #pragma unroll
-            for (int i = 0; i < AI; i++) As[(lr + 8 * i) * WT_LD + lk] = ra[i];
+            for (int i = 0; i < AI; i++) As[(lr + LR * i) * WT_LD + lk] = ra[i];
 #pragma unroll
-            for (int i = 0; i < 16; i++) Bs[(lr + 8 * i) * WT_LD + lk] = rb[i];
+            for (int i = 0; i < BI; i++) Bs[(lr + LR * i) * WT_LD + lk] = rb[i];
             if (last) {
 #pragma unroll
                 for (int i = 0; i < AI; i++) { mean2[i] += ra[i] * wv; norm2[i] += ra[i] * ra[i]; }
@@ -457,12 +462,14 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
 #pragma unroll
             for (int ks = 0; ks < WT_K / 4; ks++) {
                 const int kr = ks * 4 + (lane >> 4);
-                const double b0 = Bs[(wj + (lane & 15)) * WT_LD + kr], b1 = Bs[(wj + 16 + (lane & 15)) * WT_LD + kr];
+                double bv[NC];
+#pragma unroll
+                for (int j = 0; j < NC; j++) bv[j] = Bs[(wj + 16 * j + (lane & 15)) * WT_LD + kr];
 #pragma unroll
                 for (int i = 0; i < RT; i++) {
                     const double a = As[(16 * i + (lane & 15)) * WT_LD + kr];
-                    acc[i][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[i][1], 0, 0, 0);
+#pragma unroll
+                    for (int j = 0; j < NC; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv[j], acc[i][j], 0, 0, 0);
                 }
             }
         };
@@ -487,7 +494,9 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
 #pragma unroll
         for (int i = 0; i < RT; i++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) sq[i][r] += acc[i][0][r] * acc[i][0][r] + acc[i][1][r] * acc[i][1][r];
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int j = 0; j < NC; j++) sq[i][r] += acc[i][j][r] * acc[i][j][r];
     }
     // rows of sq: 16 lanes (columns) share a row -> butterfly inside the 16-lane group; the four wavefronts hold
     // different columns of the same rows and are added in wavefront order
@@ -509,21 +518,27 @@ __global__ void __launch_bounds__(256) ws_tail_kernel(int m, int n, const double
         if (lk == 0)
 #pragma unroll
             for (int i = 0; i < AI; i++) {
-                const int rl = lr + 8 * i, row = bm0 + rl;
+                const int rl = lr + LR * i, row = bm0 + rl;
                 if (row < m) {
                     out[row] = mean2[i];
-                    const double q2 = ((red[rl] + red[WT_R + rl]) + red[2 * WT_R + rl]) + red[3 * WT_R + rl];
+                    double q2 = 0.0;
+#pragma unroll
+                    for (int wv = 0; wv < NW; wv++) q2 += red[wv * WT_R + rl];        // wavefront order
                     out[m + row] = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0);
                 }
             }
         return;
     }
-    if (tid < WT_R && bm0 + tid < m)
-        part[(size_t)blockIdx.x * m + bm0 + tid] = ((red[tid] + red[WT_R + tid]) + red[2 * WT_R + tid]) + red[3 * WT_R + tid];
+    if (tid < WT_R && bm0 + tid < m) {
+        double q2 = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < NW; wv++) q2 += red[wv * WT_R + tid];                    // wavefront order
+        part[(size_t)blockIdx.x * m + bm0 + tid] = q2;
+    }
     if ((SPLIT == 2 ? (int)blockIdx.x == 0 : (int)blockIdx.x == ncb - 1) && lk == 0)     // owner of the last column block: full k range seen
 #pragma unroll
         for (int i = 0; i < AI; i++) {
-            const int row = bm0 + lr + 8 * i;
+            const int row = bm0 + lr + LR * i;
             if (row < m) { mn[row] = mean2[i]; mn[(size_t)m + row] = norm2[i]; }
         }
     if (SPLIT == 2) return;                                      // ws_tail_combine_kernel adds the parts
@@ -952,10 +967,11 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
     if (ncb >= 2) {
         // many rows: 64-row workgroups take column blocks x and ncb - 1 - x (equal work for every workgroup, half the
         // C^-1 bytes per flop of the 32-row form), their sums are combined by a second small launch
-        constexpr int R2 = 64;
+        constexpr int R2 = 64, NW2 = 8;
+        constexpr size_t lds2 = wt_lds_bytes<R2, NW2>();
         static bool attr2 = false;
         if (!attr2) {
-            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R2>()));
+            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R2, 2, NW2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             attr2 = true;
         }
         const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
@@ -970,7 +986,7 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
             GPR_HIP_TRY(hipMemset(done, 0, sizeof(int)));
         }
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
-        hipLaunchKernelGGL((ws_tail_kernel<R2, 2>), dim3(npart, nrb2), dim3(256), wt_lds_bytes<R2>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
+        hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
                            out, vsq, part, mn, (int *)nullptr);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
                            (const double *)mn, diag, out, vsq, status_src, status_dst, done);

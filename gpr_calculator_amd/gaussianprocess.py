@@ -1101,6 +1101,9 @@ class GP():
         des = self.descriptor
         if ws is None or not self.weight_space_mean or getattr(des, "_stress", False) or not des.derivative:
             return None
+        tr = self._trace
+        if tr is not None:
+            tr.append(("enter", time.perf_counter_ns()))
         got = _pygather.gather(strucs)
         if got is None:
             return None
@@ -1132,11 +1135,15 @@ class GP():
         E, F = np.empty(nS), np.empty((natoms, 3))
         Es, Fs = (np.empty(nS), np.empty((natoms, 3))) if return_std else (None, None)
         vp = lambda a: None if a is None else a.ctypes.data
+        if tr is not None:
+            tr.append(("native call", time.perf_counter_ns()))
         dev.check(_lib.lib().gpr_dot2_session_predict(
             ses[1], nS, a0.ctypes.data, np.frombuffer(got[2], dtype=np.float64).ctypes.data,
             np.frombuffer(got[3], dtype=np.float64).ctypes.data, np.frombuffer(got[4], dtype=np.int32).ctypes.data,
             np.frombuffer(got[1], dtype=np.int32).ctypes.data, vp(fixed), E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None),
             "gpr_dot2_session_predict")
+        if tr is not None:
+            tr.append(("native done", time.perf_counter_ns()))
         n0 = int(a0[1]) if nS else 0
         if natoms == nS * n0:                                            # same size everywhere (an NEB band): one reshape
             Fl = list(F.reshape(nS, n0, 3))
