@@ -455,9 +455,15 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
                                (uint4 *)nb->d_in, n16, nb->d_err);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: upload failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
     }
+    // the event that guards the staging buffer is recorded behind the count pass (the stream is in order): between the
+    // upload and the first kernel that needs it the host does nothing but launch
+    auto guard_stage = [&]() {
+        const hipError_t e = hipEventRecord(sb.ev, st);
+        sb.pending = e == hipSuccess;
+        return e;
+    };
     nb->d_wpos = (const double *)nb->d_in;
     nb->d_shift = (const double *)(nb->d_in + b_wpos);
     nb->d_sinfo = (const nbr_sinfo *)(nb->d_in + b_wpos + b_shift);
@@ -474,12 +480,13 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         // sizes guessed by the caller: everything is queued without waiting for the count pass; the true sizes and the
         // overflow flag stay on the device (gpr_nbr_info_to)
         nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;
+        hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);       // the count pass needs no pair arrays
+        hipError_t e = guard_stage();
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: event failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
         if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double) + ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
         nb->d_vec = (double *)p; nb->d_w = nb->d_vec + 3 * (size_t)cap_pairs;
         nb->d_seq = (int *)(nb->d_vec + 4 * (size_t)cap_pairs); nb->d_rp0 = nb->d_seq + 2 * (size_t)cap_rows;
         nb->seq_in_vec = true;
-        hipError_t e;
-        hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
         hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
                            cap_pairs, cap_rows, nb->d_rp0);
         a.cr0 = nb->d_off; a.cp0 = nb->d_off + natoms + 1; a.ovf = nb->d_err + 1;
@@ -493,8 +500,8 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     nb->centre_row0.assign(natoms + 1, 0);
     std::vector<int> h_off(2 * (size_t)natoms + 2, 0);
     {
-        hipError_t e = hipSuccess;
-        if (natoms > 0) {
+        hipError_t e = guard_stage();
+        if (e == hipSuccess && natoms > 0) {
             hipLaunchKernelGGL(nbr_centre_kernel<false>, dim3(natoms), dim3(64), 0, st, a);
             hipLaunchKernelGGL(nbr_scan_kernel, dim3(1), dim3(1024), 0, st, natoms, cnt_rows, cnt_pairs, nb->d_off, nb->d_err + 1,
                                0, 0, (int *)nullptr);

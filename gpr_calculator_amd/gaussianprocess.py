@@ -1145,13 +1145,14 @@ class GP():
         if tr is not None:
             tr.append(("native done", time.perf_counter_ns()))
         n0 = int(a0[1]) if nS else 0
-        if natoms == nS * n0:                                            # same size everywhere (an NEB band): one reshape
-            Fl = list(F.reshape(nS, n0, 3))
-            Fsl = list(Fs.reshape(nS, n0, 3)) if return_std else [None] * nS
-        else:
-            Fl = [F[a0[k]:a0[k + 1]] for k in range(nS)]
-            Fsl = [Fs[a0[k]:a0[k + 1]] for k in range(nS)] if return_std else [None] * nS
-        return list(E), Fl, (list(Es) if return_std else [None] * nS), Fsl
+        none = [None] * nS
+        if natoms == nS * n0:
+            # same size everywhere (an NEB band): the arrays themselves, first axis = structure (64 views and 64 boxed
+            # floats per array cost more host time than the unpacking in C)
+            return E, F.reshape(nS, n0, 3), (Es if return_std else none), (Fs.reshape(nS, n0, 3) if return_std else none)
+        Fl = [F[a0[k]:a0[k + 1]] for k in range(nS)]
+        Fsl = [Fs[a0[k]:a0[k + 1]] for k in range(nS)] if return_std else none
+        return list(E), Fl, (list(Es) if return_std else none), Fsl
 
     _session = None
     _trace = None               # a list: host timestamps (label, ns) of the native batch call are appended (tools/native_split.py)
@@ -1170,7 +1171,8 @@ class GP():
         """Batched predict_structure(stress=False): one neighbour search, one descriptor launch and one prediction
         (feature rows x weight-space tables for the Dot kernel at zeta = 2, K_trans + triangular product otherwise) for
         the whole batch; over ranks the batch is split by structure.
-        Returns lists (E, F, E_std, F_std) ordered like `strucs` (identical on every rank)."""
+        Returns sequences (E, F, E_std, F_std) ordered like `strucs` (identical on every rank): lists, or -- a batch of
+        equally sized structures on one rank -- arrays whose first axis is the structure."""
         nb = len(strucs)
         size, rank = self.comm.size, self.comm.rank
         if size == 1 and nb and self.session_batch:
