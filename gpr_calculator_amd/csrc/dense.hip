@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
                                                        const double *__restrict__ Ci, long long ldc,
                                                        const double *__restrict__ w, const double *__restrict__ diag,
                                                        double *__restrict__ out, double vsq, double *__restrict__ part,
-                                                       double *__restrict__ mn, int *__restrict__ cnt) {
+                                                       double *__restrict__ mn, int *__restrict__ cnt, int std_out) {
     constexpr int RT = WT_R / 16, AI = WT_R / (2 * NW);          // 16-row MFMA tiles, A loads per thread and tile
     constexpr int NC = WT_C / (16 * NW), BI = WT_C / (2 * NW), LR = 2 * NW;   // column tiles per wavefront, B loads per thread and tile, rows per load pass
     __shared__ int s_last;
@@ -524,7 +524,7 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
                     double q2 = 0.0;
 #pragma unroll
                     for (int wv = 0; wv < NW; wv++) q2 += red[wv * WT_R + rl];        // wavefront order
-                    out[m + row] = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0);
+                    { const double v = fmax(diag[row] - vsq * (norm2[i] - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
                 }
             }
         return;
@@ -554,7 +554,7 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
         double q2 = 0.0;
         for (int x = 0; x < ncb; x++) q2 += __builtin_nontemporal_load(&part[(size_t)x * m + row]);
         out[row] = __builtin_nontemporal_load(&mn[row]);
-        out[m + row] = fmax(diag[row] - vsq * (__builtin_nontemporal_load(&mn[(size_t)m + row]) - q2), 0.0);
+        { const double v = fmax(diag[row] - vsq * (__builtin_nontemporal_load(&mn[(size_t)m + row]) - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
     }
 }
 
@@ -565,14 +565,14 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
 __global__ void __launch_bounds__(256) ws_tail_combine_kernel(int m, int npart, const double *__restrict__ part,
                                                               const double *__restrict__ mn, const double *__restrict__ diag,
                                                               double *__restrict__ out, double vsq, const int *status_src,
-                                                              double *status_dst, int *done) {
+                                                              double *status_dst, int *done, int std_out) {
     __shared__ int s_last;
     const int row = blockIdx.x * blockDim.x + threadIdx.x;
     if (row < m) {
         double q2 = 0.0;
         for (int x = 0; x < npart; x++) q2 += part[(size_t)x * m + row];
         out[row] = mn[row];
-        out[m + row] = fmax(diag[row] - vsq * (mn[(size_t)m + row] - q2), 0.0);
+        { const double v = fmax(diag[row] - vsq * (mn[(size_t)m + row] - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
     }
     if (!status_dst) return;
     __threadfence_system();
@@ -927,6 +927,13 @@ extern "C" int gpr_ws_tail(void *stream, int m, int n, const double *P, long lon
 extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
                                   const double *w, const double *diag, double *out, double vsq, const int *status_src,
                                   double *status_dst) {
+    return gpr_ws_tail_internal(stream, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq, status_src, status_dst, 0);
+}
+
+// std_out: the second half of `out` holds standard deviations (square roots of the clamped variances) instead of variances
+int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                         const double *w, const double *diag, double *out, double vsq, const int *status_src,
+                         double *status_dst, int std_out) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE((status_src == nullptr) == (status_dst == nullptr), "gpr_ws_tail_status: status source and destination go together");
     auto status_only = [&]() {
@@ -957,7 +964,7 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
         if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, cnt);
+                           out, vsq, part, mn, cnt, std_out);
         gpr_prof_end(st, pid);
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
@@ -987,9 +994,9 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
         }
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, (int *)nullptr);
+                           out, vsq, part, mn, (int *)nullptr, std_out);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
-                           (const double *)mn, diag, out, vsq, status_src, status_dst, done);
+                           (const double *)mn, diag, out, vsq, status_src, status_dst, done, std_out);
         gpr_prof_end(st, pid2);
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
@@ -998,7 +1005,7 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
     hipLaunchKernelGGL((ws_tail_kernel<R, 0>), dim3(nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq,
-                       (double *)nullptr, (double *)nullptr, (int *)nullptr);
+                       (double *)nullptr, (double *)nullptr, (int *)nullptr, std_out);
     gpr_prof_end(st, pid);
     LAUNCH_CHECK("ws_tail");
     return status_only();

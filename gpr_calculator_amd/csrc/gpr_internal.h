@@ -114,6 +114,11 @@ void gpr_prof_end(hipStream_t st, int id);
 int gpr_gemm_internal(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                       const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only);
 
+// gpr_ws_tail_status with standard deviations instead of variances in the second half of `out` (std_out != 0)
+int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
+                         const double *w, const double *diag, double *out, double vsq, const int *status_src,
+                         double *status_dst, int std_out);
+
 // small helpers
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
 int gpr_dev_free(void *p, hipStream_t st);

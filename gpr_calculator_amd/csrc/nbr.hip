@@ -48,8 +48,8 @@ struct nbr_geom {
     int nimg = 0, zero_img = 0;
     bool singular = false;
     // cell analysis of the last call
-    bool have_cell = false, any = false;
-    double cell[9], perp[3][3], det = 0.0;
+    bool have_cell = false, any = false, reused = false;      // reused: same cell and pbc as the call before (same shift table)
+    double cell[9], perp[3][3], det = 0.0, inv_det = 0.0;
     int pb[3] = {0, 0, 0};
 };
 
@@ -57,6 +57,7 @@ static void nbr_geometry(int n, const double *positions, const double *cell, con
     const bool same = g.have_cell && !g.singular && memcmp(g.cell, cell, sizeof(g.cell)) == 0 && g.pb[0] == pb[0] &&
                       g.pb[1] == pb[1] && g.pb[2] == pb[2];
     g.wrapped.assign(positions, positions + 3 * (size_t)n);
+    g.reused = same;
     if (!same) {
         g.shifts.clear(); g.nimg = 0; g.zero_img = 0; g.singular = false;
         memcpy(g.cell, cell, sizeof(g.cell)); g.pb[0] = pb[0]; g.pb[1] = pb[1]; g.pb[2] = pb[2];
@@ -68,6 +69,7 @@ static void nbr_geometry(int n, const double *positions, const double *cell, con
             g.det = cell[0] * g.perp[0][0] + cell[1] * g.perp[0][1] + cell[2] * g.perp[0][2];
             const double vol = std::fabs(g.det);
             if (vol < 1e-12) { g.singular = true; return; }
+            g.inv_det = 1.0 / g.det;
             for (int k = 0; k < 3; k++)          // perp[k]: normal of the plane spanned by the other two cell vectors
                 if (pb[k]) {
                     const double area = std::sqrt(g.perp[k][0] * g.perp[k][0] + g.perp[k][1] * g.perp[k][1] + g.perp[k][2] * g.perp[k][2]);
@@ -86,7 +88,14 @@ static void nbr_geometry(int n, const double *positions, const double *cell, con
         for (int i = 0; i < n; i++) {
             double *p = &g.wrapped[3 * i];
             double f[3];
-            for (int k = 0; k < 3; k++) f[k] = (p[0] * g.perp[k][0] + p[1] * g.perp[k][1] + p[2] * g.perp[k][2]) / g.det;
+            bool inside = true;                  // every periodic fractional coordinate safely inside [0, 1): nothing to wrap
+            for (int k = 0; k < 3; k++) {
+                f[k] = p[0] * g.perp[k][0] + p[1] * g.perp[k][1] + p[2] * g.perp[k][2];
+                const double q = f[k] * g.inv_det;                   // within 2 ulp of the quotient: decides unless q is at an edge
+                inside = inside && (!pb[k] || (q > 1e-9 && q < 1.0 - 1e-9));
+            }
+            if (inside) continue;
+            for (int k = 0; k < 3; k++) f[k] = f[k] / g.det;         // the quotient itself, as before
             for (int k = 0; k < 3; k++)
                 if (pb[k]) {
                     const double fl = std::floor(f[k]);
@@ -373,7 +382,7 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 }  // namespace
 
 namespace {
-struct stage_buf { void *p = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };
+struct stage_buf { void *p = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };   // dev: device alias of p
 thread_local stage_buf g_stage[2];
 thread_local int g_stage_next = 0;
 }
@@ -396,9 +405,11 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         GPR_REQUIRE(n >= 0, "gpr_nbr_build_device: atom0 not ascending at structure %d", s);
         nbr_geometry(n, positions + 3 * (size_t)atom0[s], cells + 9 * s, pbc + 3 * s, rcut, g);
         if (g.singular) { gpr_set_error("gpr_nbr_build_device: periodic structure %d has a singular cell", s); return GPR_ERR_ARG; }
-        sinfo[s] = nbr_sinfo{atom0[s], n, (int)(shifts.size() / 3), g.nimg, g.zero_img, 0};
+        // structures with the cell and pbc of their predecessor (a band of images) share its shift table
+        const int img0 = (g.reused && s > 0) ? sinfo[s - 1].img0 : (int)(shifts.size() / 3);
+        sinfo[s] = nbr_sinfo{atom0[s], n, img0, g.nimg, g.zero_img, 0};
         wpos.insert(wpos.end(), g.wrapped.begin(), g.wrapped.end());
-        shifts.insert(shifts.end(), g.shifts.begin(), g.shifts.end());
+        if (!(g.reused && s > 0)) shifts.insert(shifts.end(), g.shifts.begin(), g.shifts.end());
         for (int k = 0; k < n; k++) sid[atom0[s] + k] = s;
     }
     const size_t b_wpos = wpos.size() * 8, b_shift = shifts.size() * 8, b_sinfo = sinfo.size() * sizeof(nbr_sinfo),
@@ -413,7 +424,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     if (sb.pending) { (void)hipEventSynchronize(sb.ev); sb.pending = false; }
     if (sb.cap < b_total) {
         if (sb.p) (void)hipHostFree(sb.p);
-        sb.p = nullptr; sb.cap = 0;
+        sb.p = nullptr; sb.dev = nullptr; sb.cap = 0;
         const size_t want = std::max(b_total * 2, (size_t)1 << 16);
         if (hipHostMalloc(&sb.p, want, hipHostMallocDefault) != hipSuccess) {
             gpr_set_error("gpr_nbr_build_device: cannot allocate %zu bytes of page-locked memory", want);
@@ -448,7 +459,9 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     nb->d_err = cnt_pairs + natoms;
     {
         void *src_dev = nullptr;
-        hipError_t e = hipHostGetDevicePointer(&src_dev, sb.p, 0);
+        hipError_t e = hipSuccess;
+        if (!sb.dev) e = hipHostGetDevicePointer(&sb.dev, sb.p, 0);
+        src_dev = sb.dev;
         if (e == hipSuccess) {
             const size_t n16 = (b_total + 15) / 16;
             hipLaunchKernelGGL(nbr_upload_kernel, dim3((unsigned)((n16 + 255) / 256)), dim3(256), 0, st, (const uint4 *)src_dev,

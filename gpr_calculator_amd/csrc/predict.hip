@@ -7,6 +7,10 @@
 #include <cmath>
 #include "gpr_internal.h"
 
+// set by the session call around gpr_predict_dot2_batch: the tail kernel then writes standard deviations (the session
+// hands those to its caller; the square roots of 18 000 numbers are not the host's job)
+static thread_local int t_std_out = 0;
+
 extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double rcut, double alpha, int nseg, int ncheb,
                                       const double *so3_table, int nstruct, const int *atom0, const double *positions,
                                       const double *cells, const int *pbc, const int *numbers, int weight_on,
@@ -96,8 +100,8 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
     // mean = Psi w, var = max(diag - rowsum((Psi M) o Psi), 0); with C^-1 at hand the factored form in one launch
     if (want_std && Cinv_dev) {
         // the tail delivers the status words behind the results itself (no separate launch)
-        if ((rc = gpr_ws_tail_status(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma,
-                                     gpr_nbr_info_ptr(nb), out_dev + 2 * m))) return cleanup(rc);
+        if ((rc = gpr_ws_tail_internal(stream, (int)m, F, d_psi, F, Cinv_dev, F, w_dev, d_diag, out_dev, sigma * sigma,
+                                       gpr_nbr_info_ptr(nb), out_dev + 2 * m, t_std_out))) return cleanup(rc);
         return cleanup(GPR_OK);
     } else {
         if (want_std) {
@@ -190,6 +194,7 @@ extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const 
         s->pin_cap = want;
     }
     volatile double *tail = s->pin + nout;
+    const int dev_std = (s->want_std && s->Cinv) ? 1 : 0;     // the device delivers standard deviations, not variances
     int cap_pairs = 0, cap_rows = 0;
     if (s->pairs_per_atom > 0.0) {
         cap_pairs = (int)(s->pairs_per_atom * natoms * 1.125) + 64;
@@ -197,9 +202,11 @@ extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const 
     }
     for (int attempt = 0; attempt < 2; attempt++) {
         for (int k = 0; k < 4; k++) tail[k] = __builtin_nan("");
+        t_std_out = dev_std;
         int rc = gpr_predict_dot2_batch(s->st, s->nmax, s->lmax, s->rcut, s->alpha, s->nseg, s->ncheb, s->table, nstruct, atom0,
                                         positions, cells, pbc, numbers, s->weight_on, free_mask, s->ns, s->species.data(), s->sigma,
                                         s->sigma0, s->w, s->M, s->Cinv, s->want_std, cap_pairs, cap_rows, s->pin_dev, nout + 4);
+        t_std_out = 0;
         if (rc) return rc;
         // the status words are the last thing the last kernel writes (system-scope fence before them): spin on them in
         // host memory; fall back to a blocking synchronisation if they do not show up within seconds
@@ -224,17 +231,20 @@ extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const 
     const double *mean = s->pin, *var = s->pin + m;
     for (int k = 0; k < nstruct; k++) {
         E[k] = mean[k] * (atom0[k + 1] - atom0[k]);
-        if (s->want_std) E_std[k] = sqrt(var[k]);
+        if (s->want_std) E_std[k] = dev_std ? var[k] : sqrt(var[k]);
     }
     const double *mf = mean + nstruct, *vf = var + nstruct;
     if (!free_mask) {
         memcpy(F, mf, (size_t)3 * natoms * sizeof(double));
-        if (s->want_std) for (long long i = 0; i < 3LL * natoms; i++) F_std[i] = sqrt(vf[i]);
+        if (s->want_std) {
+            if (dev_std) memcpy(F_std, vf, (size_t)3 * natoms * sizeof(double));
+            else for (long long i = 0; i < 3LL * natoms; i++) F_std[i] = sqrt(vf[i]);
+        }
     } else {
         long long r = 0;
         for (int a = 0; a < natoms; a++) {
             if (free_mask[a]) {
-                for (int c = 0; c < 3; c++) { F[3 * a + c] = mf[r + c]; if (s->want_std) F_std[3 * a + c] = sqrt(vf[r + c]); }
+                for (int c = 0; c < 3; c++) { F[3 * a + c] = mf[r + c]; if (s->want_std) F_std[3 * a + c] = dev_std ? vf[r + c] : sqrt(vf[r + c]); }
                 r += 3;
             } else {
                 for (int c = 0; c < 3; c++) { F[3 * a + c] = 0.0; if (s->want_std) F_std[3 * a + c] = 0.0; }
