@@ -233,6 +233,8 @@ def main():
         # every seq row (i, j) is one row of atom j's force point; its species is that of centre i
         ele_rows = np.concatenate([np.asarray(nums)[sq[:, 0]] for nums, sq in zip(desc["numbers"], desc["seq"])])
         tX, _, tE, _ = gp.train_x["force"]
+        tEe = gp.train_x["energy"][1] if gp.train_x.get("energy") is not None and len(gp.train_x["energy"][-1]) else np.zeros(0, dtype=int)
+        ele_atoms = np.concatenate([np.asarray(nums) for nums in desc["numbers"]])      # energy rows of the batch: one per atom
         N = gp.alpha_.shape[0]
         m_rows = sum(1 + 3 * len(s) for s in batch)                    # predicted quantities per step
         n_nbr = int(gp.descriptor.neighbor_index_batch(batch)["w"].shape[0])
@@ -244,6 +246,12 @@ def main():
         work = {   # algorithmic FP64 operations of one step per kernel kind (SURVEY.md section 8d where it defines them)
             "ff": ("kblock_kernel<FF>: force-force block of K_trans", same_species_pairs(ele_rows, tE) * FLOP_PER_PAIR_FF,
                    "1.10 kflop per same-species row pair"),
+            # energy rows of the batch against the training force rows + force rows of the batch against the training
+            # energy rows (both through kblock_kernel<EF>), energy rows against energy rows (<EE>)
+            "ef": ("kblock_kernel<EF>: energy-force blocks of K_trans",
+                   (same_species_pairs(ele_atoms, tE) + same_species_pairs(ele_rows, tEe)) * 285.0, "285 flop per same-species row pair"),
+            "ee": ("kblock_kernel<EE>: energy-energy block of K_trans", same_species_pairs(ele_atoms, tEe) * 95.0,
+                   "95 flop per same-species row pair"),
             "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
                      "N^2 m (triangular-solve form of the variance)"),
             "gemm": (("ws_tail_kernel (+ ws_tail_combine_kernel; gpr_ws_tail): mean = Psi* w and the weight-space variance "
