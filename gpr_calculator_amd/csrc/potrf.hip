@@ -475,6 +475,17 @@ __global__ void zero_upper2_kernel(int n, double *a, long long lda) {
     do { hipError_t _e = hipGetLastError();                                                  \
          if (_e != hipSuccess) { gpr_set_error("%s launch failed: %s", name, hipGetErrorString(_e)); return GPR_ERR_HIP; } } while (0)
 
+// Can two kernels on different streams run at the same time here?  The consumer is enqueued first and polls (bounded) for
+// a flag the producer sets.  Under a tool that serialises kernels (rocprofv3 --pmc does), or when the two streams land on
+// one hardware queue, the consumer runs alone and gives up: the factorisation then keeps every hand-over at kernel
+// boundaries (events) instead of polling.
+__global__ void pipe_probe_wait_kernel(const int *flag, int *seen) {
+    int polls = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0 && polls < 4096) { __builtin_amdgcn_s_sleep(8); polls++; }
+    *seen = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__global__ void pipe_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // second stream + events of the look-ahead (one set per process; the factorisation is not re-entrant anyway: it owns
 // the scratch of the diagonal kernel for the duration of the call)
 struct lookahead_ctx {
@@ -485,6 +496,7 @@ struct lookahead_ctx {
                                          // [1] workgroups of the updates of diagonal blocks that have finished
     unsigned seq = 0;                    // diagonal blocks launched so far
     unsigned done_total = 0;             // value flag[1] reaches when every update launched so far is through
+    bool concurrent = false;             // kernels of two streams overlap in time (probed once): polled hand-overs are safe
     std::mutex mu;                       // one factorisation with look-ahead at a time per process
     int init() {
         if (side) return GPR_OK;
@@ -492,7 +504,15 @@ struct lookahead_ctx {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
         if (hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; return GPR_ERR_HIP; }
-        if (hipMalloc((void **)&flag, 2 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 2 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
+        if (hipMalloc((void **)&flag, 4 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 4 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
+        {   // flag[2]: probe flag, flag[3]: what the consumer saw
+            int seen = 0;
+            hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, mid, (const int *)(flag + 2), flag + 3);
+            hipLaunchKernelGGL(pipe_probe_set_kernel, dim3(1), dim3(1), 0, side, flag + 2);
+            if (hipStreamSynchronize(mid) != hipSuccess || hipStreamSynchronize(side) != hipSuccess ||
+                hipMemcpy(&seen, flag + 3, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return GPR_ERR_HIP;
+            concurrent = seen != 0 && !getenv("GPR_POTRF_NO_POLL");
+        }
         ev.resize(256);
         for (auto &e : ev)
             if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GPR_ERR_HIP;
@@ -573,16 +593,31 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
                                (int *)nullptr, 0, (const int *)nullptr, 0);
             break;
         }
-        const int base = (int)(++g_la.seq * 32u);
-        hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
-                           g_la.flag, base, (const int *)(g_la.flag + 1), (int)g_la.done_total);
         double *p = at(c1, K0);
         const int KB1 = (R < DB) ? R : DB, c2 = c1 + KB1, Rrest = n - c2;   // top = rows of block K + 1
-        // mid: P top beside D, U top counted into flag[1]
-        hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
-                           (const int *)g_la.flag, base, info_dev);
-        GPR_HIP_TRY(wait(g_la.mid, bulk_first));
-        g_la.done_total += (unsigned)launch_narrow(g_la.mid, KB1, KB1, p, p, at(c1, c1), lda, 1, g_la.flag + 1);
+        if (g_la.concurrent) {
+            const int base = (int)(++g_la.seq * 32u);
+            hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
+                               g_la.flag, base, (const int *)(g_la.flag + 1), (int)g_la.done_total);
+            // mid: P top beside D, U top counted into flag[1]
+            hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
+                               (const int *)g_la.flag, base, info_dev);
+            GPR_HIP_TRY(wait(g_la.mid, bulk_first));
+            g_la.done_total += (unsigned)launch_narrow(g_la.mid, KB1, KB1, p, p, at(c1, c1), lda, 1, g_la.flag + 1);
+        } else {
+            // kernels of different streams do not overlap here (see pipe_probe_wait_kernel): same schedule, every hand-over
+            // an event -- D_K, then P top on mid, then U top on the main stream again
+            GPR_HIP_TRY(wait(st, mid_last));
+            hipLaunchKernelGGL((potrf_diag256_kernel<false, false>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
+                               (int *)nullptr, 0, (const int *)nullptr, 0);
+            GPR_HIP_TRY(wait(g_la.mid, mark(st)));
+            launch_panel(g_la.mid, p, lda, KB1, KB, wop, lop);
+            GPR_HIP_TRY(wait(st, mark(g_la.mid)));
+            GPR_HIP_TRY(wait(st, bulk_first));
+            launch_narrow(st, KB1, KB1, p, p, at(c1, c1), lda, 1);
+            GPR_HIP_TRY(wait(g_la.mid, mark(st)));                // (the rest of the panel reads the top rows; keeps mid behind U top too)
+            GPR_HIP_TRY(wait(g_la.mid, bulk_first));
+        }
         mid_last = mark(g_la.mid);
         if (Rrest <= 0) { bulk_first = nullptr; continue; }
         launch_panel(g_la.mid, at(c2, K0), lda, Rrest, KB, wop, lop);                          // P rest, U rest
