@@ -243,149 +243,187 @@ __device__ __forceinline__ void fm_lds_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &A, int blk, double (*smem)[32 * FM_LD]) {
+// One species block of one force point.  P0: native operands -> Psi rows; P1: numpy-eps operands -> prior variance.
+// Both products are formed in ONE pass over the rows: what is expensive per step is the staging of four rows (gathered
+// loads, the norm and the projection by DPP sums, three LDS round trips), and the two operand sets differ by scale
+// factors only (a~_eps = s a~, A'_eps = s (D/n - s^2 a~ proj), s = n / (n + 1e-8)).  The accumulators hold S = M + M^T
+// directly -- S_ab += A~_a^T A'_b + A'_a^T A~_b: an LDS operand tile serves as the A or the B operand of the MFMA alike
+// -- so a component needs three tiles (S_00, S_01, S_11) instead of the four of M, and both sets fit the register file.
+template <bool P0, bool P1>
+__device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int si, int zs, int r0, int r1, double *sm,
+                                                 const int *km, double (&dacc)[3]) {
+    const int lane = threadIdx.x & 63;
+    const int slot = lane >> 4, g = lane & 15;
+    double *opA0 = sm, *opB0 = sm + 4 * FM_LD, *opA1 = sm + 16 * FM_LD, *opB1 = sm + 20 * FM_LD;   // op?[row][k], opB?[q][row][k]
+    fm_d4 acc0[3][3], acc1[3][3];                               // [component q][tile 00, 01, 11]
+#pragma unroll
+    for (int q = 0; q < 3; q++)
+#pragma unroll
+        for (int t = 0; t < 3; t++) { acc0[q][t] = fm_d4{0.0, 0.0, 0.0, 0.0}; acc1[q][t] = fm_d4{0.0, 0.0, 0.0, 0.0}; }
+    // Row indices of up to 64 rows at a time sit in registers (lane j: row cb + j) and reach the staging lanes by
+    // shuffle; the x / dxdr values of the next four rows are requested before the current four are processed, so
+    // no dependent global load sits on the loop's critical path.
+    for (int cb = r0; cb < r1; cb += 64) {
+        int my_xs = -1, my_ds = -1;
+        {
+            const int rr = cb + lane;
+            if (rr < r1) {
+                my_xs = A.x_index ? A.x_index[rr] : rr;
+                my_ds = A.d_index ? A.d_index[rr] : rr;
+                if (my_xs < 0 || my_ds < 0 || A.ele[my_xs] != zs) { my_xs = -1; my_ds = -1; }   // absent or other species
+            }
+        }
+        const int cend = min(r1, cb + 64);
+        double nx0 = 0.0, nx1 = 0.0, ndv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        bool nok = false;
+#define FM_FETCH(RB)                                                                                       \
+        {   const int j_ = (RB) - cb + slot;                                                                \
+            const int xs_ = __shfl(my_xs, j_ & 63), ds_ = __shfl(my_ds, j_ & 63);                           \
+            nok = ((RB) + slot < cend) && xs_ >= 0;                                                         \
+            nx0 = 0.0; nx1 = 0.0;                                                                           \
+            _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) ndv[u_] = 0.0;                                 \
+            if (nok) {                                                                                      \
+                const double *xr_ = A.x + (size_t)xs_ * A.d;                                                \
+                if (g < A.d) nx0 = xr_[g];                                                                  \
+                if (g + 16 < A.d) nx1 = xr_[g + 16];                                                        \
+                const double *D_ = A.dxdr + (size_t)ds_ * A.d * 3;                                          \
+                _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) { const int el_ = g + 16 * u_; if (el_ < 3 * A.d) ndv[u_] = D_[el_]; } } }
+        FM_FETCH(cb)
+        for (int rb = cb; rb < cend; rb += 4) {
+            // ---- stage four rows: 16 lanes per row (values fetched one step ahead)
+            const bool ok = nok;
+            const double x0 = nx0, x1 = nx1;
+            double raw[6];
+#pragma unroll
+            for (int u = 0; u < 6; u++) raw[u] = ndv[u];
+            if (rb + 4 < cend) FM_FETCH(rb + 4)
+            const double n = sqrt(fm_row_sum16(x0 * x0 + x1 * x1));
+            // native: rows with |x| <= 1e-8 are skipped (dot_kernel.cpp); numpy-eps: norm + 1e-8, nothing skipped
+            const double inv = (ok && n > 0.0) ? 1.0 / n : 0.0;
+            const double m0 = (ok && n > 1e-8) ? 1.0 : 0.0;                   // native operands: the row counts or not
+            const double sc = n / (n + 1e-8), s2 = sc * sc;
+            const double a0 = x0 * inv, a1 = x1 * inv;
+            // a~ goes to LDS first: the lanes that hold dxdr element (k, c) fetch a~_k from there
+            opA1[slot * FM_LD + g] = a0;
+            opA1[slot * FM_LD + g + 16] = a1;
+            fm_lds_sync();
+            double dv[6], ak[6], pr[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                dv[u] = raw[u] * inv;                                        // zero beyond 3 d and for absent rows
+                ak[u] = (kk < 32) ? opA1[slot * FM_LD + kk] : 0.0;
+                const double t = ak[u] * dv[u];
+                pr[0] += (c == 0) ? t : 0.0; pr[1] += (c == 1) ? t : 0.0; pr[2] += (c == 2) ? t : 0.0;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; c++) pr[c] = fm_row_sum16(pr[c]);
+            fm_lds_sync();                                                   // every lane has its a~_k: the row may be overwritten
+            if (P0) { opA0[slot * FM_LD + g] = m0 * a0; opA0[slot * FM_LD + g + 16] = m0 * a1; }
+            if (P1) { opA1[slot * FM_LD + g] = sc * a0; opA1[slot * FM_LD + g + 16] = sc * a1; }
+            // A'_c = D/n - a~ proj_c  (native)  /  s (D/n - s^2 a~ proj_c)  (numpy-eps)
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
+                if (kk < 32) {
+                    const double prc = (c == 0) ? pr[0] : (c == 1 ? pr[1] : pr[2]);
+                    const double ap = ak[u] * prc;
+                    if (P0) opB0[(c * 4 + slot) * FM_LD + kk] = m0 * (dv[u] - ap);
+                    if (P1) opB1[(c * 4 + slot) * FM_LD + kk] = sc * (dv[u] - s2 * ap);
+                }
+            }
+            fm_lds_sync();
+            // ---- S_q += A~^T A'_q + A'_q^T A~ for these four rows (operand tile [k = row][16 columns], either role)
+            const int krow = lane >> 4, col = lane & 15;
+            if (P0) {
+                const double av0 = opA0[krow * FM_LD + col], av1 = opA0[krow * FM_LD + 16 + col];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const double b0 = opB0[(q * 4 + krow) * FM_LD + col], b1 = opB0[(q * 4 + krow) * FM_LD + 16 + col];
+                    acc0[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc0[q][0], 0, 0, 0);
+                    acc0[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av0, acc0[q][0], 0, 0, 0);
+                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc0[q][1], 0, 0, 0);
+                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av1, acc0[q][1], 0, 0, 0);
+                    acc0[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc0[q][2], 0, 0, 0);
+                    acc0[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av1, acc0[q][2], 0, 0, 0);
+                }
+            }
+            if (P1) {
+                const double av0 = opA1[krow * FM_LD + col], av1 = opA1[krow * FM_LD + 16 + col];
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    const double b0 = opB1[(q * 4 + krow) * FM_LD + col], b1 = opB1[(q * 4 + krow) * FM_LD + 16 + col];
+                    acc1[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc1[q][0], 0, 0, 0);
+                    acc1[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av0, acc1[q][0], 0, 0, 0);
+                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc1[q][1], 0, 0, 0);
+                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av1, acc1[q][1], 0, 0, 0);
+                    acc1[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc1[q][2], 0, 0, 0);
+                    acc1[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av1, acc1[q][2], 0, 0, 0);
+                }
+            }
+            fm_lds_sync();
+        }
+#undef FM_FETCH
+    }
+    // ---- vech(S_q) with sqrt(2) on the off-diagonal entries, through LDS (tile layout -> packed (k, m) order)
+#pragma unroll
+    for (int pass = 0; pass < 2; pass++) {
+        if ((pass == 0 && !P0) || (pass == 1 && !P1)) continue;
+        for (int q = 0; q < 3; q++) {
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int ra = (t == 2) ? 16 : 0, cbq = (t == 0) ? 0 : 16;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    sm[(ra + (lane >> 4) + 4 * r) * FM_LD + cbq + (lane & 15)] = (pass == 0) ? acc0[q][t][r] : acc1[q][t][r];
+            }
+            fm_lds_sync();
+            double part = 0.0;
+#pragma unroll
+            for (int t = 0; t < 9; t++) {
+                const int kmt = km[64 * t + lane];
+                if (kmt >= 0) {
+                    const int k = kmt >> 8, m = kmt & 255, e = lane + 64 * t;         // m <= k
+                    const double sv = (k >= 16 && m < 16) ? sm[m * FM_LD + k] : sm[k * FM_LD + m];
+                    if (pass == 0) A.out[(long long)(p * 3 + q) * A.ld + si * A.npair + e] = -((k == m) ? sv : 1.4142135623730951 * sv);
+                    else part += (k == m) ? sv * sv : 2.0 * sv * sv;
+                }
+            }
+            if (pass == 1) dacc[q] += part;
+            fm_lds_sync();
+        }
+    }
+}
+
+__device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &A, int blk, double (*smem)[32 * FM_LD], int (*skm)[9 * 64]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int p = blk * 4 + wave;
     if (p >= A.npts) return;                                    // wavefront-uniform; no block barriers below
     double *sm = smem[wave];
-    double *opA = sm, *opB = sm + 4 * FM_LD;                    // opA[row][k], opB[q][row][k]
     const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
-    const int slot = lane >> 4, g = lane & 15;
-    double dacc[3] = {0.0, 0.0, 0.0};                           // sum over species and (k, m) of (M_km + M_mk)^2, eps pass
-    // this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once
-    int km[9];
+    double dacc[3] = {0.0, 0.0, 0.0};                           // sum over species and (k, m) of (M_km + M_mk)^2, eps operands
+    // this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once (kept in LDS: nine registers
+    // decide between one and two wavefronts per SIMD)
+    int *km = skm[wave];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
         const int e = lane + 64 * t;
         int k = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((k + 1) * (k + 2) / 2 <= e) k++;
         while (k * (k + 1) / 2 > e) k--;
-        km[t] = (e < A.npair) ? ((k << 8) | (e - k * (k + 1) / 2)) : -1;
+        km[64 * t + lane] = (e < A.npair) ? ((k << 8) | (e - k * (k + 1) / 2)) : -1;
     }
     for (int q = 0; q < 3; q++) {                               // the constant column of force rows is zero
         double *o = A.out + (long long)(p * 3 + q) * A.ld;
         if (lane < A.ns) o[A.ns * A.npair + lane] = 0.0;
     }
-    for (int si = 0; si < A.ns + (A.diag ? A.nsx : 0); si++) {
-        const int zs = si < A.ns ? A.species[si] : A.species_x[si - A.ns];
-#pragma unroll 1
-        for (int pass = (si < A.ns ? 0 : 1); pass < (A.diag ? 2 : 1); pass++) {  // 0: native operands -> Psi; 1: numpy-eps -> diag
-            fm_d4 acc[3][2][2];
-#pragma unroll
-            for (int q = 0; q < 3; q++)
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++) acc[q][a][b] = fm_d4{0.0, 0.0, 0.0, 0.0};
-            // Row indices of up to 64 rows at a time sit in registers (lane j: row cb + j) and reach the staging lanes by
-            // shuffle; the x / dxdr values of the next four rows are requested before the current four are processed, so
-            // no dependent global load sits on the loop's critical path.
-            for (int cb = r0; cb < r1; cb += 64) {
-            int my_xs = -1, my_ds = -1;
-            {
-                const int rr = cb + lane;
-                if (rr < r1) {
-                    my_xs = A.x_index ? A.x_index[rr] : rr;
-                    my_ds = A.d_index ? A.d_index[rr] : rr;
-                    if (my_xs < 0 || my_ds < 0 || A.ele[my_xs] != zs) { my_xs = -1; my_ds = -1; }   // absent or other species
-                }
-            }
-            const int cend = min(r1, cb + 64);
-            double nx0 = 0.0, nx1 = 0.0, ndv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-            bool nok = false;
-#define FM_FETCH(RB)                                                                                       \
-            {   const int j_ = (RB) - cb + slot;                                                            \
-                const int xs_ = __shfl(my_xs, j_ & 63), ds_ = __shfl(my_ds, j_ & 63);                       \
-                nok = ((RB) + slot < cend) && xs_ >= 0;                                                     \
-                nx0 = 0.0; nx1 = 0.0;                                                                       \
-                _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) ndv[u_] = 0.0;                             \
-                if (nok) {                                                                                  \
-                    const double *xr_ = A.x + (size_t)xs_ * A.d;                                            \
-                    if (g < A.d) nx0 = xr_[g];                                                              \
-                    if (g + 16 < A.d) nx1 = xr_[g + 16];                                                    \
-                    const double *D_ = A.dxdr + (size_t)ds_ * A.d * 3;                                      \
-                    _Pragma("unroll") for (int u_ = 0; u_ < 6; u_++) { const int el_ = g + 16 * u_; if (el_ < 3 * A.d) ndv[u_] = D_[el_]; } } }
-            FM_FETCH(cb)
-            for (int rb = cb; rb < cend; rb += 4) {
-                // ---- stage four rows: 16 lanes per row (values fetched one step ahead)
-                const bool ok = nok;
-                const double x0 = nx0, x1 = nx1;
-                double raw[6];
-#pragma unroll
-                for (int u = 0; u < 6; u++) raw[u] = ndv[u];
-                if (rb + 4 < cend) FM_FETCH(rb + 4)
-                const double n = sqrt(fm_row_sum16(x0 * x0 + x1 * x1));
-                // native: rows with |x| <= 1e-8 are skipped (dot_kernel.cpp); numpy-eps: norm + 1e-8, nothing skipped
-                const bool live = ok && (pass == 1 || n > 1e-8);
-                const double inv = (live && n > 0.0) ? 1.0 / n : 0.0;
-                const double sc = (pass == 1) ? n / (n + 1e-8) : 1.0, s2 = sc * sc;
-                const double a0 = x0 * inv, a1 = x1 * inv;
-                // a~ goes to LDS first: the lanes that hold dxdr element (k, c) fetch a~_k from there
-                opA[slot * FM_LD + g] = sc * a0;
-                opA[slot * FM_LD + g + 16] = sc * a1;
-                fm_lds_sync();
-                double dv[6], ak[6], pr[3] = {0.0, 0.0, 0.0};
-                const double isc = (sc > 0.0) ? 1.0 / sc : 0.0;               // opA holds sc a~
-#pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
-                    dv[u] = raw[u] * inv;                                        // zero beyond 3 d and for rows that are not live
-                    ak[u] = (kk < 32) ? opA[slot * FM_LD + kk] * isc : 0.0;
-                    const double t = ak[u] * dv[u];
-                    pr[0] += (c == 0) ? t : 0.0; pr[1] += (c == 1) ? t : 0.0; pr[2] += (c == 2) ? t : 0.0;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; c++) pr[c] = fm_row_sum16(pr[c]);
-                // A'_c = sc (D/n - s2 a~ proj_c)
-#pragma unroll
-                for (int u = 0; u < 6; u++) {
-                    const int el = g + 16 * u, kk = el / 3, c = el - 3 * kk;
-                    if (kk < 32) {
-                        const double prc = (c == 0) ? pr[0] : (c == 1 ? pr[1] : pr[2]);
-                        opB[(c * 4 + slot) * FM_LD + kk] = sc * (dv[u] - s2 * ak[u] * prc);
-                    }
-                }
-                fm_lds_sync();
-                // ---- M_q += A~^T A'_q for these four rows: A operand [m = monomial index k][k = row], B [row][n]
-                const int krow = lane >> 4, col = lane & 15;
-                const double av0 = opA[krow * FM_LD + col], av1 = opA[krow * FM_LD + 16 + col];
-#pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    const double b0 = opB[(q * 4 + krow) * FM_LD + col], b1 = opB[(q * 4 + krow) * FM_LD + 16 + col];
-                    acc[q][0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc[q][0][0], 0, 0, 0);
-                    acc[q][0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc[q][0][1], 0, 0, 0);
-                    acc[q][1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b0, acc[q][1][0], 0, 0, 0);
-                    acc[q][1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc[q][1][1], 0, 0, 0);
-                }
-                fm_lds_sync();
-            }
-#undef FM_FETCH
-            }
-            // ---- S_q = M_q + M_q^T through a transpose buffer, vech with sqrt(2) on the off-diagonal entries
-            for (int q = 0; q < 3; q++) {
-#pragma unroll
-                for (int a = 0; a < 2; a++)
-#pragma unroll
-                    for (int b = 0; b < 2; b++)
-#pragma unroll
-                        for (int r = 0; r < 4; r++)
-                            sm[(16 * a + (lane >> 4) + 4 * r) * FM_LD + 16 * b + (lane & 15)] = acc[q][a][b][r];
-                fm_lds_sync();
-                double part = 0.0;
-#pragma unroll
-                for (int t = 0; t < 9; t++) {
-                    if (km[t] >= 0) {
-                        const int k = km[t] >> 8, m = km[t] & 255, e = lane + 64 * t;
-                        const double sv = sm[k * FM_LD + m] + sm[m * FM_LD + k];
-                        if (pass == 0) A.out[(long long)(p * 3 + q) * A.ld + si * A.npair + e] = -((k == m) ? sv : 1.4142135623730951 * sv);
-                        else part += (k == m) ? sv * sv : 2.0 * sv * sv;
-                    }
-                }
-                if (pass == 1) dacc[q] += part;
-                fm_lds_sync();
-            }
-        }
+    for (int si = 0; si < A.ns; si++) {                         // species of the model: Psi rows (+ their share of the prior variance)
+        if (A.diag) fm_species_block<true, true>(A, p, si, A.species[si], r0, r1, sm, km, dacc);
+        else fm_species_block<true, false>(A, p, si, A.species[si], r0, r1, sm, km, dacc);
     }
+    if (A.diag)
+        for (int sx = 0; sx < A.nsx; sx++)                      // species the model does not know: prior variance only
+            fm_species_block<false, true>(A, p, A.ns + sx, A.species_x[sx], r0, r1, sm, km, dacc);
     if (A.diag) {
 #pragma unroll
         for (int q = 0; q < 3; q++) {
@@ -399,7 +437,8 @@ __device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &
 
 __global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_args A) {
     __shared__ double smem[4][32 * FM_LD];                     // per wavefront: operands of one step / transpose buffer
-    dot2_force_features_mfma_body(A, blockIdx.x, smem);
+    __shared__ int skm[4][9 * 64];
+    dot2_force_features_mfma_body(A, blockIdx.x, smem, skm);
 }
 
 // energy-point feature rows with 256 threads (thread t owns monomials t, t + 256, t + 512): the block role of the
@@ -480,10 +519,11 @@ __device__ __forceinline__ void dot2_features_direct256_body(const dfeat_args &A
 // point.  The three roles have nothing in common but their inputs; side by side they fill the chip where three
 // launches in a row each left most of it idle (64 energy points = 64 workgroups).
 template <int NS>
-__global__ void __launch_bounds__(256) dot2_features_ef_kernel(dfeat_args AF, dfeat_args AE, int nblkF) {
+__global__ void __launch_bounds__(256, 2) dot2_features_ef_kernel(dfeat_args AF, dfeat_args AE, int nblkF) {
     __shared__ double smem[4][32 * FM_LD];
+    __shared__ int skm[4][9 * 64];
     const int b = blockIdx.x;
-    if (b < nblkF) dot2_force_features_mfma_body(AF, b, smem);
+    if (b < nblkF) dot2_force_features_mfma_body(AF, b, smem, skm);
     else if (b < nblkF + AE.npts) dot2_features_direct256_body<NS>(AE, b - nblkF, &smem[0][0], (int *)&smem[1][0]);
     else dot2_diag_ee_body(AE, b - nblkF - AE.npts, &smem[0][0]);
 }
