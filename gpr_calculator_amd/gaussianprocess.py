@@ -511,7 +511,9 @@ class GP():
     #   M = sigma^4 Psi^T (K + D)^-1 Psi = sigma^2 (I - G^-1)
     # -- the same w and M the dense route derives from L and alpha (_weight_space), without forming K at all.
     weight_space_fit = True
-    dist_chol_min_n = 16384     # several ranks: matrices from this size on are factored with the rows spread over them
+    # several ranks: matrices from this size on are factored with the rows spread over them (GPR_DIST_CHOL_MIN_N overrides:
+    # rehearsals of the block-cyclic route at small sizes)
+    dist_chol_min_n = int(os.environ.get("GPR_DIST_CHOL_MIN_N", "16384"))
 
     def _ws_share(self, train_x, species, noise_e, noise_f):
         """This rank's share of the weight-space system: (S, y~, rs, NE_local) with S = D^-1/2 sigma Psi for the rows of
