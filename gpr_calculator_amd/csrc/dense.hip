@@ -25,6 +25,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
     if ((lower_only & 1) && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
     if (lower_only & 2) k = min(k, bm0 + BM);                // op(A) lower triangular: zero beyond the row block
     if (lower_only & 4) k = min(k, bn0 + BN);                // op(B) = B^T with B lower triangular: zero beyond the column block
+    if (lower_only & 16) {                                   // op(B) = B lower triangular: zero before the column block
+        const int kbeg = (bn0 / BK) * BK;
+        A += TA ? (long long)kbeg * lda : (long long)kbeg; B += TB ? (long long)kbeg : (long long)kbeg * ldb; k -= kbeg;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
     d4 acc[2][2];
@@ -124,6 +128,10 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
     if ((lower_only & 1) && bn0 > bm0 + GM - 1) return;
     if (lower_only & 2) k = min(k, bm0 + GM);
     if (lower_only & 4) k = min(k, bn0 + GN);
+    if (lower_only & 16) {                                       // op(B) = B lower triangular: zero before the column block
+        const int kbeg = (bn0 / GK) * GK;
+        A += TA ? (long long)kbeg * lda : (long long)kbeg; B += TB ? (long long)kbeg : (long long)kbeg * ldb; k -= kbeg;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     d4 acc[4][4];

@@ -272,7 +272,11 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
 template <bool FULL, bool PIPE>
 __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict__ p, long long lda, int rows, int kb_,
                                                               const double *__restrict__ wop,
-                                                              const double *__restrict__ lop, const int *flag, int base, int *info) {
+                                                              const double *__restrict__ lop, const int *flag, int base, int *info,
+                                                              long long p_batch, long long ops_batch) {
+    // blockIdx.y: independent problems (gpr_trtri_lower inverts all diagonal blocks at once), slab / operand tiles
+    // p_batch / ops_batch doubles apart
+    p += (long long)blockIdx.y * p_batch; wop += (long long)blockIdx.y * ops_batch; lop += (long long)blockIdx.y * ops_batch;
     __shared__ double ops[2][16 * TILE_DOUBLES];             // [buffer][slot = j - k][operand order]; slot 0 = W_k
     __shared__ double xk[2][TILE_DOUBLES];                   // X_k^T of the stage, B-operand order
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -523,8 +527,8 @@ struct lookahead_ctx {
 static lookahead_ctx g_la;
 
 static void launch_panel(hipStream_t st, double *p, long long lda, int rows, int kb, const double *wop, const double *lop) {
-    if (kb == DB) hipLaunchKernelGGL((potrf_panel256_kernel<true, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr);
-    else hipLaunchKernelGGL((potrf_panel256_kernel<false, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr);
+    if (kb == DB) hipLaunchKernelGGL((potrf_panel256_kernel<true, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr, 0LL, 0LL);
+    else hipLaunchKernelGGL((potrf_panel256_kernel<false, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr, 0LL, 0LL);
 }
 // C[m x n] -= A[m x 256] B[n x 256]^T
 static int launch_narrow(hipStream_t st, int m, int n, const double *A, const double *B, double *C, long long lda, int lower_only,
@@ -601,7 +605,7 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
                                g_la.flag, base, (const int *)(g_la.flag + 1), (int)g_la.done_total);
             // mid: P top beside D, U top counted into flag[1]
             hipLaunchKernelGGL((potrf_panel256_kernel<true, true>), dim3((KB1 + DT - 1) / DT), dim3(256), 0, g_la.mid, p, lda, KB1, KB, wop, lop,
-                               (const int *)g_la.flag, base, info_dev);
+                               (const int *)g_la.flag, base, info_dev, 0LL, 0LL);
             GPR_HIP_TRY(wait(g_la.mid, bulk_first));
             g_la.done_total += (unsigned)launch_narrow(g_la.mid, KB1, KB1, p, p, at(c1, c1), lda, 1, g_la.flag + 1);
         } else {
@@ -691,20 +695,32 @@ extern "C" int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, d
     return GPR_OK;
 }
 
-// X = L^-1 for a lower-triangular L (n x n, e.g. from gpr_potrf_lower), X lower triangular with zeros above the
-// diagonal.  Block rows of 256: the inverse of a diagonal block is the panel kernel applied to the identity
-// (I L_kk^-T, transposed while it is stored), the blocks to its left are  X[k, :k] = -L_kk^-1 (L[k, :k] X[:k, :k])  --
-// two products on the matrix cores per block row instead of a 64-wide substitution sweep over all n columns.
-__global__ void __launch_bounds__(256) trtri_store_kernel(int kb, const double *__restrict__ t, double *__restrict__ x, long long ldx) {
-    // x[i][j] = t[j][i] (t = L_kk^-T, kb x kb, ld DB); zero above the diagonal
+// X = L^-1 for a lower-triangular L (n x n, e.g. from gpr_potrf_lower): the lower triangle of X and the zeros above the
+// diagonal inside the 256 x 256 diagonal blocks are written; the blocks above them are left as they are (callers
+// hand over a zeroed matrix).
+//   1. all diagonal blocks at once: operand tiles of each block (tri_tiles256_kernel), the panel kernel applied to the
+//      identity (I L_kk^-T), stored transposed.
+//   2. recursively by halves:  X21 = -X22 (L21 X11)  -- two products on the matrix cores whose three dimensions are all
+//      n / 2, n / 4, ...: the top levels hold most of the work and run as large GEMMs (block rows of 256 against all n
+//      columns, the first form of this routine, were 2 x n / 128 workgroups per launch: 14 ms at n = 6063).  Both products
+//      skip the zero halves of their triangular operands.
+__global__ void __launch_bounds__(256) trtri_store_kernel(int n, const double *__restrict__ t, double *__restrict__ x, long long ldx) {
+    // diagonal block blockIdx.z: x[i][j] = t[j][i] (t = L_kk^-T, ld DB); zero above the diagonal
+    const int K0 = blockIdx.z * DB, kb = min(DB, n - K0);
+    const double *tb = t + (size_t)blockIdx.z * DB * DB;
+    double *xb = x + (long long)K0 * ldx + K0;
     const int i = blockIdx.x * 16 + (threadIdx.x >> 4), j = blockIdx.y * 16 + (threadIdx.x & 15);
-    if (i < kb && j < kb) x[(long long)i * ldx + j] = (j <= i) ? t[(size_t)j * DB + i] : 0.0;
+    if (i < kb && j < kb) xb[(long long)i * ldx + j] = (j <= i) ? tb[(size_t)j * DB + i] : 0.0;
 }
-// operand tiles (as the diagonal kernel emits them) of an already factored kb x kb lower-triangular block: W_k = inverse of
-// its k-th 16 x 16 diagonal tile (one wavefront per tile: the tiles are independent), L_jk copied into operand order
-__global__ void __launch_bounds__(1024) tri_tiles256_kernel(const double *__restrict__ l, long long ldl, int kb,
-                                                             double *__restrict__ wop, double *__restrict__ lop) {
+// operand tiles (as the diagonal kernel emits them) of already factored lower-triangular diagonal blocks (block
+// blockIdx.x of an n x n matrix): W_k = inverse of its k-th 16 x 16 diagonal tile (one wavefront per tile: the tiles are
+// independent), L_jk copied into operand order
+__global__ void __launch_bounds__(1024) tri_tiles256_kernel(const double *__restrict__ l, long long ldl, int n,
+                                                             double *__restrict__ ops_all) {
     __shared__ double W[16][16][17];
+    const int K0 = blockIdx.x * DB, kb = min(DB, n - K0);
+    l += (long long)K0 * ldl + K0;
+    double *wop = ops_all + (size_t)blockIdx.x * (16 + NTILE) * TILE_DOUBLES, *lop = wop + 16 * TILE_DOUBLES;
     const int tid = threadIdx.x, lane = tid & 63, k = tid >> 6, lr = lane & 15, lq = lane >> 4;
     const int nt = (kb + DT - 1) / DT;
     if (k < nt && lane < 16) {
@@ -741,36 +757,50 @@ __global__ void __launch_bounds__(1024) tri_tiles256_kernel(const double *__rest
     }
 }
 
-__global__ void __launch_bounds__(256) trtri_eye_kernel(double *t) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e < DB * DB) t[e] = (e / DB == e % DB) ? 1.0 : 0.0;
+__global__ void __launch_bounds__(256) trtri_eye_kernel(double *t, size_t total) {      // identities, one per diagonal block
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < total) { const size_t w = e % ((size_t)DB * DB); t[e] = (w / DB == w % DB) ? 1.0 : 0.0; }
+}
+
+// X[rows, rows] for the block rows [b0, b1) whose diagonal blocks are already inverted
+static int trtri_halves(hipStream_t st, int n, const double *l, long long ldl, double *x, long long ldx, int b0, int b1, double *tmp) {
+    if (b1 - b0 < 2) return GPR_OK;
+    const int mid = b0 + (b1 - b0 + 1) / 2;
+    int rc = trtri_halves(st, n, l, ldl, x, ldx, b0, mid, tmp);
+    if (rc == GPR_OK) rc = trtri_halves(st, n, l, ldl, x, ldx, mid, b1, tmp);
+    if (rc) return rc;
+    const int r0 = b0 * DB, r1 = mid * DB, r2 = std::min(b1 * DB, n), m = r2 - r1, k = r1 - r0;
+    // tmp[m, k] = L21 X11 (X11 lower triangular: the k range of a column block starts at its own rows)
+    rc = gpr_gemm_internal(st, 0, 0, m, k, k, 1.0, l + (long long)r1 * ldl + r0, ldl, x + (long long)r0 * ldx + r0, ldx, 0.0, tmp, k, 16);
+    if (rc) return rc;
+    // X21 = -X22 tmp (X22 lower triangular: the k range of a row block ends at its own rows)
+    return gpr_gemm_internal(st, 0, 0, m, k, m, -1.0, x + (long long)r1 * ldx + r1, ldx, tmp, k, 0.0, x + (long long)r1 * ldx + r0, ldx, 2);
 }
 
 extern "C" int gpr_trtri_lower(void *stream, int n, const double *l, long long ldl, double *x, long long ldx) {
     hipStream_t st = (hipStream_t)stream;
     GPR_REQUIRE(n >= 0 && (n == 0 || (l && x)) && ldl >= n && ldx >= n, "gpr_trtri_lower: bad arguments");
     if (n == 0) return GPR_OK;
+    const int nblk = (n + DB - 1) / DB, nfull = n / DB;
+    const size_t ops = (size_t)(16 + NTILE) * TILE_DOUBLES, half = (size_t)((nblk + 1) / 2) * DB;
     void *scratch;
-    const size_t ops = (size_t)(16 + NTILE) * TILE_DOUBLES;
-    int rc = gpr_dev_alloc(&scratch, (ops + (size_t)DB * DB + (size_t)DB * n) * sizeof(double), st);
+    int rc = gpr_dev_alloc(&scratch, ((size_t)nblk * (ops + (size_t)DB * DB) + half * half) * sizeof(double), st);
     if (rc) return rc;
-    double *wop = (double *)scratch, *lop = wop + 16 * TILE_DOUBLES, *eye = wop + ops, *tmp = eye + DB * DB;
-    for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB) {
-        const int KB = (n - K0 < DB) ? n - K0 : DB;
-        hipLaunchKernelGGL(tri_tiles256_kernel, dim3(1), dim3(1024), 0, st, l + (long long)K0 * ldl + K0, ldl, KB, wop, lop);
-        hipLaunchKernelGGL(trtri_eye_kernel, dim3(DB), dim3(256), 0, st, eye);
-        launch_panel(st, eye, (long long)DB, DB, KB, wop, lop);
-        // eye now holds L_kk^-T (rows / columns < KB); X[k, k] = its transpose
-        double *xkk = x + (long long)K0 * ldx + K0;
-        hipLaunchKernelGGL(trtri_store_kernel, dim3((KB + 15) / 16, (KB + 15) / 16), dim3(256), 0, st, KB, eye, xkk, ldx);
-        if (K0 > 0) {
-            // tmp[KB, K0] = L[k, :k] X[:k, :k] (X lower triangular: k range of a column block starts at its own rows; the
-            // tiled product simply runs over all of them), then X[k, :k] = -X[k, k] tmp
-            rc = gpr_gemm_internal(st, 0, 0, KB, K0, K0, 1.0, l + (long long)K0 * ldl, ldl, x, ldx, 0.0, tmp, n, 0);
-            if (rc) break;
-            rc = gpr_gemm_internal(st, 0, 0, KB, K0, KB, -1.0, xkk, ldx, tmp, n, 0.0, x + (long long)K0 * ldx, ldx, 0);
-        }
-    }
+    double *ops_all = (double *)scratch, *eye = ops_all + (size_t)nblk * ops, *tmp = eye + (size_t)nblk * DB * DB;
+    // 1. diagonal blocks: eye[b] <- L_bb^-T, X[b, b] = its transpose
+    hipLaunchKernelGGL(tri_tiles256_kernel, dim3(nblk), dim3(1024), 0, st, l, ldl, n, ops_all);
+    const size_t eyes = (size_t)nblk * DB * DB;
+    hipLaunchKernelGGL(trtri_eye_kernel, dim3((unsigned)((eyes + 255) / 256)), dim3(256), 0, st, eye, eyes);
+    if (nfull > 0)
+        hipLaunchKernelGGL((potrf_panel256_kernel<true, false>), dim3(DB / DT, nfull), dim3(256), 0, st, eye, (long long)DB, DB, DB, ops_all,
+                           ops_all + 16 * TILE_DOUBLES, (const int *)nullptr, 0, (int *)nullptr, (long long)DB * DB, (long long)ops);
+    if (nblk > nfull)
+        hipLaunchKernelGGL((potrf_panel256_kernel<false, false>), dim3(DB / DT), dim3(256), 0, st, eye + (size_t)nfull * DB * DB, (long long)DB, DB,
+                           n - nfull * DB, ops_all + (size_t)nfull * ops, ops_all + (size_t)nfull * ops + 16 * TILE_DOUBLES, (const int *)nullptr, 0,
+                           (int *)nullptr, 0LL, 0LL);
+    hipLaunchKernelGGL(trtri_store_kernel, dim3(DB / 16, DB / 16, nblk), dim3(256), 0, st, n, eye, x, ldx);
+    // 2. the blocks below the diagonal, by halves
+    rc = trtri_halves(st, n, l, ldl, x, ldx, 0, nblk, tmp);
     const hipError_t e = hipGetLastError();
     const int rc2 = gpr_dev_free(scratch, st);
     if (e != hipSuccess) { gpr_set_error("gpr_trtri_lower launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
