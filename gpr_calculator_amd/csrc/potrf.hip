@@ -93,7 +93,20 @@ constexpr int TSLOTS = (NTILE + TWAVES - 1) / TWAVES;   // 16 tiles per wavefron
 __device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-constexpr int PIPE_MAX_POLLS = 1 << 20;                  // ~1 s: a consumer whose producer never ran gives up instead of hanging the GPU
+constexpr int PIPE_MAX_POLLS = 1 << 23;                  // ~10 s: a consumer whose producer never ran gives up instead of hanging the GPU
+// ... and says so in abort word `flag[4]`, which every later poll of the same factorisation looks at first: one missing
+// producer costs one time-out, not one per kernel.  poll_until: lane-0 helper, true = the counter got there.
+__device__ __forceinline__ bool poll_until(const int *ctr, int target, const int *abort_word) {
+    int polls = 0;
+    while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+        if (++polls >= PIPE_MAX_POLLS || ((polls & 1023) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(const_cast<int *>(abort_word), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(3);
+    }
+    return true;
+}
 
 // TRACE: debug instance (tools/potrf_stage_trace.py) that stamps the phases of every stage with the 100 MHz clock
 // PUB:   the operand tiles are published stage by stage through `flag` (see above)
@@ -111,14 +124,7 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
     const int nt = (kb + DT - 1) / DT;
     const int lr = lane & 15, lq = lane >> 4;
     if (PUB && wait_ctr) {       // the block is still receiving its last update from a kernel running beside this one
-        if (tid == 0) {
-            int polls = 0;
-            while ((int)(__hip_atomic_load(wait_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - wait_target) < 0 && polls < PIPE_MAX_POLLS) {
-                __builtin_amdgcn_s_sleep(2);
-                polls++;
-            }
-            if (polls >= PIPE_MAX_POLLS && info) atomicExch(info, -1);
-        }
+        if (tid == 0 && !poll_until(wait_ctr, wait_target, wait_ctr + 3) && info) atomicExch(info, -1);
         __syncthreads();
     }
     if (wave == 0) {
@@ -301,14 +307,7 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
     __shared__ int gave_up;
     auto await_stages = [&](int done) {                      // until `done` stages of the diagonal block are published
         if (!PIPE) return;
-        if (tid == 0) {
-            int polls = 0;
-            while ((int)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - (base + done)) < 0 && polls < PIPE_MAX_POLLS) {
-                __builtin_amdgcn_s_sleep(4);
-                polls++;
-            }
-            gave_up = polls >= PIPE_MAX_POLLS;
-        }
+        if (tid == 0) gave_up = !poll_until(flag, base + done, flag + 4);
         __syncthreads();
     };
     await_stages(nt < 2 ? nt : 2);
@@ -508,7 +507,7 @@ struct lookahead_ctx {
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
         if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
         if (hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; return GPR_ERR_HIP; }
-        if (hipMalloc((void **)&flag, 4 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 4 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
+        if (hipMalloc((void **)&flag, 8 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 8 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
         {   // flag[2]: probe flag, flag[3]: what the consumer saw
             int seen = 0;
             hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, mid, (const int *)(flag + 2), flag + 3);
@@ -553,7 +552,7 @@ static int launch_narrow(hipStream_t st, int m, int n, const double *A, const do
 // is headroom).
 // D_K is always enqueued before the P_K top that polls its counter, and depends on nothing enqueued after it, so a
 // polling kernel cannot starve its producer; if a producer never runs (a failed launch) the consumer gives up after
-// PIPE_MAX_POLLS and reports info = -1.
+// PIPE_MAX_POLLS, reports info = -1 and raises the abort word (flag[4]) that ends every later poll of the call at once.
 // N = 6063: 14 ms (round 1: 64-wide steps) -> 5.4 ms (256-wide steps, two streams, tiled narrow GEMMs) -> 4.5 ms
 // (syrk_narrow_kernel) -> 4.2 ms (top panel beside the diagonal block, polled hand-overs).  Tried on top of this and
 // slower (4.8 ms): the tail of the panel (rows beyond block K + 2) on a fourth stream -- every hop between streams costs
@@ -575,6 +574,7 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     auto mark = [&](hipStream_t s) { hipEvent_t e = g_la.take(); return hipEventRecord(e, s) == hipSuccess ? e : nullptr; };
     hipEvent_t bulk_first = nullptr, bulk_last = nullptr, mid_last = nullptr;
     if (la) {                                                // the other streams start behind what the caller queued
+        GPR_HIP_TRY(hipMemsetAsync(g_la.flag + 4, 0, sizeof(int), st));      // abort word of the polls
         hipEvent_t e0 = mark(st);
         GPR_HIP_TRY(wait(g_la.mid, e0)); GPR_HIP_TRY(wait(g_la.side, e0));
     }
