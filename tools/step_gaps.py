@@ -1,15 +1,15 @@
-"""Device timeline of the last prediction steps in a rocprofv3 kernel trace: per step (from the count pass of the
-neighbour search to the status kernel) the span on the device, the summed kernel durations and the idle time between
-kernels.  usage: python tools/step_gaps.py <kernel_trace.csv> [nsteps]"""
+"""Device timeline of the last prediction steps in a rocprofv3 kernel trace of bench.py: per step (from the geometry
+upload kernel to the combine launch of the tail) the span on the device, the summed kernel durations and the idle time
+between kernels.  usage: python tools/step_gaps.py <kernel_trace.csv> [nsteps]"""
 import csv
 import sys
 
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(sys.argv[1]))))
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-ends = [i for i, r in enumerate(rows) if "nbr_info_kernel" in r[2] or "nbr_status_kernel" in r[2]]
+ends = [i for i, r in enumerate(rows) if "ws_tail_combine_kernel" in r[2]]
 for e in ends[-nsteps:]:
     s = e
-    while s > 0 and "nbr_centre_kernel<false>" not in rows[s][2].replace(" ", "") and "nbr_centre_kernel<0>" not in rows[s][2]:
+    while s > 0 and "nbr_upload_kernel" not in rows[s][2]:
         s -= 1
     seg = rows[s:e + 1]
     span = seg[-1][1] - seg[0][0]
