@@ -343,7 +343,9 @@ int gpr_gemm_nt_cyclic_lower(void *stream, int m, int n, int k, double alpha, co
                              const double *b, long long ldb, double beta, double *c, long long ldc, int nb, int nranks,
                              int rank, int lb0, int col0);
 int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, double *dinv);
-/* X = L^-1 of a lower-triangular L (zeros above the diagonal of X), 256-row blocks on the matrix cores */
+/* X = L^-1 of a lower-triangular L on the matrix cores (diagonal blocks of 256 rows at once, the blocks below them
+ * recursively by halves).  Written: the lower triangle of X and the zeros above the diagonal inside the 256 x 256 diagonal
+ * blocks; the blocks above those are left untouched -- hand over a zeroed X. */
 int gpr_trtri_lower(void *stream, int n, const double *l, long long ldl, double *x, long long ldx);
 int gpr_mirror_lower(void *stream, int n, double *a, long long lda);
 /* Solve L X = B (trans = 0) or L^T X = B (trans = 1) in place; B is n x nrhs row-major, ldb. */
