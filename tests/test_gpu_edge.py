@@ -322,3 +322,29 @@ def test_save_and_load_reproduce_the_model(kind, tmp_path):
     e_lj = gp.base_potential.calculate(rows[0]["atoms"])[0]
     got = asedb.read_db(db)[0]["key_value_pairs"]["dft_energy"]
     assert abs(got - (rows[0]["data"]["energy"] + e_lj) / len(rows[0]["atoms"])) < 1e-12
+
+
+def test_shared_shift_tables_and_positions_outside_the_cell():
+    """Structures that share the cell of their predecessor share its image table on the device (runs of equal cells in
+    any order in the batch), and atoms outside the cell -- by whole lattice vectors, or sitting exactly on a face --
+    are wrapped the slow, exact way: predictions are those of the structures one at a time."""
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model("Dot")
+    a = [fcc_cell(seed=20 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(3)]          # equal cells
+    b = fcc_cell(seed=30, reps=1, species=(46, 78), sigma=0.08)
+    b.cell = b.cell * 1.05                                                                        # another cell in between
+    b.positions = b.positions * 1.05
+    far = fcc_cell(seed=22, reps=1, species=(46, 78), sigma=0.08)                                 # a[2] again, displaced
+    far.positions = far.positions + 2.0 * far.cell[0] - 3.0 * far.cell[1] + far.cell[2]
+    far.positions[1] = far.cell[0] * 1.0                                                          # exactly on a lattice point
+    edge = fcc_cell(seed=22, reps=1, species=(46, 78), sigma=0.08)
+    edge.positions[1] = 0.0
+    batch = [a[0], a[1], b, a[2], far, edge]
+    Es, Fs, Es_std, Fs_std = gp.predict_structures(batch, return_std=True)
+    gp.device_single = False
+    for k, s in enumerate(batch):
+        e1, f1, _, es1, fs1 = gp.predict_structure(s, stress=False, return_std=True)
+        assert abs(Es[k] - e1) < 1e-8 * max(1.0, abs(e1)) and np.abs(Fs[k] - f1).max() < 1e-8
+        assert abs(Es_std[k] - es1) < 1e-7 and np.abs(Fs_std[k] - fs1).max() < 1e-7
+    # the displaced copy is the same crystal: same energy, same forces
+    assert abs(Es[4] - Es[5]) < 1e-9 * max(1.0, abs(Es[5])) and np.abs(Fs[4] - Fs[5]).max() < 1e-9
