@@ -53,10 +53,13 @@ struct nbr_geom {
     int pb[3] = {0, 0, 0};
 };
 
-static void nbr_geometry(int n, const double *positions, const double *cell, const int *pb, double rcut, nbr_geom &g) {
+// dst: where the wrapped positions go (3 n doubles); NULL: into g.wrapped
+static void nbr_geometry(int n, const double *positions, const double *cell, const int *pb, double rcut, nbr_geom &g,
+                         double *dst = nullptr) {
     const bool same = g.have_cell && !g.singular && memcmp(g.cell, cell, sizeof(g.cell)) == 0 && g.pb[0] == pb[0] &&
                       g.pb[1] == pb[1] && g.pb[2] == pb[2];
-    g.wrapped.assign(positions, positions + 3 * (size_t)n);
+    if (!dst) { g.wrapped.resize(3 * (size_t)n); dst = g.wrapped.data(); }
+    memcpy(dst, positions, 3 * (size_t)n * sizeof(double));
     g.reused = same;
     if (!same) {
         g.shifts.clear(); g.nimg = 0; g.zero_img = 0; g.singular = false;
@@ -84,24 +87,29 @@ static void nbr_geometry(int n, const double *positions, const double *cell, con
                     g.nimg++;
                 }
     }
-    if (g.any)
+    if (g.any) {
+        // quick test with the rows of the inverse cell (within a few ulp of the quotients below): every periodic
+        // fractional coordinate safely inside [0, 1) -> nothing to wrap, no division
+        double c[3][3];
+        for (int k = 0; k < 3; k++)
+            for (int q = 0; q < 3; q++) c[k][q] = g.perp[k][q] * g.inv_det;
+        const double lo[3] = {pb[0] ? 1e-9 : -1e300, pb[1] ? 1e-9 : -1e300, pb[2] ? 1e-9 : -1e300};
+        const double hi[3] = {pb[0] ? 1.0 - 1e-9 : 1e300, pb[1] ? 1.0 - 1e-9 : 1e300, pb[2] ? 1.0 - 1e-9 : 1e300};
         for (int i = 0; i < n; i++) {
-            double *p = &g.wrapped[3 * i];
+            double *p = dst + 3 * i;
+            const double q0 = p[0] * c[0][0] + p[1] * c[0][1] + p[2] * c[0][2];
+            const double q1 = p[0] * c[1][0] + p[1] * c[1][1] + p[2] * c[1][2];
+            const double q2 = p[0] * c[2][0] + p[1] * c[2][1] + p[2] * c[2][2];
+            if (q0 > lo[0] && q0 < hi[0] && q1 > lo[1] && q1 < hi[1] && q2 > lo[2] && q2 < hi[2]) continue;
             double f[3];
-            bool inside = true;                  // every periodic fractional coordinate safely inside [0, 1): nothing to wrap
-            for (int k = 0; k < 3; k++) {
-                f[k] = p[0] * g.perp[k][0] + p[1] * g.perp[k][1] + p[2] * g.perp[k][2];
-                const double q = f[k] * g.inv_det;                   // within 2 ulp of the quotient: decides unless q is at an edge
-                inside = inside && (!pb[k] || (q > 1e-9 && q < 1.0 - 1e-9));
-            }
-            if (inside) continue;
-            for (int k = 0; k < 3; k++) f[k] = f[k] / g.det;         // the quotient itself, as before
+            for (int k = 0; k < 3; k++) f[k] = (p[0] * g.perp[k][0] + p[1] * g.perp[k][1] + p[2] * g.perp[k][2]) / g.det;   // the quotient itself
             for (int k = 0; k < 3; k++)
                 if (pb[k]) {
                     const double fl = std::floor(f[k]);
-                    for (int c = 0; c < 3; c++) p[c] -= fl * cell[3 * k + c];
+                    for (int cc = 0; cc < 3; cc++) p[cc] -= fl * cell[3 * k + cc];
                 }
         }
+    }
 }
 
 // per-structure result (structure-local pair / row numbering), merged afterwards
@@ -396,19 +404,17 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     const int natoms = nstruct ? atom0[nstruct] : 0;
     // host: wrap positions, image tables; one blob [wpos | shifts | sinfo | numbers | sid]
     std::vector<nbr_sinfo> sinfo(nstruct);
-    std::vector<double> wpos, shifts;
-    wpos.reserve(3 * (size_t)natoms);
+    std::vector<double> wpos(3 * (size_t)natoms), shifts;
     std::vector<int> sid(natoms);
     nbr_geom g;
     for (int s = 0; s < nstruct; s++) {
         const int n = atom0[s + 1] - atom0[s];
         GPR_REQUIRE(n >= 0, "gpr_nbr_build_device: atom0 not ascending at structure %d", s);
-        nbr_geometry(n, positions + 3 * (size_t)atom0[s], cells + 9 * s, pbc + 3 * s, rcut, g);
+        nbr_geometry(n, positions + 3 * (size_t)atom0[s], cells + 9 * s, pbc + 3 * s, rcut, g, wpos.data() + 3 * (size_t)atom0[s]);
         if (g.singular) { gpr_set_error("gpr_nbr_build_device: periodic structure %d has a singular cell", s); return GPR_ERR_ARG; }
         // structures with the cell and pbc of their predecessor (a band of images) share its shift table
         const int img0 = (g.reused && s > 0) ? sinfo[s - 1].img0 : (int)(shifts.size() / 3);
         sinfo[s] = nbr_sinfo{atom0[s], n, img0, g.nimg, g.zero_img, 0};
-        wpos.insert(wpos.end(), g.wrapped.begin(), g.wrapped.end());
         if (!(g.reused && s > 0)) shifts.insert(shifts.end(), g.shifts.begin(), g.shifts.end());
         for (int k = 0; k < n; k++) sid[atom0[s] + k] = s;
     }
