@@ -48,6 +48,7 @@ _L1_SIGNATURES = {
     "gpr_potrf_lower_dinv": ([_vp, _i, _vp, _ll, _vp, _vp], _i),
     "gpr_trsm_lower_dinv": ([_vp, _i, _i, _i, _vp, _ll, _vp, _vp, _ll], _i),
     "gpr_gemm": ([_vp, _i, _i, _i, _i, _i, _d, _vp, _ll, _vp, _ll, _d, _vp, _ll], _i),
+    "gpr_xtx_lower": ([_vp, _i, _vp, _ll, _vp, _ll], _i),
     "gpr_dot2_session_create": ([C.POINTER(_vp), _vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, c_int_p, _d, _d, _vp, _vp, _vp, _i], _i),
     "gpr_dot2_session_predict": ([_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "gpr_dot2_session_set_hint": ([_vp, _d, _d], _i),

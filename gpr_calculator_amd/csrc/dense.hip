@@ -25,8 +25,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
     if ((lower_only & 1) && bn0 > bm0 + BM - 1) return;      // tile strictly above the diagonal
     if (lower_only & 2) k = min(k, bm0 + BM);                // op(A) lower triangular: zero beyond the row block
     if (lower_only & 4) k = min(k, bn0 + BN);                // op(B) = B^T with B lower triangular: zero beyond the column block
-    if (lower_only & 16) {                                   // op(B) = B lower triangular: zero before the column block
-        const int kbeg = (bn0 / BK) * BK;
+    if (lower_only & (16 | 64)) {                            // op(B) = B lower triangular: zero before the column block (16);
+        const int kbeg = (((lower_only & 64) ? bm0 : bn0) / BK) * BK;   // op(A) = A^T with A lower triangular: before the row block (64)
         A += TA ? (long long)kbeg * lda : (long long)kbeg; B += TB ? (long long)kbeg : (long long)kbeg * ldb; k -= kbeg;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
     if ((lower_only & 1) && bn0 > bm0 + GM - 1) return;
     if (lower_only & 2) k = min(k, bm0 + GM);
     if (lower_only & 4) k = min(k, bn0 + GN);
-    if (lower_only & 16) {                                       // op(B) = B lower triangular: zero before the column block
-        const int kbeg = (bn0 / GK) * GK;
+    if (lower_only & (16 | 64)) {                                // op(B) = B lower triangular: zero before the column block (16);
+        const int kbeg = (((lower_only & 64) ? bm0 : bn0) / GK) * GK;   // op(A) = A^T with A lower triangular: before the row block (64)
         A += TA ? (long long)kbeg * lda : (long long)kbeg; B += TB ? (long long)kbeg : (long long)kbeg * ldb; k -= kbeg;
     }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -713,6 +713,19 @@ extern "C" int gpr_gemm(void *stream, int transa, int transb, int m, int n, int 
     const int rc = launch_gemm((hipStream_t)stream, transa, transb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0);
     gpr_prof_end((hipStream_t)stream, pid);
     return rc;
+}
+
+// C = X^T X for a lower-triangular X (n x n, zeros above the diagonal), C symmetric and written in full: only the tiles on
+// or below the diagonal are computed, their k range starts at their row block (X[k][i] = 0 for k < i) -- a sixth of
+// the multiply-adds of the plain product -- and the upper triangle is mirrored.  K^-1 = L^-T L^-1 from X = L^-1.
+extern "C" int gpr_xtx_lower(void *stream, int n, const double *x, long long ldx, double *c, long long ldc) {
+    GPR_REQUIRE(n >= 0 && (n == 0 || (x && c)) && ldx >= n && ldc >= n, "gpr_xtx_lower: bad arguments");
+    if (n == 0) return GPR_OK;
+    const int pid = gpr_prof_begin((hipStream_t)stream, GPR_PROF_GEMM);
+    const int rc = launch_gemm((hipStream_t)stream, 1, 0, n, n, n, 1.0, x, ldx, x, ldx, 0.0, c, ldc, 1 | 64);
+    gpr_prof_end((hipStream_t)stream, pid);
+    if (rc) return rc;
+    return gpr_mirror_lower(stream, n, c, ldc);
 }
 
 // C[n, nrhs] = T B with T an n x n LOWER-triangular matrix (zeros above the diagonal): the k loop of

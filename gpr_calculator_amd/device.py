@@ -313,6 +313,14 @@ def gemm(a, b, transa=False, transb=False, alpha=1.0, beta=0.0, out=None):
     return out
 
 
+def xtx_lower(x):
+    """x^T x of a lower-triangular device matrix (zeros above the diagonal), the full symmetric result: K^-1 from L^-1"""
+    n = x.shape[0]
+    out = torch.empty((n, n), dtype=F64, device=x.device)
+    check(_lib.lib().gpr_xtx_lower(stream_ptr(), n, ptr(x), max(int(x.stride(0)), n), ptr(out), n), "gpr_xtx_lower")
+    return out
+
+
 def trmm_lower(t, b, out=None):
     """t @ b with t lower triangular [n, n], b [n, nrhs] (row-major device matrices)"""
     n, nrhs = b.shape

@@ -187,7 +187,7 @@ class GP():
         """K^-1 = L^-T L^-1 (gaussianprocess.py:128-131), formed on the device only when asked for."""
         if self._K_inv_dev is None and self._L_dev is not None:
             Linv = self._Linv()
-            Kinv = dev.gemm(Linv, Linv, transa=True)
+            Kinv = dev.xtx_lower(Linv)
             if self._perm_dev is not None:        # back to the reference's row order
                 full = torch.empty_like(Kinv)
                 full[self._perm_dev[:, None], self._perm_dev[None, :]] = Kinv
@@ -247,7 +247,7 @@ class GP():
             return MLL
         # gradient: 0.5 * tr((alpha alpha^T - K^-1) dK/dtheta)   (GPML eq. 5.9; gaussianprocess.py:188-200)
         Linv = dev.trtri_lower(L)
-        Kinv = dev.gemm(Linv, Linv, transa=True)
+        Kinv = dev.xtx_lower(Linv)
         grads = []
         for dK in (dK0, dK1):
             quad = dev.frob_dot(alpha, dev.gemm(dK, alpha)).item()

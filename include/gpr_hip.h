@@ -343,6 +343,9 @@ int gpr_gemm_nt_cyclic_lower(void *stream, int m, int n, int k, double alpha, co
                              const double *b, long long ldb, double beta, double *c, long long ldc, int nb, int nranks,
                              int rank, int lb0, int col0);
 int gpr_potrf_finish(void *stream, int n, double *l, long long ldl, double *dinv);
+/* C = X^T X of a lower-triangular X (zeros above its diagonal), written in full (computed as the lower triangle with the
+ * zero part of every k range skipped, then mirrored): K^-1 = L^-T L^-1 from X = L^-1 (gaussianprocess.py:128-131) */
+int gpr_xtx_lower(void *stream, int n, const double *x, long long ldx, double *c, long long ldc);
 /* X = L^-1 of a lower-triangular L on the matrix cores (diagonal blocks of 256 rows at once, the blocks below them
  * recursively by halves).  Written: the lower triangle of X and the zeros above the diagonal inside the 256 x 256 diagonal
  * blocks; the blocks above those are left untouched -- hand over a zeroed X. */
