@@ -12,6 +12,8 @@
 #include <cstdarg>
 #include <numeric>
 #include <mutex>
+#include <unordered_map>
+#include <vector>
 #include "gpr_internal.h"
 
 // ---------------------------------------------------------------- errors / misc
@@ -54,16 +56,56 @@ static void gpr_pool_keep_cached() {
     done_for = devid;
 }
 
+// Stream-ordered temporaries.  A block freed on stream `st` may be handed to the next request on the same stream without
+// a trip to the driver: everything that used it was enqueued on `st` before the free, everything that will use it is
+// enqueued after the request -- the guarantee hipFreeAsync / hipMallocAsync give, minus two driver calls (2-3 us each; a
+// prediction step makes three requests of the same sizes every time, between its first, short launches).  The cache is
+// per host thread (the thread that frees a block may reuse it), small (16 blocks, 512 MB); block sizes are kept in one
+// table for the process, so a block may be freed by another thread than the one that asked for it.
+namespace {
+struct cached_block { void *p; size_t bytes; hipStream_t st; };
+thread_local std::vector<cached_block> t_cache;
+std::unordered_map<void *, size_t> g_sizes;               // every live block of gpr_dev_alloc -> its size
+std::mutex g_sizes_mu;
+thread_local size_t t_cached_bytes = 0;
+constexpr size_t CACHE_BLOCKS = 16, CACHE_BYTES = (size_t)512 << 20, CACHE_BLOCK_MAX = (size_t)256 << 20;
+}
+
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
+    for (size_t i = 0; i < t_cache.size(); i++) {
+        const cached_block &c = t_cache[i];
+        if (c.st == st && c.bytes >= bytes && c.bytes <= 2 * bytes + 4096) {
+            *p = c.p;
+            t_cached_bytes -= c.bytes;
+            t_cache.erase(t_cache.begin() + (long)i);
+            return GPR_OK;
+        }
+    }
     gpr_pool_keep_cached();
     GPR_HIP_TRY(hipMallocAsync(p, bytes, st));
+    { std::lock_guard<std::mutex> lk(g_sizes_mu); g_sizes[*p] = bytes; }
     return GPR_OK;
 }
 
 int gpr_dev_free(void *p, hipStream_t st) {
-    if (p) GPR_HIP_TRY(hipFreeAsync(p, st));
+    if (!p) return GPR_OK;
+    size_t bytes = 0;
+    { std::lock_guard<std::mutex> lk(g_sizes_mu); const auto it = g_sizes.find(p); if (it != g_sizes.end()) bytes = it->second; }
+    auto release = [&](void *q, hipStream_t s) {
+        { std::lock_guard<std::mutex> lk(g_sizes_mu); g_sizes.erase(q); }
+        return hipFreeAsync(q, s);
+    };
+    if (bytes == 0 || bytes > CACHE_BLOCK_MAX) { GPR_HIP_TRY(release(p, st)); return GPR_OK; }
+    while (!t_cache.empty() && (t_cache.size() >= CACHE_BLOCKS || t_cached_bytes + bytes > CACHE_BYTES)) {
+        const cached_block old = t_cache.front();                          // oldest out, back to the driver's pool
+        t_cache.erase(t_cache.begin());
+        t_cached_bytes -= old.bytes;
+        GPR_HIP_TRY(release(old.p, old.st));
+    }
+    t_cache.push_back(cached_block{p, bytes, st});
+    t_cached_bytes += bytes;
     return GPR_OK;
 }
 
