@@ -131,3 +131,33 @@ def test_appended_fit_matches_a_full_refit():
     inc.kernel.update([2.0, 1.0])
     inc.fit(show=False, opt=False)
     assert inc._perm_dev is None
+
+
+def test_weight_space_fit_call_by_call():
+    """INTEGRATION.md's recipe: the weight-space fit as a sequence of exported calls (features of the packed training
+    points, two accumulating Gram products with the noise weights in alpha, Cholesky, two solves, triangular inverse)
+    gives the w and C^-1 that GP.fit hands to the prediction session"""
+    import torch
+    from gpr_calculator_amd import device as dev
+    gp = _model(True, stress=False)
+    ws = gp._weight_space()
+    species, w_ref, Cinv_ref = ws[0], ws[2], ws[3]
+    k = gp.kernel
+    sig, s0, ne, nf = float(k.sigma), float(k.sigma0), float(gp.noise_e), float(gp.noise_f)
+    PsiE = dev.dot2_features(k.pack_energy(gp.train_x["energy"]).stream, species, s0)
+    PsiF = dev.dot2_features(k.pack_force(gp.train_x["force"]).stream, species, 0.0)
+    nE = PsiE.shape[0]
+    y = dev.to_dev(np.asarray(gp.y_train).reshape(-1, 1))
+    G = dev.gemm(PsiE, PsiE, transa=True, alpha=sig ** 2 / ne ** 2)
+    dev.gemm(PsiF, PsiF, transa=True, alpha=sig ** 2 / nf ** 2, beta=1.0, out=G)
+    w = dev.gemm(PsiE, y[:nE].contiguous(), transa=True, alpha=sig ** 2 / ne ** 2)
+    dev.gemm(PsiF, y[nE:].contiguous(), transa=True, alpha=sig ** 2 / nf ** 2, beta=1.0, out=w)
+    G.diagonal().add_(1.0)
+    info, dinv = dev.potrf_lower_(G, want_dinv=True)
+    assert int(info.item()) == 0
+    dev.trsm_lower_(G, w, dinv=dinv)
+    dev.trsm_lower_(G, w, trans=True, dinv=dinv)
+    Cinv = dev.trtri_lower(G)
+    ew = float((w - w_ref).abs().max()) / float(w_ref.abs().max())
+    ec = float((Cinv - Cinv_ref).abs().max()) / float(Cinv_ref.abs().max())
+    assert ew < 1e-9 and ec < 1e-9, (ew, ec)
