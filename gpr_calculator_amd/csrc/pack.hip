@@ -59,53 +59,67 @@ static void gpr_pool_keep_cached() {
 // Stream-ordered temporaries.  A block freed on stream `st` may be handed to the next request on the same stream without
 // a trip to the driver: everything that used it was enqueued on `st` before the free, everything that will use it is
 // enqueued after the request -- the guarantee hipFreeAsync / hipMallocAsync give, minus two driver calls (2-3 us each; a
-// prediction step makes three requests of the same sizes every time, between its first, short launches).  The cache is
-// per host thread (the thread that frees a block may reuse it), small (16 blocks, 512 MB); block sizes are kept in one
-// table for the process, so a block may be freed by another thread than the one that asked for it.
+// prediction step makes three requests of the same sizes every time, between its first, short launches).  One small
+// cache for the process (16 blocks, 512 MB, a mutex around it): stream order is what makes the reuse safe, whichever host
+// thread asks.  Blocks that fall out go back to the driver on the stream they were freed on (plain hipFree if that
+// stream is gone).
 namespace {
 struct cached_block { void *p; size_t bytes; hipStream_t st; };
-thread_local std::vector<cached_block> t_cache;
+std::vector<cached_block> g_cache;
 std::unordered_map<void *, size_t> g_sizes;               // every live block of gpr_dev_alloc -> its size
-std::mutex g_sizes_mu;
-thread_local size_t t_cached_bytes = 0;
+size_t g_cached_bytes = 0;
+std::mutex g_cache_mu;
 constexpr size_t CACHE_BLOCKS = 16, CACHE_BYTES = (size_t)512 << 20, CACHE_BLOCK_MAX = (size_t)256 << 20;
+
+void release_to_driver(void *p, hipStream_t st) {
+    if (hipFreeAsync(p, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); }
+}
 }
 
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
-    for (size_t i = 0; i < t_cache.size(); i++) {
-        const cached_block &c = t_cache[i];
-        if (c.st == st && c.bytes >= bytes && c.bytes <= 2 * bytes + 4096) {
-            *p = c.p;
-            t_cached_bytes -= c.bytes;
-            t_cache.erase(t_cache.begin() + (long)i);
-            return GPR_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size(); i++) {
+            const cached_block c = g_cache[i];
+            if (c.st == st && c.bytes >= bytes && c.bytes <= 2 * bytes + 4096) {
+                *p = c.p;
+                g_cached_bytes -= c.bytes;
+                g_cache.erase(g_cache.begin() + (long)i);
+                return GPR_OK;
+            }
         }
     }
     gpr_pool_keep_cached();
     GPR_HIP_TRY(hipMallocAsync(p, bytes, st));
-    { std::lock_guard<std::mutex> lk(g_sizes_mu); g_sizes[*p] = bytes; }
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    g_sizes[*p] = bytes;
     return GPR_OK;
 }
 
 int gpr_dev_free(void *p, hipStream_t st) {
     if (!p) return GPR_OK;
-    size_t bytes = 0;
-    { std::lock_guard<std::mutex> lk(g_sizes_mu); const auto it = g_sizes.find(p); if (it != g_sizes.end()) bytes = it->second; }
-    auto release = [&](void *q, hipStream_t s) {
-        { std::lock_guard<std::mutex> lk(g_sizes_mu); g_sizes.erase(q); }
-        return hipFreeAsync(q, s);
-    };
-    if (bytes == 0 || bytes > CACHE_BLOCK_MAX) { GPR_HIP_TRY(release(p, st)); return GPR_OK; }
-    while (!t_cache.empty() && (t_cache.size() >= CACHE_BLOCKS || t_cached_bytes + bytes > CACHE_BYTES)) {
-        const cached_block old = t_cache.front();                          // oldest out, back to the driver's pool
-        t_cache.erase(t_cache.begin());
-        t_cached_bytes -= old.bytes;
-        GPR_HIP_TRY(release(old.p, old.st));
+    std::vector<cached_block> out;                        // what leaves the cache: handed to the driver outside the lock
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        const auto it = g_sizes.find(p);
+        const size_t bytes = it != g_sizes.end() ? it->second : 0;
+        if (bytes == 0 || bytes > CACHE_BLOCK_MAX) {
+            if (it != g_sizes.end()) g_sizes.erase(it);
+            out.push_back(cached_block{p, bytes, st});
+        } else {
+            while (!g_cache.empty() && (g_cache.size() >= CACHE_BLOCKS || g_cached_bytes + bytes > CACHE_BYTES)) {
+                out.push_back(g_cache.front());               // oldest out
+                g_cached_bytes -= g_cache.front().bytes;
+                g_sizes.erase(g_cache.front().p);
+                g_cache.erase(g_cache.begin());
+            }
+            g_cache.push_back(cached_block{p, bytes, st});
+            g_cached_bytes += bytes;
+        }
     }
-    t_cache.push_back(cached_block{p, bytes, st});
-    t_cached_bytes += bytes;
+    for (const cached_block &c : out) release_to_driver(c.p, c.st);
     return GPR_OK;
 }
 
