@@ -10,7 +10,15 @@ variance for the Dot kernel at zeta = 2 (descriptor -> K_trans -> K_trans alpha 
 with --kernel RBF), inputs resident on the host as ASE-like structures, model resident in HBM, results
 back on the host.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU under torch.distributed.run.  Started that way (WORLD_SIZE set) the script is a rank; started
+plainly with --gpus N > 1 it launches `python -m torch.distributed.run --nproc-per-node N bench.py ...` as a CHILD process
+before anything here touches the GPU and relays the child's JSON line and exit code (the parent never holds GPU state
+and never re-executes itself).  The timed step is the throughput form of the call: batches are handed to the prediction
+session with up to --depth of them in flight (gpr_dot2_session_submit / _wait), K submissions and K collections inside
+the timed region; the synchronous one-batch latency (what an NEB optimiser step sees) is measured right after and
+reported as config.sync_ms_per_step.
 
 One JSON line on stdout (rank 0).  Extra objects: "roofline" for the kernel with the largest summed HIP-event
 time of the timed region (plus the same figures for every profiled kernel of the step under "per_kernel" and,
@@ -61,15 +69,19 @@ def build_model(kernel_name, n_train, comm):
     return gp
 
 
-def time_fit(gp, reps=2):
-    ts = []
-    for _ in range(reps):
+def time_fit(gp, warm=2, reps=3):
+    """(cold, warm) ms of fit(opt=False): the first call of this route in the process (feature rows / packed sets built,
+    temporaries mapped, look-ahead context created), then the mean of `reps` calls after `warm` more untimed ones"""
+    def once():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         gp.fit(show=False, opt=False)
         torch.cuda.synchronize()
-        ts.append(time.perf_counter() - t0)
-    return min(ts) * 1e3
+        return (time.perf_counter() - t0) * 1e3
+    cold = once()
+    for _ in range(warm):
+        once()
+    return cold, float(np.mean([once() for _ in range(reps)]))
 
 
 def same_species_pairs(ele1, ele2):
@@ -153,6 +165,57 @@ def fit_mode(args, comm, gp, dev):
         print(json.dumps(line))
 
 
+def launch_ranks(n):
+    """--gpus N > 1 without a torchrun environment: start the N ranks as a child job and relay its JSON line.  Runs
+    before this process has made any GPU call; the parent stays GPU-free for its whole life."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    res = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    for l in res.stdout.splitlines():
+        if not l.startswith("{"):
+            print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    sys.stdout.flush()
+    return res.returncode if res.returncode else (0 if lines else 1)
+
+
+def dry_run(args):
+    """what the launch path must get right, without a GPU: N ranks meet over the process group (gloo on a CPU-only box),
+    agree on who is there, and rank 0 prints the JSON line the parent relays"""
+    from gpr_calculator_amd.parallel import init_from_env
+    comm = init_from_env()
+    seen = comm.allreduce(np.eye(comm.size)[comm.rank])          # one tensor all-reduce: 1 at every rank that took part
+    comm.barrier()
+    if comm.rank == 0:
+        print(json.dumps({"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": None, "dry_run": True,
+                          "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"ranks": comm.size, "ranks_seen": [int(v) for v in np.atleast_1d(seen)],
+                                     "backend": torch.distributed.get_backend() if comm.size > 1 else None}}))
+    if comm.size > 1:
+        torch.distributed.destroy_process_group()
+
+
+def run_pipelined(gp, batch, steps, depth):
+    """`steps` submissions and `steps` collections, at most `depth` batches in flight; returns the last results"""
+    from collections import deque
+    q, out = deque(), None
+    for _ in range(steps):
+        if len(q) == depth:
+            out = gp.predict_structures_collect(q.popleft())
+        q.append(gp.predict_structures_submit(batch, return_std=True))
+    while q:
+        out = gp.predict_structures_collect(q.popleft())
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -164,7 +227,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-route", action="store_true", help="skip the extra pair-kernel measurement of the Dot run")
     ap.add_argument("--mode", default="predict", choices=["predict", "fit"])
+    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the timed region (1 = the synchronous call)")
+    ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the untimed sustained leg after the timed region")
+    ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report (no GPU work): checks the launch path")
     args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    if args.dry_run:
+        return dry_run(args)
     # the CPU baseline first, in child processes, before this process loads the HIP runtime (N = 1, rank 0 only)
     cpu = None
     if args.mode == "predict" and int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
@@ -180,6 +250,8 @@ def main():
     _lib.require_gpu()
 
     gp = build_model(args.kernel, args.n_train, comm)
+    if world > 1:
+        assert gp.comm.size == world, (gp.comm.size, world)
     if args.mode == "fit":
         fit_mode(args, comm, gp, dev)
         if world > 1:
@@ -189,22 +261,33 @@ def main():
     # route (K assembly sharded over ranks + N x N Cholesky + alpha) is what every other kernel takes and what
     # L_ / alpha_ / _K_inv trigger lazily -- both are timed
     gp.weight_space_fit = False
-    fit_dense_ms = time_fit(gp)
+    fit_dense_cold, fit_dense_ms = time_fit(gp)
     gp.weight_space_fit = True
-    fit_ms = time_fit(gp)
+    fit_cold, fit_ms = time_fit(gp)
     # weak scaling: every rank predicts its own batch of images with the replicated model
     batch = neb_images(args.batch, seed=100 + 10 * rank)
+    real_comm = gp.comm
     gp.comm = _Serial()      # predict_structures shards a batch over gp.comm; here each rank owns a whole batch
+    depth = max(1, min(8, args.depth))
+    gp.session_depth = depth
+    pipelined = depth > 1 and args.kernel == "Dot"
 
     def step():
         return gp.predict_structures(batch, return_std=True, f_tol=1e-8)
+
+    def run(n):
+        if pipelined:
+            return run_pipelined(gp, batch, n, depth)
+        out = None
+        for _ in range(n):
+            out = step()
+        return out
 
     # untimed: a few priming steps before the W warm-up steps the caller asked for (first call sizes the neighbour
     # tables exactly and records the capacities later calls guess from; clocks and the stream-ordered pool settle)
     for _ in range(max(0, 30 - args.warmup) if args.kernel == "Dot" else 0):
         step()
-    for _ in range(args.warmup):
-        step()
+    run(args.warmup)
     comm.barrier()
     torch.cuda.synchronize()
     # HIP events on the launch stream around every 4th launch of each kernel kind of the timed region (around every one
@@ -212,8 +295,7 @@ def main():
     sample = 4 if (args.kernel == "Dot" and args.steps >= 16) else 1
     dev.profile_enable(sample)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    out = run(args.steps)
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = time.perf_counter() - t0
@@ -223,6 +305,53 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    # --- outside the metric: the synchronous one-batch call (latency an optimiser step sees), with its own kernel times
+    nsync = min(args.steps, 100) if args.kernel == "Dot" else min(args.steps, 3)
+    for _ in range(3 if args.kernel == "Dot" else 0):
+        step()
+    torch.cuda.synchronize()
+    dev.profile_enable(sample if nsync >= 16 else 1)
+    t1 = time.perf_counter()
+    for _ in range(nsync):
+        sync_out = step()
+    torch.cuda.synchronize()
+    sync_ms = (time.perf_counter() - t1) / max(nsync, 1) * 1e3
+    prof_sync = dev.profile_fetch()
+    dev.profile_enable(False)
+    if pipelined:                                            # same batch, same model: the two forms agree to the bit
+        for a, b in zip(out, sync_out):
+            assert np.array_equal(np.asarray(a), np.asarray(b))
+    # --- outside the metric: a sustained leg of the timed loop (seconds, not milliseconds: long enough for an external
+    # GPU-busy sampler to see the device busy)
+    sustained = None
+    if args.sustain > 0:
+        chunk = max(args.steps, 50)
+        n_done, t2 = 0, time.perf_counter()
+        while time.perf_counter() - t2 < args.sustain:
+            run(chunk)
+            n_done += chunk
+        torch.cuda.synchronize()
+        sustained = {"seconds": time.perf_counter() - t2, "steps": n_done,
+                     "structures_per_s": n_done * args.batch / (time.perf_counter() - t2)}
+    # --- outside the metric, N > 1: the SAME 64-structure batch dealt over the ranks by structure (strong scaling of one
+    # prediction; results come back through one tensor all-reduce), next to the weak-scaled headline
+    strong = None
+    if world > 1:
+        gp.comm = real_comm
+        shared = neb_images(args.batch, seed=100)
+        for _ in range(5):
+            gp.predict_structures(shared, return_std=True, f_tol=1e-8)
+        comm.barrier(); torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        nst = min(args.steps, 100)
+        for _ in range(nst):
+            gp.predict_structures(shared, return_std=True, f_tol=1e-8)
+        torch.cuda.synchronize(); comm.barrier()
+        t = torch.tensor([time.perf_counter() - t3], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        strong = {"ms_per_step": float(t.item()) / nst * 1e3, "structures_per_s": args.batch * nst / float(t.item()),
+                  "what": f"one {args.batch}-structure batch dealt over {world} ranks by structure, results all-reduced"}
+        gp.comm = _Serial()
     assert all(np.isfinite(e) for e in out[0])
 
     if rank == 0:
@@ -283,7 +412,8 @@ def main():
                 traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        per_sync = {k: (ms / nsync, n / nsync) for k, (ms, n) in prof_sync.items() if n}
+        roofline = {"bound": "fp64-vector" if dom in ("so3", "ee") else "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
                     "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "event_sampling": sample, "flop_per_step": flops,
                     "work_unit": unit_note,
@@ -293,7 +423,15 @@ def main():
                     "per_kernel": {k: {"ms_per_step": round(per_step[k][0], 4), "flop_per_step": work[k][1],
                                        "achieved": work[k][1] / (per_step[k][0] * 1e-3) / 1e12 if per_step[k][0] > 0 else 0.0,
                                        "frac": work[k][1] / (per_step[k][0] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if per_step[k][0] > 0 else 0.0}
-                                   for k in per_step if k in work}}
+                                   for k in per_step if k in work},
+                    # the same kernels timed alone on the device (synchronous one-batch calls after the timed region: no
+                    # second batch shares the chip with them); in the timed region up to `depth` chains run side by side
+                    # and a launch's duration includes what it waits for the others
+                    "per_kernel_solo": {k: {"ms_per_step": round(per_sync[k][0], 4),
+                                            "frac": work[k][1] / (per_sync[k][0] * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS if per_sync[k][0] > 0 else 0.0}
+                                        for k in per_sync if k in work},
+                    "whole_step": {"flop_per_step": sum(work[k][1] for k in per_step if k in work),
+                                   "frac": sum(work[k][1] for k in per_step if k in work) / (ms_per_step * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}}
         # the same step through the row-pair route (what every other kernel / zeta takes): the Dot kernel object with its
         # feature map switched off builds K_trans with kblock_kernel<FF> -- the FP64-MFMA kernel of SURVEY section 8d --
         # measured live here so that its roofline point sits next to the headline's
@@ -329,7 +467,14 @@ def main():
                                        f"energy points (N={N}), {args.kernel} kernel zeta=2, SO3(3,4,5.0), predict "
                                        f"E/F/sigma batch of {args.batch} 32-atom structures per GPU",
                            "kernel": args.kernel, "n_train": args.n_train, "batch_per_gpu": args.batch, "N": int(N),
-                           "train_force_rows": int(len(tX)), "fit_ms": fit_ms, "fit_dense_ms": fit_dense_ms,
+                           "train_force_rows": int(len(tX)),
+                           # fit(opt=False) on `world` ranks: warm = mean of 3 calls after 2 untimed ones; cold = the
+                           # first call of that route in the process
+                           "fit_ms": fit_ms, "fit_cold_ms": fit_cold, "fit_dense_ms": fit_dense_ms, "fit_dense_cold_ms": fit_dense_cold,
+                           "batches_in_flight": depth if pipelined else 1,
+                           "sync_ms_per_step": sync_ms, "sync_structures_per_s": args.batch / (sync_ms * 1e-3),
+                           "sustained": sustained, "strong_predict": strong,
+                           "ranks": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
                            "parallelism": f"replicated model, structure-parallel predict x{world}; fit K sharded x{world}"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line))

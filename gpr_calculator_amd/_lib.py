@@ -52,7 +52,13 @@ _L1_SIGNATURES = {
     "gpr_dot2_session_create": ([C.POINTER(_vp), _vp, _i, _i, _d, _d, _i, _i, _vp, _i, _i, c_int_p, _d, _d, _vp, _vp, _vp, _i], _i),
     "gpr_dot2_session_predict": ([_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp], _i),
     "gpr_dot2_session_set_hint": ([_vp, _d, _d], _i),
+    "gpr_dot2_session_submit": ([_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i)], _i),
+    "gpr_dot2_session_wait": ([_vp, _i, _vp, _vp, _vp, _vp, _vp], _i),
+    "gpr_dot2_session_set_depth": ([_vp, _i], _i),
     "gpr_dot2_session_destroy": ([_vp], _i),
+    "gpr_potrf_set_polling": ([_i], _i),
+    "gpr_potrf_polling": ([], _i),
+    "gpr_potrf_debug_max_polls": ([_i], _i),
     "gpr_potrf_ops_doubles": ([], _i),
     "gpr_potrf_diag_block": ([_vp, _i, _vp, _ll, _i, _vp, _vp], _i),
     "gpr_potrf_panel_rows": ([_vp, _i, _vp, _vp, _ll, _i], _i),

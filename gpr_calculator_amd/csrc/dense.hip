@@ -426,6 +426,9 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
 #pragma unroll
     for (int i = 0; i < AI; i++) { mean2[i] = 0.0; norm2[i] = 0.0; }
     const int ncb = (n + WT_C - 1) / WT_C;
+    // SPLIT 2: `cnt` is the arrival counter of the combine launch that follows on the stream; it lives in this call's
+    // workspace (two predictions in flight on two streams must not share one) and is zeroed here, a launch earlier
+    if (SPLIT == 2 && cnt && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *cnt = 0;
     // SPLIT 0: all column blocks; 1: column block blockIdx.x; 2: blocks blockIdx.x and ncb - 1 - blockIdx.x (a short k
     // range with a long one)
     const int nturn = SPLIT == 0 ? ncb : (SPLIT == 1 ? 1 : ((int)blockIdx.x * 2 + 1 == ncb ? 1 : 2));
@@ -588,7 +591,6 @@ __global__ void __launch_bounds__(256) ws_tail_combine_kernel(int m, int npart, 
     if (threadIdx.x == 0) s_last = atomicAdd(done, 1) == (int)gridDim.x - 1;
     __syncthreads();
     if (s_last && threadIdx.x < 4) status_dst[threadIdx.x] = (double)status_src[threadIdx.x];
-    if (s_last && threadIdx.x == 0) *done = 0;      // ready for the next launch: no memset (a 5 us fill kernel) per call
 }
 
 __global__ void ws_status_kernel(const int *src, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)src[threadIdx.x]; }
@@ -1004,18 +1006,14 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         }
         const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
         void *wsp;
-        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double), st);
+        int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double) + 16, st);
         if (rc) return rc;
         double *part = (double *)wsp, *mn = part + (size_t)npart * m;
-        // arrival counter of the combine launch: one device int per process, zeroed once, reset by the last arriver
-        static int *done = nullptr;
-        if (!done) {
-            GPR_HIP_TRY(hipMalloc((void **)&done, sizeof(int)));
-            GPR_HIP_TRY(hipMemset(done, 0, sizeof(int)));
-        }
+        // arrival counter of the combine launch: in this call's workspace, zeroed by the tail kernel
+        int *done = (int *)(mn + 2 * (size_t)m);
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, (int *)nullptr, std_out);
+                           out, vsq, part, mn, done, std_out);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
                            (const double *)mn, diag, out, vsq, status_src, status_dst, done, std_out);
         gpr_prof_end(st, pid2);

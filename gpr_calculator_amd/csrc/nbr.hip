@@ -391,7 +391,10 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 
 namespace {
 struct stage_buf { void *p = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };   // dev: device alias of p
-thread_local stage_buf g_stage[2];
+// as many as a prediction session may have in flight (predict.hip: SESSION_SLOTS): a buffer is re-used only after the
+// submission that filled it has been waited for, or else after its event
+constexpr int NSTAGE = 8;
+thread_local stage_buf g_stage[NSTAGE];
 thread_local int g_stage_next = 0;
 }
 
@@ -426,7 +429,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     // the blob is assembled in page-locked memory (two buffers used in turn, each guarded by the event of its last
     // copy): the upload is then a real asynchronous copy instead of a staged one
     stage_buf &sb = g_stage[g_stage_next];
-    g_stage_next ^= 1;
+    g_stage_next = (g_stage_next + 1) % NSTAGE;
     if (sb.pending) { (void)hipEventSynchronize(sb.ev); sb.pending = false; }
     if (sb.cap < b_total) {
         if (sb.p) (void)hipHostFree(sb.p);

@@ -64,7 +64,7 @@ static void gpr_pool_keep_cached() {
 // thread asks.  Blocks that fall out go back to the driver on the stream they were freed on (plain hipFree if that
 // stream is gone).
 namespace {
-struct cached_block { void *p; size_t bytes; hipStream_t st; };
+struct cached_block { void *p; size_t bytes; hipStream_t st; int dev; };   // (device, stream): the null stream exists on every device
 std::vector<cached_block> g_cache;
 std::unordered_map<void *, size_t> g_sizes;               // every live block of gpr_dev_alloc -> its size
 size_t g_cached_bytes = 0;
@@ -74,16 +74,18 @@ constexpr size_t CACHE_BLOCKS = 16, CACHE_BYTES = (size_t)512 << 20, CACHE_BLOCK
 void release_to_driver(void *p, hipStream_t st) {
     if (hipFreeAsync(p, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); }
 }
+int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; } return d; }
 }
 
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
     *p = nullptr;
     if (bytes == 0) bytes = 16;
+    const int devid = current_device();
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
         for (size_t i = 0; i < g_cache.size(); i++) {
             const cached_block c = g_cache[i];
-            if (c.st == st && c.bytes >= bytes && c.bytes <= 2 * bytes + 4096) {
+            if (c.st == st && c.dev == devid && c.bytes >= bytes && c.bytes <= 2 * bytes + 4096) {
                 *p = c.p;
                 g_cached_bytes -= c.bytes;
                 g_cache.erase(g_cache.begin() + (long)i);
@@ -100,6 +102,7 @@ int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
 
 int gpr_dev_free(void *p, hipStream_t st) {
     if (!p) return GPR_OK;
+    const int devid = current_device();
     std::vector<cached_block> out;                        // what leaves the cache: handed to the driver outside the lock
     {
         std::lock_guard<std::mutex> lk(g_cache_mu);
@@ -107,7 +110,7 @@ int gpr_dev_free(void *p, hipStream_t st) {
         const size_t bytes = it != g_sizes.end() ? it->second : 0;
         if (bytes == 0 || bytes > CACHE_BLOCK_MAX) {
             if (it != g_sizes.end()) g_sizes.erase(it);
-            out.push_back(cached_block{p, bytes, st});
+            out.push_back(cached_block{p, bytes, st, devid});
         } else {
             while (!g_cache.empty() && (g_cache.size() >= CACHE_BLOCKS || g_cached_bytes + bytes > CACHE_BYTES)) {
                 out.push_back(g_cache.front());               // oldest out
@@ -115,7 +118,7 @@ int gpr_dev_free(void *p, hipStream_t st) {
                 g_sizes.erase(g_cache.front().p);
                 g_cache.erase(g_cache.begin());
             }
-            g_cache.push_back(cached_block{p, bytes, st});
+            g_cache.push_back(cached_block{p, bytes, st, devid});
             g_cached_bytes += bytes;
         }
     }

@@ -94,12 +94,14 @@ __device__ __forceinline__ void coherent_store(double *p, double v) { __hip_atom
 __device__ __forceinline__ double coherent_load(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void wait_own_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 constexpr int PIPE_MAX_POLLS = 1 << 23;                  // ~10 s: a consumer whose producer never ran gives up instead of hanging the GPU
+__device__ int g_pipe_max_polls = PIPE_MAX_POLLS;        // run-time copy (gpr_potrf_debug_max_polls: the tests force a time-out with it)
 // ... and says so in abort word `flag[4]`, which every later poll of the same factorisation looks at first: one missing
 // producer costs one time-out, not one per kernel.  poll_until: lane-0 helper, true = the counter got there.
 __device__ __forceinline__ bool poll_until(const int *ctr, int target, const int *abort_word) {
     int polls = 0;
+    const int max_polls = g_pipe_max_polls;
     while ((int)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-        if (++polls >= PIPE_MAX_POLLS || ((polls & 1023) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        if (++polls >= max_polls || ((polls & 1023) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             __hip_atomic_store(const_cast<int *>(abort_word), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             return false;
         }
@@ -489,41 +491,109 @@ __global__ void pipe_probe_wait_kernel(const int *flag, int *seen) {
 }
 __global__ void pipe_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// second stream + events of the look-ahead (one set per process; the factorisation is not re-entrant anyway: it owns
-// the scratch of the diagonal kernel for the duration of the call)
+// second stream + events of the look-ahead: one set per DEVICE (streams, events and the flag words belong to the device
+// that was current when they were made).  The factorisation is not re-entrant -- it owns the flag words and the two
+// streams -- so calls on one device are serialised: the mutex covers the host-side enqueue, and the event recorded at
+// the end of a call is what the next call's stream waits for before its first kernel (a second factorisation enqueued
+// from another host thread / on another stream while the first is still RUNNING would otherwise publish its own stage
+// counters into flag[0] under the first one's polls).
+#include <atomic>
+#include <chrono>
 struct lookahead_ctx {
     hipStream_t side = nullptr, mid = nullptr;
     std::vector<hipEvent_t> ev;
+    hipEvent_t end_ev = nullptr;         // end of the last factorisation that used this context
+    bool end_valid = false;
     size_t next = 0;
     int *flag = nullptr;                 // [0] stages published by the diagonal-block kernel in flight (see coherent_store)
                                          // [1] workgroups of the updates of diagonal blocks that have finished
+                                         // [2], [3] overlap probe   [4] abort word of the polls
     unsigned seq = 0;                    // diagonal blocks launched so far
     unsigned done_total = 0;             // value flag[1] reaches when every update launched so far is through
-    bool concurrent = false;             // kernels of two streams overlap in time (probed once): polled hand-overs are safe
-    std::mutex mu;                       // one factorisation with look-ahead at a time per process
+    bool ready = false;                  // every resource below exists (set last)
+    bool failed = false;                 // creation failed once: stay on the no-look-ahead path, do not retry every call
+    bool concurrent = false;             // kernels of two streams overlap in time (probed): polled hand-overs are safe
+    std::chrono::steady_clock::time_point probed;
+    std::mutex mu;                       // one factorisation with look-ahead at a time per device
+    void release() {
+        for (auto &e : ev) if (e) (void)hipEventDestroy(e);
+        ev.clear();
+        if (end_ev) (void)hipEventDestroy(end_ev);
+        if (flag) (void)hipFree(flag);
+        if (mid) (void)hipStreamDestroy(mid);
+        if (side) (void)hipStreamDestroy(side);
+        end_ev = nullptr; flag = nullptr; mid = side = nullptr; ready = false; end_valid = false;
+        (void)hipGetLastError();
+    }
+    // Can two kernels on different streams run at the same time here?  The consumer is enqueued first and polls (bounded)
+    // for a flag the producer sets.  Asked again when the last answer is older than a second (a profiler attached later,
+    // another process on the device): the answer costs two tiny launches and a wait for the two private streams.
+    int probe() {
+        int seen = 0;
+        if (hipMemsetAsync(flag + 2, 0, 2 * sizeof(int), mid) != hipSuccess || hipStreamSynchronize(mid) != hipSuccess) return GPR_ERR_HIP;
+        hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, mid, (const int *)(flag + 2), flag + 3);
+        hipLaunchKernelGGL(pipe_probe_set_kernel, dim3(1), dim3(1), 0, side, flag + 2);
+        if (hipStreamSynchronize(mid) != hipSuccess || hipStreamSynchronize(side) != hipSuccess ||
+            hipMemcpy(&seen, flag + 3, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return GPR_ERR_HIP;
+        concurrent = seen != 0 && !getenv("GPR_POTRF_NO_POLL");
+        probed = std::chrono::steady_clock::now();
+        return GPR_OK;
+    }
     int init() {
-        if (side) return GPR_OK;
+        if (ready) return GPR_OK;
+        if (failed) return GPR_ERR_HIP;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
-        if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) != hipSuccess) { side = nullptr; return GPR_ERR_HIP; }
-        if (hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; return GPR_ERR_HIP; }
-        if (hipMalloc((void **)&flag, 8 * sizeof(int)) != hipSuccess || hipMemset(flag, 0, 8 * sizeof(int)) != hipSuccess) return GPR_ERR_HIP;
-        {   // flag[2]: probe flag, flag[3]: what the consumer saw
-            int seen = 0;
-            hipLaunchKernelGGL(pipe_probe_wait_kernel, dim3(1), dim3(1), 0, mid, (const int *)(flag + 2), flag + 3);
-            hipLaunchKernelGGL(pipe_probe_set_kernel, dim3(1), dim3(1), 0, side, flag + 2);
-            if (hipStreamSynchronize(mid) != hipSuccess || hipStreamSynchronize(side) != hipSuccess ||
-                hipMemcpy(&seen, flag + 3, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return GPR_ERR_HIP;
-            concurrent = seen != 0 && !getenv("GPR_POTRF_NO_POLL");
+        bool ok = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) == hipSuccess;
+        if (!ok) side = nullptr;
+        if (ok && hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; ok = false; }
+        if (ok && hipMalloc((void **)&flag, 8 * sizeof(int)) != hipSuccess) { flag = nullptr; ok = false; }
+        ok = ok && hipMemset(flag, 0, 8 * sizeof(int)) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&end_ev, hipEventDisableTiming) == hipSuccess;
+        if (ok) {
+            ev.assign(256, nullptr);
+            for (auto &e : ev)
+                if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { e = nullptr; ok = false; break; }
         }
-        ev.resize(256);
-        for (auto &e : ev)
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return GPR_ERR_HIP;
+        ok = ok && probe() == GPR_OK;
+        if (!ok) { release(); failed = true; (void)hipGetLastError(); return GPR_ERR_HIP; }
+        ready = true;
         return GPR_OK;
     }
     hipEvent_t take() { return ev[next++ % ev.size()]; }
 };
-static lookahead_ctx g_la;
+constexpr int LA_MAX_DEVICES = 16;
+static lookahead_ctx g_la_dev[LA_MAX_DEVICES];
+static std::atomic<int> g_poll_mode{-1};                 // -1: polled hand-overs where the probe allows them, 0: events only
+
+// 0: every hand-over of the look-ahead is an event from now on (what the host asks for after a poll time-out);
+// -1: back to the probed answer, and probe again at the next call
+extern "C" int gpr_potrf_set_polling(int mode) {
+    g_poll_mode.store(mode == 0 ? 0 : -1);
+    if (mode != 0)
+        for (auto &c : g_la_dev) { std::lock_guard<std::mutex> lk(c.mu); c.probed = std::chrono::steady_clock::time_point(); }
+    return GPR_OK;
+}
+// 1: the next factorisation on the current device may hand tiles over between running kernels; 0: it will not
+extern "C" int gpr_potrf_polling(void) {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= LA_MAX_DEVICES) return 0;
+    std::lock_guard<std::mutex> lk(g_la_dev[d].mu);
+    return g_la_dev[d].ready && g_la_dev[d].concurrent && g_poll_mode.load() != 0;
+}
+// tests: the poll budget of the hand-overs on the current device (<= 0 restores the default); a tiny budget makes the
+// first hand-over give up, which is how the time-out path is exercised
+extern "C" int gpr_potrf_debug_max_polls(int polls) {
+    const int v = polls > 0 ? polls : PIPE_MAX_POLLS;
+    GPR_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pipe_max_polls), &v, sizeof(v)));
+    return GPR_OK;
+}
+
+// temporaries of one call, handed back on every way out
+struct scratch_guard {
+    void *p = nullptr; hipStream_t st = nullptr;
+    ~scratch_guard() { if (p) (void)gpr_dev_free(p, st); }
+};
 
 static void launch_panel(hipStream_t st, double *p, long long lda, int rows, int kb, const double *wop, const double *lop) {
     if (kb == DB) hipLaunchKernelGGL((potrf_panel256_kernel<true, false>), dim3((rows + DT - 1) / DT), dim3(256), 0, st, p, lda, rows, kb, wop, lop, (const int *)nullptr, 0, (int *)nullptr, 0LL, 0LL);
@@ -563,18 +633,31 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     if (n == 0) return GPR_OK;
     if (info_dev) GPR_HIP_TRY(hipMemsetAsync(info_dev, 0, sizeof(int), st));
     const size_t ops_doubles = (size_t)(16 + NTILE) * TILE_DOUBLES;
-    void *scratch;
-    int rc = gpr_dev_alloc(&scratch, 3 * ops_doubles * sizeof(double), st);
+    scratch_guard sg;
+    sg.st = st;
+    int rc = gpr_dev_alloc(&sg.p, 3 * ops_doubles * sizeof(double), st);
     if (rc) return rc;
+    void *scratch = sg.p;
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess || devid < 0 || devid >= LA_MAX_DEVICES) { (void)hipGetLastError(); devid = -1; }
+    lookahead_ctx &g_la = g_la_dev[devid < 0 ? 0 : devid];
     std::unique_lock<std::mutex> lock(g_la.mu);
-    const bool la = n > 3 * DB && !getenv("GPR_POTRF_NO_LOOKAHEAD") && g_la.init() == GPR_OK;
+    const bool la = devid >= 0 && n > 3 * DB && !getenv("GPR_POTRF_NO_LOOKAHEAD") && g_la.init() == GPR_OK;
     if (!la) lock.unlock();
+    if (la && g_poll_mode.load() != 0 && std::chrono::steady_clock::now() - g_la.probed > std::chrono::seconds(1))
+        GPR_REQUIRE(g_la.probe() == GPR_OK, "gpr_potrf_lower: the overlap probe failed");
+    const bool polled = la && g_la.concurrent && g_poll_mode.load() != 0;
     auto at = [&](int r, int c) { return a + (long long)r * lda + c; };
     auto wait = [&](hipStream_t s, hipEvent_t e) { return e ? hipStreamWaitEvent(s, e, 0) : hipSuccess; };
     auto mark = [&](hipStream_t s) { hipEvent_t e = g_la.take(); return hipEventRecord(e, s) == hipSuccess ? e : nullptr; };
     hipEvent_t bulk_first = nullptr, bulk_last = nullptr, mid_last = nullptr;
     if (la) {                                                // the other streams start behind what the caller queued
+        if (g_la.end_valid) GPR_HIP_TRY(hipStreamWaitEvent(st, g_la.end_ev, 0));   // ... and behind the previous factorisation
+        // the counters start from zero in every call: a hand-over that gave up in an earlier call (time-out) leaves flag[1]
+        // short of done_total for good.  Safe: everything that read them has finished before this point of `st`.
+        GPR_HIP_TRY(hipMemsetAsync(g_la.flag, 0, 2 * sizeof(int), st));
         GPR_HIP_TRY(hipMemsetAsync(g_la.flag + 4, 0, sizeof(int), st));      // abort word of the polls
+        g_la.seq = 0; g_la.done_total = 0;
         hipEvent_t e0 = mark(st);
         GPR_HIP_TRY(wait(g_la.mid, e0)); GPR_HIP_TRY(wait(g_la.side, e0));
     }
@@ -599,7 +682,7 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         }
         double *p = at(c1, K0);
         const int KB1 = (R < DB) ? R : DB, c2 = c1 + KB1, Rrest = n - c2;   // top = rows of block K + 1
-        if (g_la.concurrent) {
+        if (polled) {
             const int base = (int)(++g_la.seq * 32u);
             hipLaunchKernelGGL((potrf_diag256_kernel<false, true>), dim3(1), dim3(64 * DWAVES), 0, st, at(K0, K0), lda, KB, K0, info_dev, wop, lop,
                                g_la.flag, base, (const int *)(g_la.flag + 1), (int)g_la.done_total);
@@ -640,10 +723,10 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     if (la) { GPR_HIP_TRY(wait(st, mid_last)); GPR_HIP_TRY(wait(st, bulk_last)); }
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
     if (n > 1) hipLaunchKernelGGL(zero_upper2_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, n, a, lda);
+    if (la) g_la.end_valid = hipEventRecord(g_la.end_ev, st) == hipSuccess;
     const hipError_t e = hipGetLastError();
-    const int rc2 = gpr_dev_free(scratch, st);
     if (e != hipSuccess) { gpr_set_error("potrf launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
-    return rc ? rc : rc2;
+    return rc;
 }
 
 // ---- building blocks of a factorisation whose rows live on several GPUs (gpr_calculator_amd/distributed.py):

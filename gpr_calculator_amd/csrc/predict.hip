@@ -119,20 +119,44 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
 // ---------------------------------------------------------------------------------------------------------------------
 // Host-in / host-out form of the same prediction: the model stays in the session, the caller hands over the structures
 // as host arrays and gets E, F, E_std, F_std back as host arrays -- what GP.predict_structure returns per structure
-// (gaussianprocess.py:880-911), for a whole batch.  The session owns the page-locked result buffer the device writes
-// into, polls its status words instead of blocking on the stream, guesses the neighbour-table capacities from the
+// (gaussianprocess.py:880-911), for a whole batch.  The session owns page-locked result buffers the device writes
+// into, polls their status words instead of blocking on a stream, guesses the neighbour-table capacities from the
 // densest batch it has seen and repeats a call whose guess was too small.
+//
+// Two ways to call it:
+//   gpr_dot2_session_predict            one batch, synchronous (an NEB step: the optimiser needs the forces to go on);
+//   gpr_dot2_session_submit / _wait     several batches in flight.  Every submission takes a *slot*: its own result
+//                                       buffer and its own stream, so the device chain of batch k + 1 (eleven short
+//                                       kernels, none of which fills the chip) runs beside the chain of batch k, and the
+//                                       host gathers / unpacks one batch while the device works on the others.
+//                                       Same kernels, same order inside a batch: results are bit-identical to _predict.
+constexpr int SESSION_SLOTS = 8;
+struct session_slot {
+    hipStream_t st = nullptr;
+    bool own_stream = false;
+    double *pin = nullptr;          // page-locked [2 m + 4]
+    double *pin_dev = nullptr;      // its device address
+    long long pin_cap = 0;
+    std::vector<unsigned char> mask;
+    bool busy = false;
+    // the submission in flight; the input arrays stay the caller's until _wait returns
+    int nstruct = 0, natoms = 0, nfree = 0;
+    long long m = 0, nout = 0;
+    bool masked = false;
+    const int *atom0 = nullptr, *pbc = nullptr, *numbers = nullptr;
+    const double *positions = nullptr, *cells = nullptr;
+};
 struct gpr_dot2_session {
     hipStream_t st;
     int nmax, lmax, nseg, ncheb, weight_on, ns, want_std;
     double rcut, alpha, sigma, sigma0;
     const double *table, *w, *M, *Cinv;
     std::vector<int> species;
-    double *pin = nullptr;          // page-locked [2 m + 4]
-    double *pin_dev = nullptr;      // its device address
-    long long pin_cap = 0;
     double pairs_per_atom = 0.0, rows_per_atom = 0.0;
-    std::vector<unsigned char> mask;
+    session_slot slot[SESSION_SLOTS];
+    int depth = 2;                  // slots _submit rotates over
+    int next = 0;
+    hipEvent_t model_ready = nullptr;
 };
 
 extern "C" int gpr_dot2_session_create(gpr_dot2_session **out, void *stream, int nmax, int lmax, double rcut, double alpha,
@@ -145,6 +169,7 @@ extern "C" int gpr_dot2_session_create(gpr_dot2_session **out, void *stream, int
     s->st = (hipStream_t)stream; s->nmax = nmax; s->lmax = lmax; s->rcut = rcut; s->alpha = alpha; s->nseg = nseg; s->ncheb = ncheb;
     s->table = so3_table; s->weight_on = weight_on; s->ns = ns; s->species.assign(species_host, species_host + ns);
     s->sigma = sigma; s->sigma0 = sigma0; s->w = w_dev; s->M = M_dev; s->Cinv = Cinv_dev; s->want_std = want_std;
+    s->slot[0].st = s->st;          // slot 0 works on the caller's stream: the synchronous call behaves as it always did
     *out = s;
     return GPR_OK;
 }
@@ -156,70 +181,129 @@ extern "C" int gpr_dot2_session_set_hint(gpr_dot2_session *s, double pairs_per_a
     return GPR_OK;
 }
 
+// how many submissions may be in flight (1 .. 8; default 2)
+extern "C" int gpr_dot2_session_set_depth(gpr_dot2_session *s, int depth) {
+    GPR_REQUIRE(s && depth >= 1 && depth <= SESSION_SLOTS, "gpr_dot2_session_set_depth: depth must be 1 .. %d", SESSION_SLOTS);
+    s->depth = depth;
+    return GPR_OK;
+}
+
 extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
     if (!s) return GPR_OK;
-    if (s->pin) (void)hipHostFree(s->pin);
+    for (session_slot &sl : s->slot) {
+        if (sl.busy && sl.st) (void)hipStreamSynchronize(sl.st);      // the device still writes into sl.pin
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        if (sl.own_stream && sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+    }
+    if (s->model_ready) (void)hipEventDestroy(s->model_ready);
+    (void)hipGetLastError();
     delete s;
     return GPR_OK;
 }
 
+// a private stream for slot k >= 1: behind everything queued on the session's stream so far (the model arrays)
+static int session_slot_stream(gpr_dot2_session *s, session_slot &sl) {
+    if (sl.st) return GPR_OK;
+    if (!s->model_ready) GPR_HIP_TRY(hipEventCreateWithFlags(&s->model_ready, hipEventDisableTiming));
+    GPR_HIP_TRY(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+    sl.own_stream = true;
+    GPR_HIP_TRY(hipEventRecord(s->model_ready, s->st));
+    GPR_HIP_TRY(hipStreamWaitEvent(sl.st, s->model_ready, 0));
+    return GPR_OK;
+}
+
+static int session_enqueue(gpr_dot2_session *s, session_slot &sl, int cap_pairs, int cap_rows) {
+    volatile double *tail = sl.pin + sl.nout;
+    for (int k = 0; k < 4; k++) tail[k] = __builtin_nan("");
+    t_std_out = (s->want_std && s->Cinv) ? 1 : 0;             // the device delivers standard deviations, not variances
+    const int rc = gpr_predict_dot2_batch(sl.st, s->nmax, s->lmax, s->rcut, s->alpha, s->nseg, s->ncheb, s->table, sl.nstruct, sl.atom0,
+                                          sl.positions, sl.cells, sl.pbc, sl.numbers, s->weight_on, sl.masked ? sl.mask.data() : nullptr,
+                                          s->ns, s->species.data(), s->sigma, s->sigma0, s->w, s->M, s->Cinv, s->want_std, cap_pairs,
+                                          cap_rows, sl.pin_dev, sl.nout + 4);
+    t_std_out = 0;
+    return rc;
+}
+
 // fixed[natoms] (may be NULL): non-zero marks atoms held by FixAtoms -- F = F_std = 0 there, no force rows.
-// E[nstruct] total energies, F[natoms, 3], E_std[nstruct] (per atom, as upstream), F_std[natoms, 3]; the two std
-// outputs may be NULL when the session was created without want_std.  info[4] (may be NULL): status words of the call.
-extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
-                                        const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
-                                        double *E, double *F, double *E_std, double *F_std, double *info) {
-    GPR_REQUIRE(s && nstruct >= 0 && atom0 && E && F && (!s->want_std || (E_std && F_std)), "gpr_dot2_session_predict: null pointer");
-    if (nstruct == 0) return GPR_OK;
-    const int natoms = atom0[nstruct];
-    const unsigned char *free_mask = nullptr;
-    int nfree = natoms;
+// Queues the whole prediction of the batch and returns; *ticket names the submission for _wait.  The input arrays must
+// stay valid and unchanged until _wait has returned.  At most `depth` submissions may be waiting.
+extern "C" int gpr_dot2_session_submit(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
+                                       const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
+                                       int *ticket) {
+    GPR_REQUIRE(s && nstruct >= 0 && atom0 && ticket, "gpr_dot2_session_submit: null pointer");
+    int k = -1;
+    for (int t = 0; t < s->depth && k < 0; t++) {
+        const int c = (s->next + t) % s->depth;
+        if (!s->slot[c].busy) k = c;
+    }
+    GPR_REQUIRE(k >= 0, "gpr_dot2_session_submit: %d submissions are waiting already (gpr_dot2_session_wait first, or raise the depth)", s->depth);
+    s->next = (k + 1) % s->depth;
+    session_slot &sl = s->slot[k];
+    int rc = session_slot_stream(s, sl);
+    if (rc) return rc;
+    const int natoms = nstruct ? atom0[nstruct] : 0;
+    sl.nstruct = nstruct; sl.natoms = natoms; sl.nfree = natoms; sl.masked = false;
+    sl.atom0 = atom0; sl.positions = positions; sl.cells = cells; sl.pbc = pbc; sl.numbers = numbers;
     if (fixed) {
         bool any = false;
         for (int a = 0; a < natoms && !any; a++) any = fixed[a] != 0;
         if (any) {
-            s->mask.resize((size_t)natoms);
-            nfree = 0;
-            for (int a = 0; a < natoms; a++) { s->mask[a] = fixed[a] ? 0 : 1; nfree += s->mask[a]; }
-            free_mask = s->mask.data();
+            sl.mask.resize((size_t)natoms);
+            sl.nfree = 0;
+            for (int a = 0; a < natoms; a++) { sl.mask[a] = fixed[a] ? 0 : 1; sl.nfree += sl.mask[a]; }
+            sl.masked = true;
         }
     }
-    const long long m = (long long)nstruct + 3LL * nfree, nout = (s->want_std ? 2 : 1) * m;
-    if (s->pin_cap < nout + 4) {
-        if (s->pin) (void)hipHostFree(s->pin);
-        s->pin = nullptr; s->pin_cap = 0;
-        const long long want = std::max<long long>(2 * (nout + 4), 4096);
-        GPR_HIP_TRY(hipHostMalloc((void **)&s->pin, (size_t)want * sizeof(double), hipHostMallocDefault));
-        GPR_HIP_TRY(hipHostGetDevicePointer((void **)&s->pin_dev, s->pin, 0));
-        s->pin_cap = want;
+    sl.m = (long long)nstruct + 3LL * sl.nfree;
+    sl.nout = (s->want_std ? 2 : 1) * sl.m;
+    *ticket = k;
+    if (nstruct == 0) { sl.busy = true; return GPR_OK; }
+    if (sl.pin_cap < sl.nout + 4) {
+        if (sl.pin) (void)hipHostFree(sl.pin);
+        sl.pin = nullptr; sl.pin_cap = 0;
+        const long long want = std::max<long long>(2 * (sl.nout + 4), 4096);
+        GPR_HIP_TRY(hipHostMalloc((void **)&sl.pin, (size_t)want * sizeof(double), hipHostMallocDefault));
+        GPR_HIP_TRY(hipHostGetDevicePointer((void **)&sl.pin_dev, sl.pin, 0));
+        sl.pin_cap = want;
     }
-    volatile double *tail = s->pin + nout;
-    const int dev_std = (s->want_std && s->Cinv) ? 1 : 0;     // the device delivers standard deviations, not variances
     int cap_pairs = 0, cap_rows = 0;
     if (s->pairs_per_atom > 0.0) {
         cap_pairs = (int)(s->pairs_per_atom * natoms * 1.125) + 64;
         cap_rows = (int)(s->rows_per_atom * natoms * 1.125) + 64;
     }
+    rc = session_enqueue(s, sl, cap_pairs, cap_rows);
+    if (rc) return rc;
+    sl.busy = true;
+    return GPR_OK;
+}
+
+// E[nstruct] total energies, F[natoms, 3], E_std[nstruct] (per atom, as upstream), F_std[natoms, 3]; the two std
+// outputs may be NULL when the session was created without want_std.  info[4] (may be NULL): status words of the call.
+extern "C" int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E, double *F, double *E_std, double *F_std,
+                                     double *info) {
+    GPR_REQUIRE(s && ticket >= 0 && ticket < SESSION_SLOTS && s->slot[ticket].busy, "gpr_dot2_session_wait: no submission with ticket %d", ticket);
+    session_slot &sl = s->slot[ticket];
+    sl.busy = false;
+    if (sl.nstruct == 0) return GPR_OK;
+    GPR_REQUIRE(E && F && (!s->want_std || (E_std && F_std)), "gpr_dot2_session_wait: null pointer");
+    const int nstruct = sl.nstruct, natoms = sl.natoms;
+    const long long m = sl.m, nout = sl.nout;
+    const int dev_std = (s->want_std && s->Cinv) ? 1 : 0;
+    volatile double *tail = sl.pin + nout;
     for (int attempt = 0; attempt < 2; attempt++) {
-        for (int k = 0; k < 4; k++) tail[k] = __builtin_nan("");
-        t_std_out = dev_std;
-        int rc = gpr_predict_dot2_batch(s->st, s->nmax, s->lmax, s->rcut, s->alpha, s->nseg, s->ncheb, s->table, nstruct, atom0,
-                                        positions, cells, pbc, numbers, s->weight_on, free_mask, s->ns, s->species.data(), s->sigma,
-                                        s->sigma0, s->w, s->M, s->Cinv, s->want_std, cap_pairs, cap_rows, s->pin_dev, nout + 4);
-        t_std_out = 0;
-        if (rc) return rc;
         // the status words are the last thing the last kernel writes (system-scope fence before them): spin on them in
         // host memory; fall back to a blocking synchronisation if they do not show up within seconds
         bool seen = false;
         for (long long spin = 0; spin < (1LL << 33); spin++) {
             if (tail[0] == tail[0] && tail[1] == tail[1] && tail[2] == tail[2] && tail[3] == tail[3]) { seen = true; break; }
-            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(s->st) == hipSuccess) break;
+            if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(sl.st) == hipSuccess) break;
         }
-        if (!seen) GPR_HIP_TRY(hipStreamSynchronize(s->st));
+        if (!seen) GPR_HIP_TRY(hipStreamSynchronize(sl.st));
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (tail[1] == 0.0) break;                       // no overflow
-        GPR_REQUIRE(attempt == 0, "gpr_dot2_session_predict: neighbour table overflow with exact sizes");
-        cap_pairs = cap_rows = 0;
+        GPR_REQUIRE(attempt == 0, "gpr_dot2_session_wait: neighbour table overflow with exact sizes");
+        const int rc = session_enqueue(s, sl, 0, 0);     // the guess was too small: once more with exact sizes
+        if (rc) return rc;
     }
     if (info) for (int k = 0; k < 4; k++) info[k] = tail[k];
     if (natoms > 0) {
@@ -228,19 +312,21 @@ extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const 
     }
     GPR_REQUIRE(tail[0] == 0.0, "neighbour table is not symmetric: %d force rows missing", (int)tail[0]);
     // unpack [mean | var]: energies per atom -> total energies, force rows -> [natoms, 3] with zeros at fixed atoms
-    const double *mean = s->pin, *var = s->pin + m;
+    const double *mean = sl.pin, *var = sl.pin + m;
+    const int *atom0 = sl.atom0;
     for (int k = 0; k < nstruct; k++) {
         E[k] = mean[k] * (atom0[k + 1] - atom0[k]);
         if (s->want_std) E_std[k] = dev_std ? var[k] : sqrt(var[k]);
     }
     const double *mf = mean + nstruct, *vf = var + nstruct;
-    if (!free_mask) {
+    if (!sl.masked) {
         memcpy(F, mf, (size_t)3 * natoms * sizeof(double));
         if (s->want_std) {
             if (dev_std) memcpy(F_std, vf, (size_t)3 * natoms * sizeof(double));
             else for (long long i = 0; i < 3LL * natoms; i++) F_std[i] = sqrt(vf[i]);
         }
     } else {
+        const unsigned char *free_mask = sl.mask.data();
         long long r = 0;
         for (int a = 0; a < natoms; a++) {
             if (free_mask[a]) {
@@ -252,4 +338,20 @@ extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const 
         }
     }
     return GPR_OK;
+}
+
+// one batch, synchronous: submit on slot 0 (the caller's stream) and wait
+extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
+                                        const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
+                                        double *E, double *F, double *E_std, double *F_std, double *info) {
+    GPR_REQUIRE(s && nstruct >= 0 && atom0 && E && F && (!s->want_std || (E_std && F_std)), "gpr_dot2_session_predict: null pointer");
+    if (nstruct == 0) return GPR_OK;
+    GPR_REQUIRE(!s->slot[0].busy, "gpr_dot2_session_predict: slot 0 holds a submission that has not been waited for");
+    const int depth = s->depth, next = s->next;
+    s->depth = 1; s->next = 0;                            // slot 0
+    int ticket = -1;
+    int rc = gpr_dot2_session_submit(s, nstruct, atom0, positions, cells, pbc, numbers, fixed, &ticket);
+    s->depth = depth; s->next = next;
+    if (rc) return rc;
+    return gpr_dot2_session_wait(s, ticket, E, F, E_std, F_std, info);
 }

@@ -273,6 +273,43 @@ def potrf_lower_(a, want_dinv=False):
     return (info, dinv) if want_dinv else info
 
 
+class PipelineTimeout(RuntimeError):
+    """the look-ahead schedule of the factorisation gave up waiting for a hand-over (info = -1): a statement about the
+    schedule, never about the matrix"""
+
+
+_timeout_logged = False
+
+
+def potrf_factor(make, log=None, comm=None):
+    """(L, info, dinv) of the matrix `make()` builds.  info = -1 means that a polled hand-over between two running kernels
+    of the factorisation timed out (gpr_hip.h, gpr_potrf_lower_dinv) and says nothing about the matrix, which is partly
+    overwritten by then: the hand-overs are switched to stream events for the rest of the process (said once), the
+    matrix is built again and factored on that schedule.  A second time-out raises PipelineTimeout -- it is never
+    reported as 'not positive definite'.  With a communicator of several ranks `make` may contain collectives, so the
+    ranks agree (one small all-reduce) on whether anyone timed out and repeat together."""
+    global _timeout_logged
+    a = make()
+    info, dinv = potrf_lower_(a, want_dinv=True)
+    timed_out = int(info.item()) == -1
+    if comm is not None and getattr(comm, "size", 1) > 1:
+        flag = torch.tensor([1.0 if timed_out else 0.0], dtype=F64, device=a.device)
+        timed_out = float(comm.all_reduce_sum_(flag).item()) > 0.0
+    if timed_out:
+        check(_lib.lib().gpr_potrf_set_polling(0), "gpr_potrf_set_polling")
+        if not _timeout_logged:
+            _timeout_logged = True
+            msg = ("gpr_potrf_lower: a polled hand-over of the look-ahead timed out; the factorisation now orders its "
+                   "kernels by stream events only and is repeated")
+            (log.warning if log is not None else print)(msg)
+        del a
+        a = make()
+        info, dinv = potrf_lower_(a, want_dinv=True)
+        if int(info.item()) == -1:
+            raise PipelineTimeout("gpr_potrf_lower: hand-over time-out on the event-ordered schedule")
+    return a, info, dinv
+
+
 def tri_inv64(l):
     """inverses of the 64 x 64 diagonal blocks of a lower-triangular factor (the `dinv` of potrf_lower_), for a factor
     that was put together block-wise; also zeroes the strict upper triangle of l"""

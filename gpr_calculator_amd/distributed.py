@@ -58,27 +58,27 @@ def assemble_sharded(train_x, comm, block_fn, ops, nmat=1):
     N = nE + 3 * nF
     shards = shard_points(E[-1], F[-1], comm.size)
     e0, e1, f0, f1 = shards[comm.rank]
-    slab_e = [ops.zeros((e1 - e0, N)) for _ in range(nmat)]
-    slab_f = [ops.zeros((3 * (f1 - f0), N)) for _ in range(nmat)]
+    # every rank holds the whole matrix and fills its own rows of it: the slabs are produced where they stay, the
+    # others' rows arrive in place (Comm.gather_rows_inplace), nothing is padded, stacked or concatenated
+    full = [ops.zeros((N, N)) for _ in range(nmat)]
     if e1 > e0:         # energy rows: columns of the energy points up to the shard's end
         out = block_fn({"energy": slice_energy(E, e0, e1)}, {"energy": slice_energy(E, 0, e1)})
-        for s, o in zip(slab_e, out):
-            s[:, :e1] = o
+        for K, o in zip(full, out):
+            K[e0:e1, :e1] = o
     if f1 > f0:         # force rows: all energy columns, force columns up to the shard's end
         d2 = {"force": slice_force(F, 0, f1)}
         if nE:
             d2 = {"energy": E, "force": d2["force"]}
         out = block_fn({"force": slice_force(F, f0, f1)}, d2)
-        for s, o in zip(slab_f, out):
-            s[:, :nE + 3 * f1] = o
-    ce = [s[1] - s[0] for s in shards]
-    cf = [3 * (s[3] - s[2]) for s in shards]
-    res = []
-    for se, sf in zip(slab_e, slab_f):
-        K = torch.cat((comm.all_gather_rows(se, ce), comm.all_gather_rows(sf, cf)), dim=0)
+        for K, o in zip(full, out):
+            K[nE + 3 * f0:nE + 3 * f1, :nE + 3 * f1] = o
+    row0 = [s[0] for s in shards] + [nE + 3 * s[2] for s in shards]
+    cnt = [s[1] - s[0] for s in shards] + [3 * (s[3] - s[2]) for s in shards]
+    owners = list(range(comm.size)) * 2
+    for K in full:
+        comm.gather_slabs_inplace(K, row0, cnt, owners)
         ops.mirror_lower_(K)
-        res.append(K)
-    return tuple(res)
+    return tuple(full)
 
 
 # ------------------------------------------------------------------------------------------------ row distribution
@@ -127,49 +127,86 @@ class RowBlockCyclic:
 
 def cholesky_block_cyclic(Aloc, dist, comm, ops):
     """In-place lower Cholesky of a symmetric matrix held as block-cyclic row blocks: Aloc [local rows, n] holds, on
-    return, this rank's rows of L (entries above the diagonal are unspecified).  Only the lower triangle is read."""
+    return, this rank's rows of L (entries above the diagonal are unspecified).  Only the lower triangle is read.
+    A diagonal block that is not positive definite sets the owner's info word and the loop carries on (on NaNs) through
+    the same collectives on every rank; potrf_distributed makes the ranks agree on info afterwards."""
     rank, size, nb, n = comm.rank, comm.size, dist.nb, dist.n
+    # row orders of every step, on the device, built once: the gathered panel is rank-major, the update wants global order
+    perms = ops.index_tables([dist.perm_after(k) for k in range(dist.nblk - 1)])
+    buf = ops.new_tiles()
+    panel_rm = ops.zeros((max(n - nb, 0), nb)) if dist.nblk > 1 else None          # rank-major landing zone, reused
     for k in range(dist.nblk):
         k0, kb, owner = k * nb, dist.block_rows(k), k % size
-        buf = ops.new_tiles()
         if rank == owner:
             ops.diag_(Aloc, dist.local_row0(rank, k), k0, kb, buf)
         comm.broadcast_(buf, root=owner)
         c1 = k0 + kb
         if c1 >= n:
-            break
+            return k + 1
         r0, m = dist.rows_after(rank, k)
         if m > 0:
             ops.panel_(buf, Aloc, r0, k0, kb, m)
         counts = [dist.rows_after(q, k)[1] for q in range(size)]
         mine = Aloc[r0:r0 + m, k0:c1].contiguous()
-        panel = comm.all_gather_rows(mine, counts)                  # rank-major
-        panel = ops.take_rows(panel, dist.perm_after(k))            # global order: rows c1 .. n - 1
+        land = panel_rm[:n - c1] if kb == nb else ops.zeros((n - c1, kb))
+        panel = comm.all_gather_rows(mine, counts, out=land)         # rank-major
+        panel = ops.take_rows(panel, perms[k])                      # global order: rows c1 .. n - 1
         if m > 0:
             ops.update_(Aloc, r0, m, k0, kb, panel, c1, n - c1, dist, rank)
-    return Aloc
+    return dist.nblk
 
 
 def gather_factor(Aloc, dist, comm, ops):
     """the full n x n factor on every rank, rows in global order"""
     counts = [dist.local_nrows(q) for q in range(comm.size)]
     full = comm.all_gather_rows(Aloc, counts)
-    return ops.take_rows(full, dist.perm_after(-1))
+    return ops.take_rows(full, ops.index_tables([dist.perm_after(-1)])[0])
 
 
 def potrf_distributed(K, comm, ops, nb=NB):
     """Cholesky of the replicated symmetric matrix K with the work spread over the ranks; returns the replicated L
-    (strict upper triangle zero) and the diagonal-block inverses (see device.potrf_lower_)."""
+    (strict upper triangle zero), the diagonal-block inverses (see device.potrf_lower_) and info -- the SAME info on
+    every rank (0, or the smallest failing pivot index any rank met), so that a matrix that is not positive definite
+    makes every rank raise, as the reference does, instead of leaving some of them in the next collective."""
     n = K.shape[0]
     dist = RowBlockCyclic(n, comm.size, nb)
-    Aloc = ops.take_rows(K, dist.global_rows(comm.rank))
+    Aloc = ops.take_rows(K, ops.index_tables([dist.global_rows(comm.rank)])[0])
     cholesky_block_cyclic(Aloc, dist, comm, ops)
     L = gather_factor(Aloc, dist, comm, ops)
-    return ops.finish_(L)
+    L, dinv, info = ops.finish_(L)
+    return L, dinv, ops.agree_info_(info, comm)
 
 
 # ------------------------------------------------------------------------------------------------ device arithmetic
-class DeviceOps:
+class OpsBase:
+    """what the schedule needs besides arithmetic, the same for every implementation of the local arithmetic"""
+
+    def index_tables(self, tables):
+        """several host index arrays -> index tensors where the matrices live, one upload for all of them"""
+        if not tables:
+            return []
+        lens = [len(t) for t in tables]
+        flat = np.concatenate([np.asarray(t, dtype=np.int64) for t in tables]) if sum(lens) else np.zeros(0, dtype=np.int64)
+        devt = torch.from_numpy(np.ascontiguousarray(flat)).to(self.zeros((0, 0)).device)
+        return list(torch.split(devt, lens))
+
+    def take_rows(self, M, idx):
+        if not torch.is_tensor(idx):
+            idx = torch.from_numpy(np.ascontiguousarray(idx)).to(M.device)
+        return M.index_select(0, idx)
+
+    def agree_info_(self, info, comm):
+        """smallest non-zero info over the ranks (0 if none), identical everywhere"""
+        if comm.size == 1:
+            return info
+        big = 2 ** 30
+        t = torch.where(info != 0, big - info.to(torch.int64), torch.zeros_like(info, dtype=torch.int64)).to(torch.float64)
+        comm.all_reduce_max_(t)
+        v = t.to(torch.int64)
+        return torch.where(v != 0, big - v, v).to(torch.int32)
+
+
+class DeviceOps(OpsBase):
     """local arithmetic of the routines above on the GPU (libgprhip.so)"""
 
     def __init__(self):
@@ -187,9 +224,6 @@ class DeviceOps:
 
     def new_tiles(self):
         return torch.empty(self.ntile, dtype=self.dev.F64, device=self.dev.device())
-
-    def take_rows(self, M, idx):
-        return M.index_select(0, torch.from_numpy(np.ascontiguousarray(idx)).to(M.device))
 
     def _at(self, M, r, c):
         return M.data_ptr() + 8 * (r * int(M.stride(0)) + c)

@@ -7,8 +7,10 @@ What runs where
   * training-set bookkeeping, queue counters, selection policy of add_structure, L-BFGS-B driver:
     host Python, same semantics as the reference;
   * ranks: one process per GPU over torch.distributed (parallel.Comm) where the reference uses
-    mpi4py; the covariance assembly of fit() is sharded over ranks and summed with one all-reduce,
-    predictions of a batch of structures are sharded by structure.
+    mpi4py; the covariance assembly of fit() is sharded by training point -- every rank computes the row slab of its
+    points in place in K, the slabs are exchanged in place (distributed.assemble_sharded) -- large factorisations run
+    block-cyclic over the ranks, the weight-space fit all-reduces its F x F system, and predictions of a batch of
+    structures are dealt to the ranks by structure and returned through one tensor all-reduce.
 
 Differences kept on purpose (documented in DESIGN.md): the predictive variance is evaluated as
 diag - |L^-1 k|^2 (triangular solve) instead of through an explicit K^-1; with the Dot kernel at zeta = 2 the fit,
@@ -40,6 +42,14 @@ except ImportError:
 from .parallel import Comm
 from .utilities import (convert_train_data, list_to_tuple, metric_values, new_pt, species_numbers,
                         tuple_to_list)
+
+
+class _SessionTicket:
+    """a batch handed to predict_structures_submit"""
+    __slots__ = ("ses", "ticket", "keep", "out", "done")
+
+    def __init__(self, ses, ticket, keep, out, done=None):
+        self.ses, self.ticket, self.keep, self.out, self.done = ses, ticket, keep, out, done
 
 
 class GP():
@@ -227,14 +237,19 @@ class GP():
                 llg = res[1] if self.noise_bounds is not None else res[1][:-1]
                 return res[0], llg
 
-        if eval_gradient:
-            K, dK0, dK1, _ = self._train_K(grad=True)
-        else:
-            K = self._train_K()
-        N = K.shape[0]
         NE = self._n_energy_points(self.train_x)
-        dev.add_diag_(K, NE, noise_e ** 2, noise_f ** 2)
-        info, dinv = dev.potrf_lower_(K, want_dinv=True)      # K now holds L
+        grads_of = {}
+
+        def build():
+            if eval_gradient:
+                K, grads_of["dK0"], grads_of["dK1"], _ = self._train_K(grad=True)
+            else:
+                K = self._train_K()
+            dev.add_diag_(K, NE, noise_e ** 2, noise_f ** 2)
+            return K
+        K, info, dinv = dev.potrf_factor(build, self.logging, self.comm)     # K now holds L
+        N = K.shape[0]
+        dK0, dK1 = grads_of.get("dK0"), grads_of.get("dK1")
         if int(info.item()) != 0:
             return (-np.inf, np.zeros_like(params)) if eval_gradient else -np.inf
         L = K
@@ -279,12 +294,16 @@ class GP():
         N, NE, F = len(self.y_train), self._n_energy_points(train_x), S.shape[1]
         zeros = lambda *shape: torch.zeros(shape, dtype=dev.F64, device=S.device)
         have = S.shape[0] > 0
-        G = dev.gemm(S, S, transa=True) if have else zeros(F, F)
         b = dev.gemm(S, yt.reshape(-1, 1), transa=True) if have else zeros(F, 1)
         yy = (yt * yt).sum().reshape(1) if have else zeros(1)
-        self._ws_sum(G, b, yy)
-        G.diagonal().add_(1.0)
-        info, dinv = dev.potrf_lower_(G, want_dinv=True)
+        self._ws_sum(b, yy)
+
+        def build():
+            G = dev.gemm(S, S, transa=True) if have else zeros(F, F)
+            self._ws_sum(G)
+            G.diagonal().add_(1.0)
+            return G
+        G, info, dinv = dev.potrf_factor(build, self.logging, self.comm)
         if int(info.item()) != 0:
             return (-np.inf, np.zeros(3)) if eval_gradient else (-np.inf,)
         u = b.clone()
@@ -379,6 +398,7 @@ class GP():
         self._K_inv_dev = None
         self._Linv_dev = None
         self._ws_cache = None
+        self._drop_session()
         self._host = {}
         # what this fit describes: points queued later (add_structure replaces train_x / y_train by longer arrays, the
         # old ones stay alive here) must not leak into a dense factorisation that is only formed on first access
@@ -402,16 +422,19 @@ class GP():
         lazy: called from an attribute access after a weight-space fit -- possibly on one rank only, possibly after
         more points were queued: no collective, and the set / targets as they were at fit time."""
         train_x, y_train = self._fit_train_x, self._fit_y
-        K = self.kernel.k_total_dev(train_x, comm=None if lazy else self.comm)
         NE = self._n_energy_points(train_x)
-        assert K.shape[0] == len(y_train), (K.shape, len(y_train))
-        dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
-        if not lazy and self.comm.size > 1 and K.shape[0] >= self.dist_chol_min_n:
+
+        def build():
+            K = self.kernel.k_total_dev(train_x, comm=None if lazy else self.comm)
+            assert K.shape[0] == len(y_train), (K.shape, len(y_train))
+            dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
+            return K
+        if not lazy and self.comm.size > 1 and len(y_train) >= self.dist_chol_min_n:
             # rows of K block-cyclic over the ranks, panels exchanged over RCCL (distributed.py); L comes back replicated
             from .distributed import DeviceOps, potrf_distributed
-            K, dinv, info = potrf_distributed(K, self.comm, DeviceOps())
+            K, dinv, info = potrf_distributed(build(), self.comm, DeviceOps())
         else:
-            info, dinv = dev.potrf_lower_(K, want_dinv=True)
+            K, info, dinv = dev.potrf_factor(build, self.logging, None if lazy else self.comm)
         if int(info.item()) != 0:
             raise np.linalg.LinAlgError(f"{int(info.item())}-th leading minor of K + noise is not positive definite")
         alpha = dev.to_dev(y_train).clone()
@@ -468,8 +491,7 @@ class GP():
         perm0 = self._perm_dev if self._perm_dev is not None else torch.arange(N0, device=D)
         Xt = B.index_select(0, perm0).contiguous()                       # rows in the factor's order
         dev.trsm_lower_(d["L"], Xt, dinv=d["dinv"])                      # X^T = L^-1 B
-        S = C - dev.gemm(Xt, Xt, transa=True)
-        info, _ = dev.potrf_lower_(S, want_dinv=True)
+        S, info, _ = dev.potrf_factor(lambda: C - dev.gemm(Xt, Xt, transa=True), self.logging)
         if int(info.item()) != 0:
             return False                                                 # not positive definite in finite precision: refit
         L1 = torch.zeros((N0 + k, N0 + k), dtype=dev.F64, device=D)
@@ -493,6 +515,7 @@ class GP():
         self._K_inv_dev = None
         self._host = {}
         self._ws_cache = None
+        self._drop_session()
         if Linv0 is not None:                                            # extend L^-1 too: -L_s^-1 X L^-1 | L_s^-1
             Ls_inv = torch.eye(k, dtype=dev.F64, device=D)
             dev.trsm_lower_(S, Ls_inv)
@@ -568,11 +591,15 @@ class GP():
         S, y, rs, NE = self._ws_share(train_x, species, self.noise_e, self.noise_f)    # rows of this rank
         F = S.shape[1]
         sig = float(self.kernel.sigma)
-        G = dev.gemm(S, S, transa=True) if S.shape[0] else torch.zeros((F, F), dtype=dev.F64, device=S.device)
         b = (dev.gemv_t(S, y) if S.shape[0] else torch.zeros(F, dtype=dev.F64, device=S.device)).reshape(-1, 1)   # Psi'^T D^-1 y
-        self._ws_sum(G, b)
-        G.diagonal().add_(1.0)
-        info, dinv = dev.potrf_lower_(G, want_dinv=True)
+        self._ws_sum(b)
+
+        def build():
+            G = dev.gemm(S, S, transa=True) if S.shape[0] else torch.zeros((F, F), dtype=dev.F64, device=S.device)
+            self._ws_sum(G)
+            G.diagonal().add_(1.0)
+            return G
+        G, info, dinv = dev.potrf_factor(build, self.logging, self.comm)
         if int(info.item()) != 0:
             return False
         dev.trsm_lower_(G, b, dinv=dinv)
@@ -1110,11 +1137,10 @@ class GP():
             tr.append(("native:exit", time.perf_counter_ns()))
         return res
 
-    def _predict_batch_session(self, strucs, return_std):
-        """(E, F, E_std, F_std) lists of a batch through the host-in / host-out session call gpr_dot2_session_predict
-        (csrc/predict.hip): gather the structures' arrays in one C pass, one native call that queues the device chain,
-        waits for the results in page-locked memory and unpacks them into per-atom arrays.  None when the model or the
-        structures do not fit that route (the other routes take over)."""
+    def _session_submit(self, strucs, return_std, sync):
+        """hand a batch to the prediction session (csrc/predict.hip): gather the structures' arrays in one C pass and
+        either run the synchronous call (sync: returns the finished results) or queue it and return a ticket for
+        _session_collect.  None when the model or the structures do not fit that route (the other routes take over)."""
         if (not self.native_batch or _pygather is None or self.base_potential is not None
                 or not hasattr(self.descriptor, "_device_tables")):
             return None
@@ -1130,9 +1156,11 @@ class GP():
             return None
         from . import _lib
         import ctypes as C
-        key = (id(ws), bool(return_std), float(self.kernel.sigma), float(self.kernel.sigma0))
+        # the session holds device pointers of ONE fitted model: it is tied to the weight-space cache object itself
+        # (kept alive in the tuple, compared by identity -- an id() alone can be handed to the next model's list)
+        key = (bool(return_std), float(self.kernel.sigma), float(self.kernel.sigma0))
         ses = self._session
-        if ses is None or ses[0] != key:
+        if ses is None or ses[3] is not ws or ses[0] != key:
             if ses is not None:
                 _lib.lib().gpr_dot2_session_destroy(ses[1])
             table, nseg, ncheb = des._device_tables()[:3]
@@ -1145,7 +1173,8 @@ class GP():
                 C.byref(h), dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
                 int(bool(des.weight_on)), len(sp), sp.ctypes.data_as(_lib.c_int_p), float(self.kernel.sigma),
                 float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std))), "gpr_dot2_session_create")
-            ses = self._session = (key, h, (table, w, M, Cinv))          # the tuple keeps the device arrays alive
+            dev.check(_lib.lib().gpr_dot2_session_set_depth(h, int(self.session_depth)), "gpr_dot2_session_set_depth")
+            ses = self._session = (key, h, (table, w, M, Cinv), ws)      # the tuple keeps the device arrays alive
         a0 = np.frombuffer(got[0], dtype=np.int32)
         nS, natoms = len(strucs), int(a0[-1])
         fixed = None
@@ -1156,15 +1185,26 @@ class GP():
         E, F = np.empty(nS), np.empty((natoms, 3))
         Es, Fs = (np.empty(nS), np.empty((natoms, 3))) if return_std else (None, None)
         vp = lambda a: None if a is None else a.ctypes.data
+        ins = (a0, np.frombuffer(got[2], dtype=np.float64), np.frombuffer(got[3], dtype=np.float64),
+               np.frombuffer(got[4], dtype=np.int32), np.frombuffer(got[1], dtype=np.int32), fixed)
         if tr is not None:
             tr.append(("native call", time.perf_counter_ns()))
-        dev.check(_lib.lib().gpr_dot2_session_predict(
-            ses[1], nS, a0.ctypes.data, np.frombuffer(got[2], dtype=np.float64).ctypes.data,
-            np.frombuffer(got[3], dtype=np.float64).ctypes.data, np.frombuffer(got[4], dtype=np.int32).ctypes.data,
-            np.frombuffer(got[1], dtype=np.int32).ctypes.data, vp(fixed), E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None),
-            "gpr_dot2_session_predict")
-        if tr is not None:
-            tr.append(("native done", time.perf_counter_ns()))
+        if sync:
+            dev.check(_lib.lib().gpr_dot2_session_predict(
+                ses[1], nS, ins[0].ctypes.data, ins[1].ctypes.data, ins[2].ctypes.data, ins[3].ctypes.data, ins[4].ctypes.data,
+                vp(fixed), E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None), "gpr_dot2_session_predict")
+            if tr is not None:
+                tr.append(("native done", time.perf_counter_ns()))
+            return self._session_shape(a0, nS, natoms, return_std, E, F, Es, Fs)
+        ticket = C.c_int(-1)
+        dev.check(_lib.lib().gpr_dot2_session_submit(
+            ses[1], nS, ins[0].ctypes.data, ins[1].ctypes.data, ins[2].ctypes.data, ins[3].ctypes.data, ins[4].ctypes.data,
+            vp(fixed), C.byref(ticket)), "gpr_dot2_session_submit")
+        # the ticket keeps the gathered input buffers alive until the results are collected
+        return _SessionTicket(ses, int(ticket.value), (got, ins), (a0, nS, natoms, return_std, E, F, Es, Fs))
+
+    @staticmethod
+    def _session_shape(a0, nS, natoms, return_std, E, F, Es, Fs):
         n0 = int(a0[1]) if nS else 0
         none = [None] * nS
         if natoms == nS * n0:
@@ -1174,6 +1214,46 @@ class GP():
         Fl = [F[a0[k]:a0[k + 1]] for k in range(nS)]
         Fsl = [Fs[a0[k]:a0[k + 1]] for k in range(nS)] if return_std else none
         return list(E), Fl, (list(Es) if return_std else none), Fsl
+
+    def _predict_batch_session(self, strucs, return_std):
+        """(E, F, E_std, F_std) of a batch through the host-in / host-out session call gpr_dot2_session_predict"""
+        return self._session_submit(strucs, return_std, sync=True)
+
+    def predict_structures_submit(self, strucs, return_std=True):
+        """Queue predict_structures(strucs) and return at once with a ticket; predict_structures_collect(ticket) hands out
+        the results.  Up to GP.session_depth batches may be in flight: each has its own stream and result buffer
+        (gpr_dot2_session_submit), so the device chains of consecutive batches overlap and the host prepares / unpacks one
+        batch while the device works on the others -- the throughput form of the call (an image band evaluated batch
+        after batch); same numbers as predict_structures, bit for bit.  Models or batches the session route does not take
+        (other kernels, several ranks, a base potential) are evaluated on the spot and the ticket only carries the result."""
+        if self.comm.size == 1 and len(strucs) and self.session_batch:
+            t = self._session_submit(strucs, return_std, sync=False)
+            if t is not None:
+                return t
+        return _SessionTicket(None, -1, None, None, done=self.predict_structures(strucs, return_std=return_std))
+
+    def predict_structures_collect(self, ticket):
+        if ticket.done is not None:
+            res, ticket.done = ticket.done, None
+            return res
+        ses, k, _, out = ticket.ses, ticket.ticket, ticket.keep, ticket.out
+        if ses is None:
+            raise RuntimeError("this ticket has been collected already")
+        if self._session is not ses:
+            raise RuntimeError("the model was refitted while this batch was in flight; its session is gone")
+        from . import _lib
+        a0, nS, natoms, return_std, E, F, Es, Fs = out
+        vp = lambda a: None if a is None else a.ctypes.data
+        dev.check(_lib.lib().gpr_dot2_session_wait(ses[1], k, E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None), "gpr_dot2_session_wait")
+        ticket.ses = ticket.keep = None
+        return self._session_shape(a0, nS, natoms, return_std, E, F, Es, Fs)
+
+    def _drop_session(self):
+        """a (re)fit ends the prediction session of the previous model: its device pointers must never serve another"""
+        ses, self._session = self._session, None
+        if ses is not None:
+            from . import _lib
+            _lib.lib().gpr_dot2_session_destroy(ses[1])
 
     _session = None
     _trace = None               # a list: host timestamps (label, ns) of the native batch call are appended (tools/native_split.py)
@@ -1186,6 +1266,7 @@ class GP():
 
     native_batch = True
     session_batch = True        # one rank: the host-in / host-out session call (False: the Python-side unpacking route)
+    session_depth = 2           # batches predict_structures_submit may have in flight (1 .. 8)
     device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
@@ -1281,12 +1362,32 @@ class GP():
                     results[k] = (E, F, None, None)
                 off += nf
         if size > 1:
-            import torch.distributed as dist
-            box = [None] * size
-            dist.all_gather_object(box, results)
+            # every rank knows the whole batch, hence where each structure's numbers go in one flat vector
+            # [E, E_std, F (3n), F_std (3n)]: the ranks fill their own structures and ONE tensor all-reduce (zeros
+            # elsewhere, so the sum is exact) leaves the complete vector everywhere -- nothing is pickled
+            ns = np.array([len(s) for s in strucs], dtype=np.int64)
+            per = (2 + 6 * ns) if return_std else (1 + 3 * ns)
+            off = np.concatenate(([0], np.cumsum(per)))
+            flat = np.zeros(int(off[-1]))
+            for k, (E, F, es, fs) in results.items():
+                o, n = int(off[k]), int(ns[k])
+                if return_std:
+                    flat[o], flat[o + 1] = E, es
+                    flat[o + 2:o + 2 + 3 * n] = np.asarray(F).reshape(-1)
+                    flat[o + 2 + 3 * n:o + 2 + 6 * n] = np.asarray(fs).reshape(-1)
+                else:
+                    flat[o] = E
+                    flat[o + 1:o + 1 + 3 * n] = np.asarray(F).reshape(-1)
+            t = torch.from_numpy(flat).to(getattr(self.comm, "tensor_device", "cpu"))
+            flat = self.comm.all_reduce_sum_(t).cpu().numpy()
             results = {}
-            for part in box:
-                results.update(part)
+            for k in range(nb):
+                o, n = int(off[k]), int(ns[k])
+                if return_std:
+                    results[k] = (float(flat[o]), flat[o + 2:o + 2 + 3 * n].reshape(n, 3), float(flat[o + 1]),
+                                  flat[o + 2 + 3 * n:o + 2 + 6 * n].reshape(n, 3))
+                else:
+                    results[k] = (float(flat[o]), flat[o + 1:o + 1 + 3 * n].reshape(n, 3), None, None)
         Es, Fs, Es_std, Fs_std = [], [], [], []
         for k in range(nb):
             E, F, es, fs = results[k]

@@ -46,37 +46,88 @@ class Comm:
         return box[0]
 
     def allreduce(self, value, op=None):
-        """sum of a python float / numpy array over ranks (gaussianprocess.py:246-247)"""
+        """sum of a python float / numpy array over ranks (gaussianprocess.py:246-247): one tensor all-reduce, nothing
+        pickled"""
         if not self.active or self.size == 1:
             return value
-        box = [None] * self.size
-        dist.all_gather_object(box, value, group=self.group)
-        out = box[0]
-        for v in box[1:]:
-            out = out + v
-        return out
+        import numpy as np
+        arr = np.asarray(value, dtype=np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(arr).reshape(-1).copy()).to(self.tensor_device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        out = t.cpu().numpy().reshape(arr.shape)
+        return float(out) if arr.ndim == 0 else out
 
     # ---- tensor collectives (device tensors on nccl, cpu tensors on gloo)
-    def all_gather_rows(self, local, counts):
-        """concatenate row slabs [counts[r], ncols] of every rank into [sum(counts), ncols]"""
+    @property
+    def tensor_device(self):
+        """where a tensor has to live to go through this communicator's backend: RCCL moves device memory only"""
+        if self.active and dist.get_backend(self.group) == "nccl":
+            return torch.device("cuda", torch.cuda.current_device())
+        return torch.device("cpu")
+
+    def all_gather_rows(self, local, counts, out=None):
+        """row slabs [counts[r], ncols] of every rank -> [sum(counts), ncols], rank-major, written straight into `out`
+        (allocated here when None).  Equal slabs: one all_gather_into_tensor.  Ragged slabs: rank r's slab is broadcast
+        into its rows of `out` -- every element crosses a link once and lands where it stays; there is no padded
+        staging copy and no concatenation (a 24 250^2 matrix is 4.7 GB: each avoided copy is one of those)."""
         if not self.active or self.size == 1:
-            return local
-        # all_gather wants equal shapes: pad every slab to the largest one, then cut the padding off
-        ncols, cmax = local.shape[1], int(max(counts))
-        padded = torch.zeros((cmax, ncols), dtype=local.dtype, device=local.device)
-        padded[:local.shape[0]] = local
-        parts = [torch.empty_like(padded) for _ in range(self.size)]
-        dist.all_gather(parts, padded, group=self.group)
-        return torch.cat([p[:int(c)] for p, c in zip(parts, counts)], dim=0)
+            if out is None:
+                return local
+            out[:local.shape[0]].copy_(local)
+            return out
+        counts = [int(c) for c in counts]
+        total, ncols = sum(counts), local.shape[1]
+        assert local.shape[0] == counts[self.rank], (local.shape, counts, self.rank)
+        if out is None:
+            out = torch.empty((total, ncols), dtype=local.dtype, device=local.device)
+        assert out.is_contiguous() and tuple(out.shape) == (total, ncols), (out.shape, total, ncols)
+        if total == 0 or ncols == 0:
+            return out
+        if min(counts) == max(counts):
+            dist.all_gather_into_tensor(out, local.contiguous(), group=self.group)
+            return out
+        off, works = 0, []
+        for r, c in enumerate(counts):
+            if c:
+                view = out[off:off + c]
+                if r == self.rank and view.data_ptr() != local.data_ptr():
+                    view.copy_(local)
+                works.append(dist.broadcast(view, src=self._global_rank(r), group=self.group, async_op=True))
+            off += c
+        for w in works:
+            w.wait()
+        return out
+
+    def gather_slabs_inplace(self, full, row0, counts, owners):
+        """`full` [n, ncols] already holds this rank's row slabs (slab i = rows row0[i] : row0[i] + counts[i], computed by
+        rank owners[i]); on return it holds everyone's.  One broadcast per slab, in place: each element crosses a link
+        once and lands where it stays."""
+        if not self.active or self.size == 1:
+            return full
+        works = []
+        for o, c, r in zip(row0, counts, owners):
+            if int(c):
+                works.append(dist.broadcast(full[int(o):int(o) + int(c)], src=self._global_rank(int(r)), group=self.group, async_op=True))
+        for w in works:
+            w.wait()
+        return full
+
+    def _global_rank(self, r):
+        return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def all_reduce_sum_(self, t):
         if self.active and self.size > 1:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
+    def all_reduce_max_(self, t):
+        if self.active and self.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
     def broadcast_(self, t, root=0):
         if self.active and self.size > 1:
-            dist.broadcast(t, src=root, group=self.group)
+            dist.broadcast(t, src=self._global_rank(root), group=self.group)
         return t
 
 

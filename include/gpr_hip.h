@@ -195,6 +195,21 @@ int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0,
                              double *E_std, double *F_std, double *info);
 int gpr_dot2_session_set_hint(gpr_dot2_session *s, double pairs_per_atom, double rows_per_atom);   /* tests / tuning */
 int gpr_dot2_session_destroy(gpr_dot2_session *s);
+/* Several batches in flight (throughput; an image band evaluated batch after batch, or several walkers):
+ *   gpr_dot2_session_submit   queues the whole prediction of one batch and returns at once; *ticket names it.  Every
+ *                             submission in flight has its own page-locked result buffer and its own stream (the first
+ *                             slot is the stream the session was created on), so the short kernels of consecutive
+ *                             batches overlap on the device and the host packs / unpacks one batch while the device
+ *                             works on the others.  The input arrays must stay valid until the matching _wait returns.
+ *   gpr_dot2_session_wait     waits for that submission (polling its status words), repeats it with exact neighbour
+ *                             table sizes if the guess was too small, and unpacks like gpr_dot2_session_predict.
+ *   gpr_dot2_session_set_depth  submissions that may be in flight (1..8, default 2); one more is an error (GPR_ERR_ARG).
+ * Same kernels in the same order per batch: the numbers are bit-identical to gpr_dot2_session_predict.  A session is
+ * used from one host thread at a time. */
+int gpr_dot2_session_submit(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions, const double *cells,
+                            const int *pbc, const int *numbers, const unsigned char *fixed, int *ticket);
+int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E, double *F, double *E_std, double *F_std, double *info);
+int gpr_dot2_session_set_depth(gpr_dot2_session *s, int depth);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
@@ -328,6 +343,19 @@ int gpr_potrf_lower(void *stream, int n, double *a, long long lda, int *info_dev
 /* same, and additionally stores the inverse of every 64 x 64 diagonal block of L (zero padded, row-major,
  * block b at dinv + b*4096) into the device buffer dinv[ceil(n/64)*4096] */
 int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long lda, int *info_dev, double *dinv);
+/* For n > 768 the factorisation runs a look-ahead schedule on two private streams of the device and, where kernels of
+ * different streams overlap in time (probed, and probed again when the answer is older than a second), hands operand
+ * tiles over between RUNNING kernels through polled counters.  A poll that is never answered gives up after a bounded
+ * number of polls and info_dev becomes -1: NOT a statement about the matrix (which is then partly overwritten) but
+ * about the schedule.  The caller restores the matrix, calls gpr_potrf_set_polling(0) -- every hand-over becomes a
+ * stream event from then on -- and factors again (gpr_calculator_amd/device.py: potrf_factor).  Calls on one device
+ * are serialised (host mutex + an event the next call's stream waits for); calls on different devices are independent.
+ *   gpr_potrf_set_polling(0)   events only, for the rest of the process;  (-1): probe again at the next call
+ *   gpr_potrf_polling()        1 when the next factorisation on the current device would poll
+ *   gpr_potrf_debug_max_polls  poll budget on the current device (<= 0: default, about 10 s); tests force the time-out */
+int gpr_potrf_set_polling(int mode);
+int gpr_potrf_polling(void);
+int gpr_potrf_debug_max_polls(int polls);
 /* Pieces of the factorisation for a matrix whose rows are spread over several GPUs (1-D block-cyclic row blocks of 256;
  * gpr_calculator_amd/distributed.py drives them, RCCL moves `ops` and the panels):
  *   gpr_potrf_diag_block   factor the kb x kb (kb <= 256) diagonal block at a in place and write its operand tiles

@@ -8,8 +8,10 @@ import numpy as np
 import torch
 from scipy.linalg import cholesky, solve_triangular
 
+from gpr_calculator_amd.distributed import OpsBase
 
-class HostOps:
+
+class HostOps(OpsBase):
     def __init__(self):
         self.info = torch.zeros(1, dtype=torch.int32)
 
@@ -25,13 +27,16 @@ class HostOps:
     def new_tiles(self):
         return torch.zeros(256 * 256 + 1, dtype=torch.float64)        # the factored diagonal block itself (+ its size)
 
-    def take_rows(self, M, idx):
-        return M[torch.from_numpy(np.asarray(idx, dtype=np.int64))].clone()
-
     def diag_(self, Aloc, r, c, kb, buf):
         a = Aloc.numpy()
         blk = a[r:r + kb, c:c + kb]
-        L = cholesky(np.tril(blk) + np.tril(blk, -1).T, lower=True)     # only the lower triangle is meaningful
+        try:
+            L = cholesky(np.tril(blk) + np.tril(blk, -1).T, lower=True, check_finite=False)     # only the lower triangle is meaningful
+        except np.linalg.LinAlgError:
+            # like the device kernel: record the failing block (first failure wins), carry on with NaNs
+            if int(self.info.item()) == 0:
+                self.info[0] = c + 1
+            L = np.full((kb, kb), np.nan)
         blk[:] = L
         buf[:kb * kb] = torch.from_numpy(L.reshape(-1))
         buf[-1] = kb
@@ -39,7 +44,7 @@ class HostOps:
     def panel_(self, buf, Aloc, r0, c, kb, m):
         L = buf[:kb * kb].numpy().reshape(kb, kb)
         a = Aloc.numpy()
-        a[r0:r0 + m, c:c + kb] = solve_triangular(L, a[r0:r0 + m, c:c + kb].T, lower=True).T
+        a[r0:r0 + m, c:c + kb] = solve_triangular(L, a[r0:r0 + m, c:c + kb].T, lower=True, check_finite=False).T
 
     def update_(self, Aloc, r0, m, c, kb, panel, c1, ncols, dist, rank):
         a = Aloc.numpy()
@@ -99,9 +104,28 @@ class ThreadComm:
             out = out + v
         return out
 
-    def all_gather_rows(self, local, counts):
+    def all_gather_rows(self, local, counts, out=None):
         parts = self._exchange(local)
-        return torch.cat([p[:int(c)] for p, c in zip(parts, counts)], dim=0).clone()
+        cat = torch.cat([p[:int(c)] for p, c in zip(parts, counts)], dim=0)
+        if out is None:
+            return cat.clone()
+        out.copy_(cat)
+        return out
+
+    def gather_slabs_inplace(self, full, row0, counts, owners):
+        mine = [(int(o), int(c), full[int(o):int(o) + int(c)].clone()) for o, c, r in zip(row0, counts, owners) if int(r) == self._rank]
+        for part in self._exchange(mine):
+            for o, c, rows in part:
+                full[o:o + c].copy_(rows)
+        return full
+
+    def all_reduce_max_(self, t):
+        parts = self._exchange(t.clone())
+        total = parts[0].clone()
+        for p in parts[1:]:
+            total = torch.maximum(total, p)
+        t.copy_(total)
+        return t
 
     def all_reduce_sum_(self, t):
         parts = self._exchange(t.clone())

@@ -51,6 +51,13 @@ def _worker(rank, world, port, q):
             A = spd(n, seed=n)
             L, _, info = potrf_distributed(torch.from_numpy(A.copy()), comm, HostOps(), nb=nb)
             out[f"chol_{n}_{nb}"] = L.numpy()
+            out[f"info_{n}_{nb}"] = int(info.item())
+        # not positive definite, and the failing diagonal block (rows 256..511) belongs to rank 1: every rank must come
+        # back with the same non-zero info (and none may be left waiting in a collective)
+        A = spd(700, seed=1)
+        A[300, 300] = -5.0
+        _, _, info = potrf_distributed(torch.from_numpy(A.copy()), comm, HostOps(), nb=256)
+        out["info_indefinite"] = int(info.item())
         kern = og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=NativeSet("port"))
         tx = synthetic_train()
 
@@ -110,6 +117,8 @@ def test_slab_assembly_and_block_cyclic_cholesky_over_gloo(port_natives):
             got = res[r][f"chol_{n}_{nb}"]
             assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max(), (n, nb, r)
             assert np.all(got[np.triu_indices(n, 1)] == 0.0)
+            assert res[r][f"info_{n}_{nb}"] == 0
+    assert res[0]["info_indefinite"] == res[1]["info_indefinite"] == 257       # first column of the failing block, 1-based
     kern = og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=port_natives)
     K = kern.k_total(synthetic_train())
     for r in range(world):

@@ -85,6 +85,94 @@ def test_session_call_matches_the_python_unpacking_route():
     assert np.allclose(c[0], a[0][:0] or c[0])
 
 
+def test_batches_in_flight_give_the_bits_of_the_synchronous_call():
+    """predict_structures_submit / _collect (gpr_dot2_session_submit / _wait: several batches in flight, each on its own
+    stream with its own result buffer) against the synchronous session call: bit-identical E / F / std for uniform,
+    fixed-atom and ragged batches, collected in and out of submission order, with a neighbour-table guess that is too
+    small (the wait repeats the batch with exact sizes) and with more submissions than slots refused"""
+    import ctypes as C
+    from gpr_calculator_amd import _lib
+    from gpr_calculator_amd.synthetic import fcc_cell
+    gp = _model(True, stress=False)
+    gp.session_depth = 3
+    uniform = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(5)]
+    fixed = [fcc_cell(seed=90 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(4)]
+    fixed[1].fixed = np.array([0, 3]); fixed[3].fixed = np.array([2])
+    ragged = uniform[:2] + [fcc_cell(seed=99, reps=2, species=(46,), sigma=0.1)]
+    batches = [uniform, fixed, ragged]
+
+    def same(a, b):
+        for x, y in zip(a, b):
+            assert len(x) == len(y)
+            for u, v in zip(x, y):
+                assert (u is None and v is None) or np.array_equal(np.asarray(u), np.asarray(v))
+    for std in (True, False):
+        want = [gp.predict_structures(b, return_std=std) for b in batches]
+        for order in ((0, 1, 2), (2, 0, 1)):
+            tickets = [gp.predict_structures_submit(b, return_std=std) for b in batches]
+            assert all(t.ses is not None for t in tickets)                  # really queued, not evaluated on the spot
+            got = {k: gp.predict_structures_collect(tickets[k]) for k in order}
+            for k in range(3):
+                same(got[k], want[k])
+        # a steady pipeline: submit k + 1 before collecting k, the way bench.py drives it
+        prev, outs = gp.predict_structures_submit(batches[0], return_std=std), []
+        for k in range(1, 7):
+            nxt = gp.predict_structures_submit(batches[k % 3], return_std=std)
+            outs.append(gp.predict_structures_collect(prev))
+            prev = nxt
+        outs.append(gp.predict_structures_collect(prev))
+        for k, o in enumerate(outs):
+            same(o, want[k % 3])
+    # a guess that is too small: the wait notices the overflow flag and repeats with exact sizes
+    want = gp.predict_structures(uniform, return_std=True)
+    _lib.lib().gpr_dot2_session_set_hint(gp._session[1], 1.0, 1.0)
+    t1, t2 = gp.predict_structures_submit(uniform, return_std=True), gp.predict_structures_submit(fixed, return_std=True)
+    same(gp.predict_structures_collect(t1), want)
+    gp.predict_structures_collect(t2)
+    # more submissions than slots: refused with a message, nothing queued, the session stays usable
+    ts = [gp.predict_structures_submit(uniform, return_std=True) for _ in range(3)]
+    with pytest.raises(RuntimeError, match="waiting already"):
+        gp.predict_structures_submit(uniform, return_std=True)
+    for t in ts:
+        same(gp.predict_structures_collect(t), want)
+    with pytest.raises(RuntimeError, match="collected already"):
+        gp.predict_structures_collect(ts[0])
+    # a refit while a batch is in flight ends the session; the stale ticket says so
+    t = gp.predict_structures_submit(uniform, return_std=True)
+    gp.fit(show=False, opt=False)
+    with pytest.raises(RuntimeError, match="refitted"):
+        gp.predict_structures_collect(t)
+    same(gp.predict_structures(uniform, return_std=True), want)
+
+
+def test_session_never_serves_the_previous_model():
+    """predict -> add_structure -> fit(opt=False) -> predict: same sigma / sigma0 before and after, so only the
+    identity of the fitted model tells the two sessions apart.  The session route must give what the non-session route
+    gives for the NEW model, several times in a row (each refit frees and reallocates the weight-space cache)."""
+    from gpr_calculator_amd.synthetic import fcc_cell, lj_energy_forces
+    gp = _model(True, stress=False)
+    batch = [fcc_cell(seed=80 + k, reps=1, species=(46, 78), sigma=0.08) for k in range(3)]
+    before = gp.predict_structures(batch, return_std=True)
+    assert gp._session is not None
+    for seed in (60, 61, 62):
+        new = fcc_cell(seed=seed, reps=1, species=(46, 78), sigma=0.25)
+        E, F = lj_energy_forces(new)
+        gp.add_structure((new, E, F.copy()))
+        assert gp.N_queue > 0
+        gp.fit(show=False, opt=False)
+        assert gp._session is None                             # the refit ended the old model's session
+        gp.session_batch = True
+        a = gp.predict_structures(batch, return_std=True)
+        gp.session_batch = False
+        b = gp.predict_structures(batch, return_std=True)
+        gp.session_batch = True
+        for x, y in zip(a, b):
+            for u, v in zip(x, y):
+                assert np.array_equal(np.asarray(u), np.asarray(v))
+        assert np.abs(np.asarray(a[0]) - np.asarray(before[0])).max() > 0.0      # and the model did change
+        before = a
+
+
 def test_appended_fit_matches_a_full_refit():
     """fit(opt=False) after add_structure with unchanged hyper-parameters extends the Cholesky factor by the queued
     rows (trsm + a small potrf) instead of rebuilding K: same alpha_, _K_inv, predictions and std as the full refit, twice

@@ -72,3 +72,78 @@ def test_event_only_schedule_matches(gpu):
     res = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "potrf_check.py"), "1025", "2049"], env=env, cwd=ROOT,
                          capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "ALL OK" in res.stdout, res.stdout + res.stderr
+
+
+def test_poll_timeout_is_a_schedule_event_not_a_verdict_on_the_matrix(gpu):
+    """A hand-over between two running kernels that is never answered (forced: a poll budget of one) makes the native
+    call return info = -1 with the matrix partly overwritten.  device.potrf_factor then orders the kernels by events
+    for the rest of the process, builds the matrix again and factors it: a correct L, info = 0, and -- for a matrix that
+    really is indefinite -- still the pivot index, never -1."""
+    import torch
+    from scipy.linalg import cholesky
+    from gpr_calculator_amd import device as dev
+    n = 2049
+    A = _spd(n, 11)
+    L = cholesky(A, lower=True)
+    if not gpu.gpr_potrf_polling():
+        # fill the context (first factorisation with look-ahead probes the device)
+        dev.potrf_lower_(torch.tensor(A, device="cuda"))
+    if not gpu.gpr_potrf_polling():
+        pytest.skip("kernels of two streams do not overlap here (profiler attached?): nothing polls, nothing can time out")
+    try:
+        assert gpu.gpr_potrf_debug_max_polls(1) == 0
+        t = torch.tensor(A, device="cuda")
+        assert int(dev.potrf_lower_(t).item()) == -1                  # the raw call: time-out reported as such
+        assert gpu.gpr_potrf_polling() == 1                           # ... and nothing switched behind the caller's back
+        built = []
+
+        def make():
+            built.append(1)
+            return torch.tensor(A, device="cuda")
+        got, info, dinv = dev.potrf_factor(make)
+        assert len(built) == 2 and int(info.item()) == 0
+        assert gpu.gpr_potrf_polling() == 0                           # events only from here on
+        assert np.abs(got.cpu().numpy() - L).max() / np.abs(L).max() < 1e-13
+        B = A.copy()
+        B[1500, 1500] = -1.0
+        _, info, _ = dev.potrf_factor(lambda: torch.tensor(B, device="cuda"))
+        assert int(info.item()) == 1501
+    finally:
+        gpu.gpr_potrf_debug_max_polls(0)
+        gpu.gpr_potrf_set_polling(-1)
+    # back on the polled schedule (probed again), same factor
+    t = torch.tensor(A, device="cuda")
+    assert int(dev.potrf_lower_(t).item()) == 0
+    assert gpu.gpr_potrf_polling() == 1
+    assert np.abs(t.cpu().numpy() - L).max() / np.abs(L).max() < 1e-13
+
+
+def test_two_host_threads_factor_at_once(gpu):
+    """two factorisations with look-ahead enqueued from two host threads on two streams: they share the look-ahead
+    context of the device (flag words, private streams) and are serialised by it -- both factors are right"""
+    import threading
+    import torch
+    from scipy.linalg import cholesky
+    from gpr_calculator_amd import device as dev
+    mats = [_spd(1800, 21), _spd(2100, 22)]
+    refs = [cholesky(a, lower=True) for a in mats]
+    out, err = [None, None], []
+
+    def work(k):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):
+                    t = torch.tensor(mats[k], device="cuda")
+                    info = dev.potrf_lower_(t)
+                    out[k] = (int(info.item()), t.cpu().numpy())
+        except Exception as e:      # noqa: BLE001
+            err.append(e)
+    ts = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not err, err
+    for k in range(2):
+        assert out[k][0] == 0
+        assert np.abs(out[k][1] - refs[k]).max() / np.abs(refs[k]).max() < 1e-13

@@ -40,6 +40,18 @@ def _worker_body(rank, world, port, q):
     counts = [3, 5]
     local = torch.full((counts[rank], 4), float(rank + 1), dtype=torch.float64)
     out["gather"] = comm.all_gather_rows(local, counts).numpy()
+    # equal slabs take the single all_gather_into_tensor; a caller-provided landing zone is filled in place
+    land = torch.zeros((8, 4), dtype=torch.float64)
+    got = comm.all_gather_rows(torch.full((4, 4), float(rank + 1), dtype=torch.float64), [4, 4], out=land)
+    out["gather_equal"] = (got.data_ptr() == land.data_ptr(), land.numpy().copy())
+    # slabs computed in place in the full matrix, then exchanged in place (covariance assembly)
+    full = torch.zeros((6, 3), dtype=torch.float64)
+    row0, cnt, owners = [0, 2, 3, 5], [2, 1, 2, 1], [0, 1, 0, 1]
+    for o, c, r in zip(row0, cnt, owners):
+        if r == rank:
+            full[o:o + c] = 10.0 * (r + 1) + torch.arange(o, o + c, dtype=torch.float64)[:, None]
+    out["slabs"] = comm.gather_slabs_inplace(full, row0, cnt, owners).numpy().copy()
+    out["max"] = comm.all_reduce_max_(torch.tensor([float(rank), 5.0 - rank], dtype=torch.float64)).numpy().copy()
     # all-reduce of a sharded matrix: every element owned by exactly one rank -> exact sum
     full = torch.arange(24, dtype=torch.float64).reshape(4, 6) * 0.1
     mine = torch.zeros_like(full)
@@ -78,6 +90,10 @@ def test_comm_world2_gloo():
         assert o["bcast"] == {"params": [1.5, 0]}
         assert np.allclose(o["allreduce"], [3.0, 6.0])
         assert o["gather"].shape == (8, 4) and (o["gather"][:3] == 1).all() and (o["gather"][3:] == 2).all()
+        assert o["gather_equal"][0] and (o["gather_equal"][1][:4] == 1).all() and (o["gather_equal"][1][4:] == 2).all()
+        want = np.array([10.0, 11.0, 22.0, 13.0, 14.0, 25.0])[:, None] * np.ones((1, 3))
+        assert np.array_equal(o["slabs"], want)
+        assert np.array_equal(o["max"], [1.0, 5.0])
         assert o["reduce_exact"]
         assert o["structures"] == {k: k * k for k in range(7)}
 
