@@ -122,4 +122,5 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
 // small helpers
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
 int gpr_dev_free(void *p, hipStream_t st);
+int gpr_dev_cache_drop_stream(hipStream_t st);      // before hipStreamDestroy: cached temporaries of that stream go back to the driver
 void gpr_reap_sets();   // frees the host side of destroyed sets whose stream work has completed

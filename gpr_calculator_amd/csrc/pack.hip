@@ -126,6 +126,25 @@ int gpr_dev_free(void *p, hipStream_t st) {
     return GPR_OK;
 }
 
+// A stream is about to be destroyed: hand its cached blocks back to the driver first (a cached block remembers the
+// stream it was freed on and would otherwise be released on a dangling handle when it falls out of the cache).
+int gpr_dev_cache_drop_stream(hipStream_t st) {
+    std::vector<cached_block> out;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (size_t i = 0; i < g_cache.size();) {
+            if (g_cache[i].st == st) {
+                out.push_back(g_cache[i]);
+                g_cached_bytes -= g_cache[i].bytes;
+                g_sizes.erase(g_cache[i].p);
+                g_cache.erase(g_cache.begin() + (long)i);
+            } else i++;
+        }
+    }
+    for (const cached_block &c : out) release_to_driver(c.p, c.st);
+    return GPR_OK;
+}
+
 extern "C" int gpr_memcpy_dtod(void *stream, void *dst, const void *src, long long bytes) {
     if (bytes <= 0) return GPR_OK;
     GPR_REQUIRE(dst && src, "gpr_memcpy_dtod: null pointer");

@@ -520,8 +520,8 @@ struct lookahead_ctx {
         ev.clear();
         if (end_ev) (void)hipEventDestroy(end_ev);
         if (flag) (void)hipFree(flag);
-        if (mid) (void)hipStreamDestroy(mid);
-        if (side) (void)hipStreamDestroy(side);
+        if (mid) { (void)gpr_dev_cache_drop_stream(mid); (void)hipStreamDestroy(mid); }
+        if (side) { (void)gpr_dev_cache_drop_stream(side); (void)hipStreamDestroy(side); }
         end_ev = nullptr; flag = nullptr; mid = side = nullptr; ready = false; end_valid = false;
         (void)hipGetLastError();
     }

@@ -132,8 +132,8 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
 //                                       Same kernels, same order inside a batch: results are bit-identical to _predict.
 constexpr int SESSION_SLOTS = 8;
 struct session_slot {
-    hipStream_t st = nullptr;
-    bool own_stream = false;
+    hipStream_t st = nullptr;       // slot 0: the caller's stream (which may be the null stream)
+    bool has_stream = false, own_stream = false;
     double *pin = nullptr;          // page-locked [2 m + 4]
     double *pin_dev = nullptr;      // its device address
     long long pin_cap = 0;
@@ -170,6 +170,7 @@ extern "C" int gpr_dot2_session_create(gpr_dot2_session **out, void *stream, int
     s->table = so3_table; s->weight_on = weight_on; s->ns = ns; s->species.assign(species_host, species_host + ns);
     s->sigma = sigma; s->sigma0 = sigma0; s->w = w_dev; s->M = M_dev; s->Cinv = Cinv_dev; s->want_std = want_std;
     s->slot[0].st = s->st;          // slot 0 works on the caller's stream: the synchronous call behaves as it always did
+    s->slot[0].has_stream = true;
     *out = s;
     return GPR_OK;
 }
@@ -191,9 +192,9 @@ extern "C" int gpr_dot2_session_set_depth(gpr_dot2_session *s, int depth) {
 extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
     if (!s) return GPR_OK;
     for (session_slot &sl : s->slot) {
-        if (sl.busy && sl.st) (void)hipStreamSynchronize(sl.st);      // the device still writes into sl.pin
+        if (sl.busy && sl.has_stream) (void)hipStreamSynchronize(sl.st);      // the device still writes into sl.pin
         if (sl.pin) (void)hipHostFree(sl.pin);
-        if (sl.own_stream && sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+        if (sl.own_stream && sl.st) { (void)gpr_dev_cache_drop_stream(sl.st); (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
     }
     if (s->model_ready) (void)hipEventDestroy(s->model_ready);
     (void)hipGetLastError();
@@ -203,10 +204,10 @@ extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
 
 // a private stream for slot k >= 1: behind everything queued on the session's stream so far (the model arrays)
 static int session_slot_stream(gpr_dot2_session *s, session_slot &sl) {
-    if (sl.st) return GPR_OK;
+    if (sl.has_stream) return GPR_OK;
     if (!s->model_ready) GPR_HIP_TRY(hipEventCreateWithFlags(&s->model_ready, hipEventDisableTiming));
     GPR_HIP_TRY(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
-    sl.own_stream = true;
+    sl.own_stream = sl.has_stream = true;
     GPR_HIP_TRY(hipEventRecord(s->model_ready, s->st));
     GPR_HIP_TRY(hipStreamWaitEvent(sl.st, s->model_ready, 0));
     return GPR_OK;

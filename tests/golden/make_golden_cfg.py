@@ -81,29 +81,61 @@ def _worker_rows(job):
 
 class CachedTrainK:
     """kernel proxy: k_total(train_x) with no second argument returns the pre-computed matrix (a copy: GP.fit
-    adds the noise in place); everything else goes to the reference kernel object"""
+    adds the noise in place); everything else goes to the reference kernel object.  The last cross-covariance
+    k_total(data1, data2) the GP asked for (K_trans of a prediction) is remembered in `last_cross`."""
 
     def __init__(self, kernel):
         object.__setattr__(self, "_k", kernel)
         object.__setattr__(self, "K", None)
+        object.__setattr__(self, "last_cross", None)
 
     def __getattr__(self, name):
         if name == "k_total":
             def k_total(data1, data2=None, *a, **kw):
                 if data2 is None and self.K is not None:
                     return self.K.copy()
-                return self._k.k_total(data1, data2, *a, **kw)
+                out = self._k.k_total(data1, data2, *a, **kw)
+                if data2 is not None:
+                    object.__setattr__(self, "last_cross", (data1, out))
+                return out
             return k_total
         return getattr(self._k, name)
 
     def __setattr__(self, name, value):
-        if name == "K":
+        if name in ("K", "last_cross"):
             object.__setattr__(self, name, value)
         else:
             setattr(self._k, name, value)
 
     def __str__(self):
         return str(self._k)
+
+
+def stable_variance_longdouble(L, K_trans, diag):
+    """diag - |L^-1 k|^2 (the quantity gaussianprocess.py:903-907 forms through an explicit K^-1) from the reference's
+    own L, K_trans and diag, forward substitution and sums in np.longdouble: the variance free of the cond(K) * eps
+    noise of the explicit inverse, for the tests to hold the device against at 1e-6 / 1e-5"""
+    L = np.asarray(L)
+    n, m = L.shape[0], K_trans.shape[0]
+    V = np.array(K_trans.T, dtype=np.longdouble)                   # [n, m], overwritten by L^-1 K_trans^T row by row
+    Ld = L.astype(np.longdouble)
+    for i in range(n):
+        if i:
+            V[i] -= Ld[i, :i] @ V[:i]
+        V[i] /= Ld[i, i]
+    return np.asarray(np.asarray(diag, dtype=np.longdouble) - (V * V).sum(axis=0), dtype=np.float64)
+
+
+def record_std_inputs(p, key, L, K_trans, diag, std):
+    """what pins sigma at full size: the prior variances, the long-double stable variance, three probe rows of the
+    reference's K_trans (first, second, last), and how far the reference's recorded sigma^2 is from the stable one"""
+    var = stable_variance_longdouble(L, K_trans, diag)
+    p[key + "_diag"], p[key + "_var_stable"] = np.asarray(diag), var
+    rows = np.array([0, 1, K_trans.shape[0] - 1])
+    p[key + "_K_trans_rows"], p[key + "_K_trans_probe"] = rows, np.asarray(K_trans)[rows]
+    rec = np.asarray(std, dtype=np.float64).reshape(-1) ** 2
+    print(f"    stable variance: min {var.min():.3e} max {var.max():.3e}; recorded sigma^2 differs by up to "
+          f"{np.abs(rec - np.clip(var, 0, None)).max():.3e}", flush=True)
 
 
 def cfg3(args):
@@ -144,6 +176,10 @@ def cfg3(args):
         a = images[img]
         t = refshim.RefAtoms(a.numbers, a.positions, a.cell, a.pbc, fixed=fixed)
         data, E, F, E_std, F_std = predict_lists(ns, gp, des, t, fixed)
+        d1, K_trans = gp.kernel.last_cross
+        diag = kern.diag({"energy": data["energy"], "force": list(data["force"])})
+        free = [i for i in range(len(t)) if i not in set(fixed)]
+        record_std_inputs(p, f"test{k}", gp.L_, K_trans, diag, np.concatenate(([E_std], F_std[free].reshape(-1))))
         p[f"test{k}_image"], p[f"test{k}_fixed"] = img, np.asarray(fixed, int)
         p[f"test{k}_positions"] = a.positions
         p[f"test{k}_E"], p[f"test{k}_F"], p[f"test{k}_E_std"], p[f"test{k}_F_std"] = E, F, E_std, F_std
@@ -161,7 +197,7 @@ def cfg2(args):
     t0 = time.time()
     ns = refshim.import_reference()
     rows = training_rows(args.n_train)
-    gp, kern, des = build_gp(ns, "RBF", [2.5, 1.3], rows)
+    gp, kern, des = build_gp(ns, "RBF", [2.5, 1.3], rows, kernel_wrap=CachedTrainK)
     print(f"descriptors done {time.time() - t0:.0f} s", flush=True)
     gp.fit(show=False, opt=False)
     print(f"fit done {time.time() - t0:.0f} s", flush=True)
@@ -174,6 +210,10 @@ def cfg2(args):
         a = images[img]
         t = refshim.RefAtoms(a.numbers, a.positions, a.cell, a.pbc, fixed=fixed)
         E, F, S, E_std, F_std = gp.predict_structure(t, stress=False, return_std=True, f_tol=1e-12)
+        d1, K_trans = gp.kernel.last_cross
+        diag = kern.diag({"energy": d1["energy"], "force": list(d1["force"])})
+        free = [i for i in range(len(t)) if i not in set(fixed)]
+        record_std_inputs(p, f"test{k}", gp.L_, K_trans, diag, np.concatenate(([E_std], F_std[free].reshape(-1))))
         p[f"test{k}_image"], p[f"test{k}_fixed"], p[f"test{k}_positions"] = img, np.asarray(fixed, int), a.positions
         p[f"test{k}_E"], p[f"test{k}_F"], p[f"test{k}_E_std"], p[f"test{k}_F_std"] = E, F, E_std, F_std
         print(f"  test {k}: image {img} E {E:.6f} E_std {E_std:.3e} at {time.time() - t0:.0f} s", flush=True)

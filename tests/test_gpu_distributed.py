@@ -105,3 +105,38 @@ def test_fit_and_lml_over_ranks_match_single_rank(kind):
         assert abs(lml - lml1) < 1e-9 * abs(lml1) and np.abs(g - g1).max() < 1e-7 * np.abs(g1).max()
         assert abs(E - E1) < 1e-7 and np.abs(F - F1).max() < 1e-7 and abs(s - s1) < 1e-7 and np.abs(fs - fs1).max() < 1e-7
         assert np.abs(alpha - single.alpha_).max() < 1e-7 * np.abs(single.alpha_).max()
+
+
+def test_cfg4_sharded_assembly_and_block_cyclic_cholesky_at_full_size():
+    """BASELINE.json configs[3]: N_train = 8000 (N = 24 250) sharded 4-way.  Four thread ranks on the one device run the
+    production schedule with the device arithmetic: (i) the block-cyclic factorisation -- owner factors, tile broadcast,
+    panel solve, panel all-gather into a reused landing zone, device-resident row permutations, trailing update, factor
+    gather -- against the single-GPU factor; (ii) the point-sharded covariance assembly -- every rank's row slabs
+    computed in place in its copy of K, exchanged in place, mirrored -- against the single-rank matrix.  What is not
+    covered here is the transport itself (RCCL over xGMI needs four GPUs; the gloo tests drive the same calls on CPU)."""
+    from gpr_calculator_amd import device as dev
+    from gpr_calculator_amd.distributed import DeviceOps, potrf_distributed
+    n, size = 24250, 4
+    d = dev.device()
+    torch.manual_seed(0)
+    B = torch.randn(n, 2048, dtype=torch.float64, device=d)
+    A = B @ B.T
+    A.diagonal().add_(0.05 * n)
+    del B
+    ref = A.clone()
+    info, dinv_ref = dev.potrf_lower_(ref, want_dinv=True)
+    assert int(info.item()) == 0
+    outs = run_ranks(size, lambda comm: potrf_distributed(A, comm, DeviceOps()))
+    for (L, dinv, info_d) in outs:
+        assert int(info_d.item()) == 0
+        assert rel(L, ref) < 1e-12
+        assert float((dinv - dinv_ref).abs().max()) < 1e-10 * float(dinv_ref.abs().max())
+    del outs, ref, A, dinv_ref
+    torch.cuda.empty_cache()
+    gp = build("RBF", 8000)
+    assert len(gp.y_train) == n
+    K1 = gp.kernel.k_total_dev(gp.train_x)
+    errs = run_ranks(size, lambda comm: (rel(gp.kernel.k_total_dev(gp.train_x, comm=comm), K1)))
+    assert max(errs) < 1e-13, errs
+    del K1
+    torch.cuda.empty_cache()
