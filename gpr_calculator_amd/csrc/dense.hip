@@ -2,6 +2,10 @@
 // Cholesky factor, triangular solves, GEMM, and the small reductions around them.
 // Replaces scipy.linalg.cholesky / cho_solve / solve_triangular and the numpy products of
 // gaussianprocess.py:128-131, 288-299, 880, 903-907.  Row-major storage throughout.
+#include <cstdlib>
+#include <cstdint>
+#include <mutex>
+#include <unordered_map>
 #include "gpr_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -569,6 +573,293 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
     }
 }
 
+// ---- the many-row form again, with the tiles brought into LDS by the DMA path (global_load_lds_dwordx4) instead of
+// through registers.  Same decomposition as ws_tail_kernel<64, 2, 8>: a workgroup of eight wavefronts owns 64 rows of P and
+// the column blocks x and ncb - 1 - x of Q = P C^-T; ws_tail_combine_kernel adds the parts.  What changes is the staging:
+//   * a k tile (32 columns) of an operand is an LDS image of 256-byte rows, [row][16 slots][2 doubles]; one DMA
+//     instruction moves 4 rows x 256 B (whole cache lines), lane (rr, jj) -> LDS offset lane x 16 B, as the instruction
+//     demands, and the bank spread comes from the SOURCE side: slot jj of row r holds the column pair jj ^ (r & 15);
+//   * an MFMA operand read is then one ds_read_b128 per lane and TWO matrix steps -- lane (c, q) of step pair t reads
+//     slot (4 t + q) ^ c of row c: sixteen rows hit sixteen different slots, no bank conflict -- with the k order
+//     inside a tile permuted identically for both operands (k = 2 (4 t + q) + e);
+//   * no tile ever sits in VGPRs, so the loads of tile t + 1 are issued before the products of tile t and nothing but
+//     the wait at the end of the step depends on them (the register-staged form drained its loads at the top of every
+//     step: the compiler places the wait at the first predicated use).
+// Columns beyond kend and rows beyond the matrix are read from a block of zeros (the source address is per lane).
+// Requires n, ldp, ldc even and 16-byte aligned operands (a pair never straddles the end of a row); other shapes
+// keep the register-staged kernel.
+typedef __attribute__((address_space(3))) void lds_void_t;
+__device__ __attribute__((aligned(16))) double g_tail_zero[2] = {0.0, 0.0};
+constexpr int TG_R = 64, TG_C = 128, TG_K = 32, TG_NW = 8, TG_NS = 3;        // three stages: two tiles in flight
+constexpr int TG_STAGE = (TG_R + TG_C) * TG_K;                       // doubles per stage: A image then B image
+constexpr size_t tg_lds_bytes() { return (size_t)(TG_NS * TG_STAGE + TG_NW * TG_R + 512) * sizeof(double); }
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+__global__ void __launch_bounds__(64 * TG_NW) ws_tail_glds_kernel(int m, int n, const double *__restrict__ P, long long ldp,
+                                                                 const double *__restrict__ Ci, long long ldc,
+                                                                 const double *__restrict__ w, double *__restrict__ part,
+                                                                 double *__restrict__ mn, int *__restrict__ cnt, int dbg) {
+    // dbg (tools/tail_bench.py, GPR_TAIL_DBG): 1 no DMA loads, 2 no matrix products, 4 no operand reads from LDS
+    extern __shared__ __attribute__((aligned(16))) double tg_smem[];
+    double *red = tg_smem + TG_NS * TG_STAGE, *sW = red + TG_NW * TG_R;  // [NW][64] | w, zero padded to 512
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bm0 = blockIdx.y * TG_R;
+    const int ncb = (n + TG_C - 1) / TG_C;
+    if (cnt && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *cnt = 0;       // arrival counter of the combine launch
+    sW[tid] = tid < n ? w[tid] : 0.0;                                           // n <= 512 (host checks)
+    const int c = lane & 15, q = lane >> 4;
+    // the six DMA instructions of this wavefront per tile: ids wave, wave + 8, ...; id < 16: rows 4 id .. of the A image,
+    // else rows 4 (id - 16) .. of the B image.  Lane (rr = lane >> 4, jj = lane & 15): row 4 id' + rr, column pair jj ^ (row & 15)
+    const int rr = lane >> 4, jj = lane & 15;
+    double sq[4][4];
+    double mean2 = 0.0, norm2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { sq[i][0] = 0.0; sq[i][1] = 0.0; sq[i][2] = 0.0; sq[i][3] = 0.0; }
+    const int nturn = ((int)blockIdx.x * 2 + 1 == ncb) ? 1 : 2;
+    // Barriers are raw s_barrier (+ lgkmcnt) and the DMA queue is counted by hand: __syncthreads() would drain it
+    // (vmcnt(0)) and with it the tile that is meant to stay in flight across the barrier.
+    auto barrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); asm volatile("" ::: "memory"); };
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int turn = 0; turn < nturn; turn++) {
+        const int cb = turn == 0 ? (int)blockIdx.x : ncb - 1 - (int)blockIdx.x;
+        const int bn0 = cb * TG_C;
+        const int kend = min(n, bn0 + TG_C);
+        const bool last = cb == ncb - 1;
+        const int nkt = (kend + TG_K - 1) / TG_K;
+        // per-instruction source rows (fixed over the k loop)
+        const double *src[6];
+        int pk[6];                                                   // first column of this lane's pair inside a tile
+        bool rok[6];
+#pragma unroll
+        for (int u = 0; u < 6; u++) {
+            const int id = wave + 8 * u;
+            const bool isA = id < 16;
+            const int row = 4 * (isA ? id : id - 16) + rr;
+            pk[u] = 2 * (jj ^ (row & 15));
+            if (isA) { const int g = bm0 + row; rok[u] = g < m; src[u] = P + (long long)min(g, m - 1) * ldp + pk[u]; }
+            else { const int g = bn0 + row; rok[u] = g < n; src[u] = Ci + (long long)min(g, n - 1) * ldc + pk[u]; }
+        }
+        auto issue = [&](int kt) {
+            double *stage = tg_smem + (kt % TG_NS) * TG_STAGE;
+            const int k0 = kt * TG_K;
+            if (dbg & 1) return;
+#pragma unroll
+            for (int u = 0; u < 6; u++) {
+                const int id = wave + 8 * u;
+                double *dst = stage + 4 * id * TG_K;                 // the B image follows the A image: row 4 id of the stage
+                const double *g = (rok[u] && k0 + pk[u] < kend) ? src[u] + k0 : g_tail_zero;
+                __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_t *)dst, 16, 0, 0);
+            }
+        };
+        d4 acc[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+        // two tiles ahead.  Iteration kt: queue tile kt + 2 (its stage was last read in iteration kt - 1, which every
+        // wavefront has left through the barrier), multiply tile kt, wait until this wavefront's pieces of tile kt + 1
+        // have landed (all but the six newest DMA instructions), barrier: tile kt + 1 is then complete for everybody.
+        issue(0);
+        if (nkt > 1) { issue(1); asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        barrier();
+        for (int kt = 0; kt < nkt; kt++) {
+            if (kt + 2 < nkt) issue(kt + 2);
+            const double *sA = tg_smem + (kt % TG_NS) * TG_STAGE, *sB = sA + TG_R * TG_K;
+            d2v a[2][4], b[2];
+            auto frag = [&](int t, int f) {
+                const int slot = 2 * ((4 * t + q) ^ c);
+                b[f] = *(const d2v *)(sB + (16 * wave + c) * TG_K + slot);
+#pragma unroll
+                for (int i = 0; i < 4; i++) a[f][i] = *(const d2v *)(sA + (16 * i + c) * TG_K + slot);
+            };
+            if (dbg & 4) { b[0] = b[1] = d2v{1.0 + kt, 2.0}; for (int i = 0; i < 4; i++) a[0][i] = a[1][i] = d2v{0.5 * i, 1.5}; }
+            else frag(0, 0);
+#pragma unroll
+            for (int t = 0; t < 4; t++) {
+                if (t < 3 && !(dbg & 4)) frag(t + 1, (t + 1) & 1);   // the next operands are on their way during these products
+                if (dbg & 2) { for (int i = 0; i < 4; i++) acc[i][0] += a[t & 1][i].x * b[t & 1].y; continue; }
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t & 1][i].x, b[t & 1].x, acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 4; i++) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t & 1][i].y, b[t & 1].y, acc[i], 0, 0, 0);
+            }
+            if (last) {
+                // P w and |p|^2 off the A image: thread (row = tid >> 3, slots 2 g, 2 g + 1), four columns per tile
+                const int row = tid >> 3, g = tid & 7, k0 = kt * TG_K;
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const int slot = 2 * g + e;
+                    const d2v v = *(const d2v *)(sA + row * TG_K + 2 * slot);
+                    const int k = k0 + 2 * (slot ^ (row & 15));
+                    mean2 += v.x * sW[k] + v.y * sW[k + 1];
+                    norm2 += v.x * v.x + v.y * v.y;
+                }
+            }
+            if (kt + 2 < nkt) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            barrier();
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) sq[i][r] += acc[i][r] * acc[i][r];
+    }
+    // rows of sq: the 16 lanes of a q group hold 16 columns of the same rows
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            for (int o = 8; o > 0; o >>= 1) sq[i][r] += __shfl_xor(sq[i][r], o, 64);
+    for (int o = 4; o > 0; o >>= 1) { mean2 += __shfl_xor(mean2, o, 64); norm2 += __shfl_xor(norm2, o, 64); }
+    if (c == 0)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave * TG_R + 16 * i + q + 4 * r] = sq[i][r];
+    barrier();
+    if (tid < TG_R && bm0 + tid < m) {
+        double q2 = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < TG_NW; wv++) q2 += red[wv * TG_R + tid];                   // wavefront order
+        part[(size_t)blockIdx.x * m + bm0 + tid] = q2;
+    }
+    if (blockIdx.x == 0 && (tid & 7) == 0) {                        // owner of the last column block: full k range seen
+        const int row = bm0 + (tid >> 3);
+        if (row < m) { mn[row] = mean2; mn[(size_t)m + row] = norm2; }
+    }
+}
+
+// ---- the many-row form, third shape: the rows stay, the columns stream.  A workgroup owns TRW_ROWS = 32 rows of P and
+// keeps ALL their columns in LDS (32 x 466 doubles = 117 KB; one contiguous DMA copy, P is read exactly once); each of its
+// sixteen wavefronts takes column tiles of Q = P C^-T (16 columns each) in pairs (j, ntile - 1 - j) -- k ranges 16 (j + 1)
+// and 16 (ntile - j): every pair costs the same, and the triangular structure of C^-1 is used at the granularity of ONE
+// column tile instead of a 128-column block (a quarter fewer matrix products than the paired-block forms) -- and streams
+// the C^-1 operand straight from L2 into registers, four steps ahead (16-byte pieces: lane (c, q) reads the column pair
+// 4 t + q of row 16 j + c and feeds two matrix steps, k order permuted like the A reads).  No tile is shared between
+// wavefronts, so the main loop has no barrier at all; the rows are complete inside the workgroup, so there is no
+// second launch: the sums of Q^2 meet in LDS in wavefront order, mean / variance (or standard deviation) are written,
+// and the last workgroup to finish (a counter) delivers the caller's status words behind the results.
+// The A operand needs no swizzle: rows are n = 2 x odd doubles apart (466: 233 pairs), so the sixteen rows a b128 read
+// touches fall into sixteen different 16-byte bank groups.  Needs n even, n <= TRW_NMAX, ldp == n (contiguous rows).
+constexpr int TRW_ROWS = 32, TRW_NW = 16, TRW_NMAX = 576, TRW_D = 4;
+__host__ __device__ constexpr size_t trw_lds_doubles(int n) { return (size_t)TRW_ROWS * n + 128 + TRW_NW * TRW_ROWS + (n + 8) + 2 * TRW_ROWS; }
+
+__global__ void __launch_bounds__(64 * TRW_NW) ws_tail_rows_kernel(int m, int n, const double *__restrict__ P,
+                                                                  const double *__restrict__ Ci, long long ldc,
+                                                                  const double *__restrict__ w, const double *__restrict__ diag,
+                                                                  double *__restrict__ out, double vsq, const int *status_src,
+                                                                  double *status_dst, int *done, int std_out) {
+    extern __shared__ __attribute__((aligned(16))) double trw_smem[];
+    double *sA = trw_smem;                                          // [32][n], then 128 doubles of slack (DMA tail, k tail)
+    double *red = sA + (size_t)TRW_ROWS * n + 128;                  // [NW][32]
+    double *sW = red + TRW_NW * TRW_ROWS;                           // [n + 8]
+    double *sMN = sW + n + 8;                                       // mean [32] | norm [32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int bm0 = blockIdx.x * TRW_ROWS;
+    const int rows = min(TRW_ROWS, m - bm0);
+    // ---- the row block: rows bm0 .. bm0 + 31 are one contiguous range of P
+    {
+        const long long valid = (long long)rows * n / 2;            // 16-byte pieces that exist
+        const int npiece = TRW_ROWS * n / 2 + 64;                    // + the slack pieces (zeros)
+        const double *base = P + (long long)bm0 * n;
+        for (int e0 = wave * 64; e0 < npiece; e0 += 64 * TRW_NW) {
+            const int e = e0 + lane;
+            const double *g = e < valid ? base + 2 * (long long)e : g_tail_zero;
+            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_t *)(sA + 2 * (size_t)e0), 16, 0, 0);
+        }
+    }
+    for (int k = tid; k < n + 8; k += 64 * TRW_NW) sW[k] = k < n ? w[k] : 0.0;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    // ---- P w and |p|^2: 32 lanes per row
+    {
+        const int row = tid >> 5, l32 = tid & 31;
+        double mean = 0.0, nrm = 0.0;
+        const double *ar = sA + (size_t)row * n;
+        for (int k = l32; k < n; k += 32) { const double v = ar[k]; mean += v * sW[k]; nrm += v * v; }
+        for (int o = 16; o > 0; o >>= 1) { mean += __shfl_xor(mean, o, 64); nrm += __shfl_xor(nrm, o, 64); }
+        if (l32 == 0) { sMN[row] = mean; sMN[TRW_ROWS + row] = nrm; }
+    }
+    // ---- column tiles
+    const int c = lane & 15, q = lane >> 4;
+    const int ntile = (n + 15) / 16, npair = (ntile + 1) / 2, ntmax = (n + 7) / 8;
+    double sq[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    const double *a0p = sA + (size_t)c * n + 2 * q, *a1p = sA + (size_t)(16 + c) * n + 2 * q;
+    for (int pr = wave; pr < npair; pr += TRW_NW) {
+        for (int half = 0; half < 2; half++) {
+            const int j = half == 0 ? pr : ntile - 1 - pr;
+            if (half == 1 && j == pr) break;                         // odd number of tiles: the middle one stands alone
+            const int col = 16 * j + c;
+            const int nts = min(2 * (j + 1), ntmax);                 // steps of 8 columns: k < 16 (j + 1)
+            const bool cok = col < n;
+            const double *bp = Ci + (long long)min(col, n - 1) * ldc + 2 * q;
+            auto loadb = [&](int t) -> d2v {
+                // columns beyond the row's end are zeros by predicate (the pair never straddles n: n is even)
+                return (cok && 8 * t + 2 * q < n) ? *(const d2v *)(bp + 8 * t) : d2v{0.0, 0.0};
+            };
+            d2v ring[TRW_D];
+#pragma unroll
+            for (int u = 0; u < TRW_D; u++) ring[u] = u < nts ? loadb(u) : d2v{0.0, 0.0};
+            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+            for (int t0 = 0; t0 < nts; t0 += TRW_D) {
+#pragma unroll
+                for (int u = 0; u < TRW_D; u++) {
+                    const int t = t0 + u;
+                    if (t < nts) {
+                        const d2v b = ring[u];
+                        if (t + TRW_D < nts) ring[u] = loadb(t + TRW_D);
+                        const d2v a0 = *(const d2v *)(a0p + 8 * t), a1 = *(const d2v *)(a1p + 8 * t);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.y, acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.y, acc1, 0, 0, 0);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { sq[0][r] += acc0[r] * acc0[r]; sq[1][r] += acc1[r] * acc1[r]; }
+        }
+    }
+    // rows of sq: the 16 lanes of a q group hold 16 columns of rows 16 i + q + 4 r
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            for (int o = 8; o > 0; o >>= 1) sq[i][r] += __shfl_xor(sq[i][r], o, 64);
+    if (c == 0)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave * TRW_ROWS + 16 * i + q + 4 * r] = sq[i][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (tid < rows) {
+        const int row = bm0 + tid;
+        double q2 = 0.0;
+#pragma unroll
+        for (int wv = 0; wv < TRW_NW; wv++) q2 += red[wv * TRW_ROWS + tid];              // wavefront order
+        const double v = fmax(diag[row] - vsq * (sMN[TRW_ROWS + tid] - q2), 0.0), sd = std_out ? sqrt(v) : v;
+        if (status_dst) {
+            // results a host may be polling for (page-locked memory): stores that go through to system scope
+            __hip_atomic_store(&out[row], sMN[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out[m + row], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else { out[row] = sMN[tid]; out[m + row] = sd; }
+    }
+    if (!status_dst) return;
+    // The last workgroup delivers the status words once every workgroup's results are out: a workgroup waits for the
+    // acknowledgement of its own write-through stores (vmcnt) and only then counts itself in -- no cache write-back, which
+    // is what a system-scope fence per workgroup would cost (194 of them doubled the kernel's time).
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(done, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (s_last && tid < 4) __hip_atomic_store(&status_dst[tid], (double)status_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (s_last && tid == 0) __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch on this stream
+}
+
 // second launch of the paired scheme: parts added in order, mean and variance written.  With status_dst the workgroup
 // that finishes last (counter) also delivers the caller's four status words (ints -> doubles behind the results) after
 // every workgroup has made its results visible system-wide: a host polling those words in page-locked memory may read
@@ -994,6 +1285,38 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
         return status_only();
     }
+    static const int tail_form = getenv("GPR_TAIL_FORM") ? atoi(getenv("GPR_TAIL_FORM")) : 0;   // 1: paired blocks (LDS DMA), 2: register-staged
+    if (ncb >= 2 && tail_form == 0 && n % 2 == 0 && n <= TRW_NMAX && ldp == n && ldc % 2 == 0 && ((uintptr_t)P & 15) == 0 &&
+        ((uintptr_t)Cinv & 15) == 0) {
+        // many rows, row-resident form: one launch, P read once, no barrier in the product loop
+        const size_t lds = trw_lds_doubles(n) * sizeof(double);
+        static bool attr3 = false;
+        if (!attr3) {
+            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)(trw_lds_doubles(TRW_NMAX) * sizeof(double))));
+            attr3 = true;
+        }
+        int *done = nullptr;
+        if (status_dst) {
+            // arrival counter of the status delivery: one per stream (launches of a stream are ordered; the last arriver
+            // leaves it at zero), never shared by two predictions in flight
+            static std::mutex mu;
+            static std::unordered_map<hipStream_t, int *> counters;
+            std::lock_guard<std::mutex> lk(mu);
+            int *&slot = counters[st];
+            if (!slot) {
+                GPR_HIP_TRY(hipMalloc((void **)&slot, sizeof(int)));
+                GPR_HIP_TRY(hipMemset(slot, 0, sizeof(int)));
+            }
+            done = slot;
+        }
+        const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
+        hipLaunchKernelGGL(ws_tail_rows_kernel, dim3((m + TRW_ROWS - 1) / TRW_ROWS), dim3(64 * TRW_NW), lds, st, m, n, P, Cinv, ldc, w,
+                           diag, out, vsq, status_src, status_dst, done, std_out);
+        gpr_prof_end(st, pid);
+        LAUNCH_CHECK("ws_tail_rows");
+        return GPR_OK;
+    }
     if (ncb >= 2) {
         // many rows: 64-row workgroups take column blocks x and ncb - 1 - x (equal work for every workgroup, half the
         // C^-1 bytes per flop of the 32-row form), their sums are combined by a second small launch
@@ -1002,8 +1325,13 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         static bool attr2 = false;
         if (!attr2) {
             GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R2, 2, NW2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg_lds_bytes()));
             attr2 = true;
         }
+        // tiles by LDS DMA where the shape allows 16-byte pieces (always, for the degree-2 feature rows: F is even)
+        static const bool no_glds = getenv("GPR_TAIL_NO_GLDS") != nullptr;
+        const bool glds = !no_glds && n <= 512 && n % 2 == 0 && ldp % 2 == 0 && ldc % 2 == 0 &&
+                          ((uintptr_t)P & 15) == 0 && ((uintptr_t)Cinv & 15) == 0;
         const int npart = (ncb + 1) / 2, nrb2 = (m + R2 - 1) / R2;
         void *wsp;
         int rc = gpr_dev_alloc(&wsp, (size_t)(npart + 2) * m * sizeof(double) + 16, st);
@@ -1012,8 +1340,13 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         // arrival counter of the combine launch: in this call's workspace, zeroed by the tail kernel
         int *done = (int *)(mn + 2 * (size_t)m);
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
-        hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, done, std_out);
+        static const int tail_dbg = getenv("GPR_TAIL_DBG") ? atoi(getenv("GPR_TAIL_DBG")) : 0;
+        if (glds)
+            hipLaunchKernelGGL(ws_tail_glds_kernel, dim3(npart, nrb2), dim3(64 * TG_NW), tg_lds_bytes(), st, m, n, P, ldp, Cinv, ldc, w,
+                               part, mn, done, tail_dbg);
+        else
+            hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
+                               out, vsq, part, mn, done, std_out);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
                            (const double *)mn, diag, out, vsq, status_src, status_dst, done, std_out);
         gpr_prof_end(st, pid2);
