@@ -17,10 +17,32 @@ E_TOL, F_TOL = 1e-6, 1e-5
 # The reference evaluates var = diag - k K^-1 k through an explicit N x N inverse (gaussianprocess.py:128-131, 903-907);
 # at these sizes its rounding noise on the VARIANCE is ~1e-7..1e-6 (cond(K + noise) * eps * diag) -- as large as the
 # energy variance itself: for image 37 of cfg3 the reference's energy variance came out negative and was clamped to 0.
-# The recorded standard deviations are therefore compared on the variance with that absolute bound; the stable
-# evaluation is pinned at the north-star tolerance by the small fixtures (test_gpu_gp_golden.check_std) and, here, by
-# the agreement of the weight-space and the dense route.
+# The fixtures therefore also hold, per test image, the prior variances `diag` the reference's kernel gave, three probe
+# rows of the reference's K_trans, and the STABLE variance diag - |L^-1 k|^2 evaluated from the reference's own L_,
+# K_trans and diag in np.longdouble (make_golden_cfg.stable_variance_longdouble): sigma is asserted against that at the
+# north-star tolerances (1e-6 eV, 1e-5 eV/A), and against the reference's recorded sigma on the variance within the
+# noise bound of its explicit inverse (the secondary check).
 VAR_NOISE = 1e-6
+S_E_TOL, S_F_TOL = 1e-6, 1e-5
+
+
+def check_sigma(z, k, gp, atoms, E_std, F_std):
+    """sigma of test image k against the stable form of the reference's own matrices; the inputs of that form (prior
+    variances, rows of K_trans) against this build's kernel on the same structure"""
+    n = len(atoms)
+    fixed = set(int(i) for i in z[f"test{k}_fixed"])
+    free = [i for i in range(n) if i not in fixed]
+    ref = np.sqrt(np.clip(z[f"test{k}_var_stable"], 0.0, None))
+    got = np.concatenate(([E_std], np.asarray(F_std)[free].reshape(-1)))
+    assert got.shape == ref.shape
+    assert abs(got[0] - ref[0]) < S_E_TOL, (k, got[0], ref[0])
+    assert np.abs(got[1:] - ref[1:]).max() < S_F_TOL, (k, np.abs(got[1:] - ref[1:]).max())
+    data, _ = gp._structure_data(atoms, gp.descriptor.calculate(atoms))
+    diag = gp.kernel.diag(data)
+    assert np.abs(diag - z[f"test{k}_diag"]).max() < 1e-12 * np.abs(z[f"test{k}_diag"]).max()
+    rows = z[f"test{k}_K_trans_rows"]
+    Kt = gp.kernel.k_total(data, gp.train_x, 1e-12) if gp.kernel.name == "RBF" else gp.kernel.k_total(data, gp.train_x)
+    assert np.abs(Kt[rows] - z[f"test{k}_K_trans_probe"]).max() < 1e-12 * np.abs(z[f"test{k}_K_trans_probe"]).max()
 
 
 def build(kind, n_train):
@@ -69,6 +91,7 @@ def test_cfg3_dot_native_batch_matches_the_reference_at_full_size():
         assert abs(Es_std[k] ** 2 - float(z[f"test{k}_E_std"]) ** 2) < VAR_NOISE, (k, Es_std[k], float(z[f"test{k}_E_std"]))
         assert np.abs(Fs_std[k] ** 2 - z[f"test{k}_F_std"] ** 2).max() < VAR_NOISE
         assert np.all(Fs[k][z[f"test{k}_fixed"]] == 0)
+        check_sigma(z, k, gp, strucs[k], Es_std[k], Fs_std[k])
     # one by one through predict_structure: the same numbers
     E1, F1, _, s1, fs1 = gp.predict_structure(strucs[2], stress=False, return_std=True)
     assert abs(E1 - Es[2]) < 1e-9 and np.abs(F1 - Fs[2]).max() < 1e-9 and abs(s1 - Es_std[2]) < 1e-9
@@ -88,6 +111,7 @@ def test_cfg3_dot_native_batch_matches_the_reference_at_full_size():
     Ed, Fd, Ed_std, Fd_std = gp.predict_structures(strucs[:1], return_std=True)
     assert abs(Ed[0] - float(z["test0_E"])) < E_TOL and np.abs(Fd[0] - z["test0_F"]).max() < F_TOL
     assert abs(Ed_std[0] - Es_std[0]) < E_TOL and np.abs(Fd_std[0] - Fs_std[0]).max() < F_TOL
+    check_sigma(z, 0, gp, strucs[0], Ed_std[0], Fd_std[0])          # the dense route's triangular form as well
 
 
 def test_cfg2_rbf_fit_predict_lml_match_the_reference_at_its_own_size():
@@ -102,6 +126,8 @@ def test_cfg2_rbf_fit_predict_lml_match_the_reference_at_its_own_size():
         assert abs(E - float(z[f"test{k}_E"])) < E_TOL and np.abs(F - z[f"test{k}_F"]).max() < F_TOL
         assert abs(E_std ** 2 - float(z[f"test{k}_E_std"]) ** 2) < VAR_NOISE
         assert np.abs(F_std ** 2 - z[f"test{k}_F_std"] ** 2).max() < VAR_NOISE
+        if f"test{k}_var_stable" in z.files:
+            check_sigma(z, k, gp, a, E_std, F_std)
     for k in range(2):
         if f"lml{k}" not in z.files:
             continue
