@@ -6,7 +6,10 @@
 // gpr_so3_power_spectrum and the force-point gather of gpr_set_create_gather without a host round
 // trip).  No floating-point model arithmetic happens here beyond the distance predicate.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
+#include <cstdint>
+#include <cstdlib>
 #include <thread>
 #include "gpr_internal.h"
 
@@ -34,6 +37,7 @@ struct gpr_nbr {
     bool capped = false;                        // P, S are capacities; the true sizes live in d_err[1..3] only
     bool seq_in_vec = false;                    // d_seq shares d_vec's allocation (capped build)
     const int *d_extra = nullptr;               // caller's extra ints uploaded with the geometry (or NULL)
+    bool fused_rows = false;                    // the one-launch build has written the force-point regrouping already
 };
 
 static void cross3(const double *a, const double *b, double *c) {
@@ -389,6 +393,241 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 
 }  // namespace
 
+// ================================================================ the whole build in ONE launch
+// One workgroup (16 wavefronts) per STRUCTURE does what upload + count + scan + fill + force-row regrouping did in five
+// launches (each boundary of that dependent chain cost ~6 us of drain and dispatch on a 36 us path):
+//   geometry of the structure from the page-locked blob into LDS (and on to the device copy later kernels read),
+//   count per centre (one wavefront per centre, the loops of nbr_centre_kernel), exclusive scan inside the workgroup,
+//   the structure's offsets among all structures by LOOKING BACK: every workgroup publishes its totals (tagged with the
+//   call's epoch, so that nobody has to clear the slots) right after its count, and sums the totals of its predecessors
+//   and of everybody else (the grand totals decide, identically everywhere, whether the guessed capacities hold); all
+//   workgroups reach that point at about the same time, the wait is bounded, and giving up fails loudly,
+//   fill (pairs ordered by (j, image), rows by j: bit-identical to the other builders), and -- the neighbour relation
+//   being exactly symmetric -- the force-point regrouping by table look-up: row k of force point a is the seq row
+//   (i, a) of a's k-th neighbour i, whose position among i's rows centre i noted in an n x n table in LDS while counting.
+// Capacity overflow: every workgroup sees the same grand totals; if they exceed the guess nobody fills anything, every
+// offset is zero and the last structure raises the flag (the caller repeats the build with exact sizes).
+struct nbrf_args {
+    const char *blob_host;           // device alias of the page-locked blob [wpos | shifts | sinfo | numbers | sid | atom0]
+    char *blob_dev;                  // its device copy
+    long long off_shift, off_sinfo, off_num, off_sid, off_a0, bytes;
+    int nstruct, natoms, weight_on, cap_pairs, cap_rows, nmax, nimg_max, dbg;
+    unsigned epoch;
+    double rc2;
+    int *cr0, *cp0, *info;           // [natoms + 1] each; info = [missing, overflow, pairs, rows]
+    unsigned long long *agg;         // [nstruct][3]: rows | pairs | missing, each tagged (epoch << 32) | value
+    double *vec, *w;
+    int *rp0, *self_row, *seq;
+    int *row_index, *x_index;        // force-point regrouping (may be NULL)
+    nbr_sinfo si[96];
+};
+constexpr int NBRF_WAVES = 16, NBRF_MAX_N = 128, NBRF_MAX_STRUCT = 96, NBRF_POLLS = 1 << 22;
+
+__device__ __forceinline__ bool nbrf_wait(const unsigned long long *p, unsigned epoch, unsigned &value) {
+    for (int polls = 0; polls < NBRF_POLLS; polls++) {
+        const unsigned long long v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(v >> 32) == epoch) { value = (unsigned)v; return true; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    value = 0;
+    return false;
+}
+
+__global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a) {
+    extern __shared__ __attribute__((aligned(16))) double nf_smem[];
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const nbr_sinfo si = a.si[s];
+    const int n = si.n, nimg = si.nimg;
+    double *pos = nf_smem;                                   // [3 nmax]
+    double *sh = pos + 3 * a.nmax;                           // [3 nimg_max]
+    int *num = (int *)(sh + 3 * a.nimg_max);                 // [nmax]
+    int *cntR = num + a.nmax, *cntP = cntR + a.nmax, *offR = cntP + a.nmax, *offP = offR + a.nmax;
+    int *misc = offP + a.nmax;                               // [8]: TR, TP, baseR, baseP, ok, missing
+    unsigned short *li = (unsigned short *)(misc + 8);       // [n][n] local row of neighbour j among centre i's rows, 0xffff: none
+    unsigned char *fnd = (unsigned char *)(li + a.nmax * a.nmax);   // [n][n] images of j within the cutoff of i
+    // ---- geometry: host blob -> LDS (+ device copy)
+    {
+        const double *hw = (const double *)a.blob_host + 3 * (size_t)si.atom0, *hs = (const double *)(a.blob_host + a.off_shift) + 3 * (size_t)si.img0;
+        const int *hn = (const int *)(a.blob_host + a.off_num) + si.atom0;
+        double *dw = (double *)a.blob_dev + 3 * (size_t)si.atom0;
+        int *dn = (int *)(a.blob_dev + a.off_num) + si.atom0, *dsid = (int *)(a.blob_dev + a.off_sid) + si.atom0;
+        for (int e = tid; e < 3 * n; e += blockDim.x) { const double v = hw[e]; pos[e] = v; dw[e] = v; }
+        for (int e = tid; e < 3 * nimg; e += blockDim.x) sh[e] = hs[e];
+        for (int e = tid; e < n; e += blockDim.x) { const int z = hn[e]; num[e] = z; dn[e] = z; dsid[e] = s; }
+        for (int e = tid; e < n * n; e += blockDim.x) li[e] = 0xffff;
+        if (s == 0) {            // what is shared by all structures: shift table, structure table, atom offsets
+            const long long lo = a.off_shift, hi = a.off_num;
+            for (long long e = lo + 8LL * tid; e < hi; e += 8LL * blockDim.x) *(double *)(a.blob_dev + e) = *(const double *)(a.blob_host + e);
+            for (long long e = a.off_a0 + 4LL * tid; e < a.bytes; e += 4LL * blockDim.x) *(int *)(a.blob_dev + e) = *(const int *)(a.blob_host + e);
+        }
+        if (tid < 8) misc[tid] = 0;
+    }
+    __syncthreads();
+    if (a.dbg == 1) return;
+    // ---- count: one wavefront per centre
+    for (int il = wave; il < n; il += NBRF_WAVES) {
+        const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
+        int pair_run = 0, row_run = 0;
+        for (int jb = 0; jb < n; jb += 64) {
+            const int j = jb + lane;
+            const bool live = j < n;
+            int found = 0;
+            if (live) {
+                const double dx0 = pos[3 * j] - pix, dy0 = pos[3 * j + 1] - piy, dz0 = pos[3 * j + 2] - piz;
+                for (int im = 0; im < nimg; im++) {
+                    if (j == il && im == si.zero_img) continue;
+                    const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                    // no fused multiply-add: the predicate has to agree with the host builder to the bit
+                    const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                    if (r2 < a.rc2) found++;
+                }
+                fnd[il * n + j] = (unsigned char)(found > 0);
+            }
+            const int isrow = (live && (found > 0 || j == il)) ? 1 : 0;
+            const int pincl = wave_incl_scan(found, lane), rincl = wave_incl_scan(isrow, lane);
+            if (isrow) li[il * n + j] = (unsigned short)(row_run + rincl - isrow);
+            pair_run += __shfl(pincl, 63);
+            row_run += __shfl(rincl, 63);
+        }
+        if (lane == 0) { cntP[il] = pair_run; cntR[il] = row_run; }
+    }
+    __syncthreads();
+    if (a.dbg == 2) return;
+    // ---- offsets inside the structure, totals out, predecessors' totals in
+    if (wave == 0) {
+        int runR = 0, runP = 0;
+        for (int b = 0; b < n; b += 64) {
+            const int i = b + lane;
+            const int vr = i < n ? cntR[i] : 0, vp = i < n ? cntP[i] : 0;
+            const int ir = wave_incl_scan(vr, lane), ip = wave_incl_scan(vp, lane);
+            if (i < n) { offR[i] = runR + ir - vr; offP[i] = runP + ip - vp; }
+            runR += __shfl(ir, 63); runP += __shfl(ip, 63);
+        }
+        const unsigned long long tag = (unsigned long long)a.epoch << 32;
+        if (lane == 0) {
+            __hip_atomic_store(&a.agg[3 * s], tag | (unsigned)runR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&a.agg[3 * s + 1], tag | (unsigned)runP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // totals of EVERY structure: those before this one give its offsets, all of them together decide -- the same way
+        // in every workgroup -- whether the guessed capacities hold.  (Workgroups of one launch that are not resident yet
+        // are dispatched as soon as a CU has room, whatever the resident ones do: the wait ends.)
+        int baseR = 0, baseP = 0, allR = 0, allP = 0, ok = 1;
+        for (int b = 0; b < a.nstruct; b += 64) {
+            const int q = b + lane;
+            unsigned vr = 0, vp = 0;
+            if (q < a.nstruct) { if (!nbrf_wait(&a.agg[3 * q], a.epoch, vr)) ok = 0; if (!nbrf_wait(&a.agg[3 * q + 1], a.epoch, vp)) ok = 0; }
+            allR += (int)vr; allP += (int)vp;
+            if (q < s) { baseR += (int)vr; baseP += (int)vp; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            baseR += __shfl_xor(baseR, o); baseP += __shfl_xor(baseP, o); allR += __shfl_xor(allR, o); allP += __shfl_xor(allP, o);
+            ok &= __shfl_xor(ok, o);
+        }
+        if (lane == 0) { misc[0] = runR; misc[1] = runP; misc[2] = baseR; misc[3] = baseP; misc[4] = ok; misc[6] = allR; misc[7] = allP; }
+    }
+    __syncthreads();
+    if (a.dbg == 3) return;
+    const int TR = misc[0], TP = misc[1], baseR = misc[2], baseP = misc[3];
+    // too small a guess (or a wait that gave up): every offset of every structure is zero -- each centre then has no
+    // pairs and no rows, and whatever is queued behind this kernel runs over empty ranges -- and the flag goes up
+    const bool over = !misc[4] || misc[6] > a.cap_rows || misc[7] > a.cap_pairs;
+    {
+        for (int i = tid; i < n; i += blockDim.x) {
+            a.cr0[si.atom0 + i] = over ? 0 : baseR + offR[i];
+            a.cp0[si.atom0 + i] = over ? 0 : baseP + offP[i];
+        }
+        if (s == a.nstruct - 1 && tid == 0) {
+            a.cr0[a.natoms] = over ? 0 : baseR + TR;
+            a.cp0[a.natoms] = over ? 0 : baseP + TP;
+            a.info[1] = over ? 1 : 0; a.info[2] = misc[7]; a.info[3] = misc[6];
+        }
+        if (!over && tid == 0) a.rp0[baseR + TR] = baseP + TP;
+    }
+    int missing = 0;
+    if (!over) {
+        // ---- fill: pairs ordered by (j, image), rows by j
+        for (int il = wave; il < n; il += NBRF_WAVES) {
+            const int i = si.atom0 + il, zi = num[il];
+            const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
+            int pair_run = baseP + offP[il];
+            const int row0 = baseR + offR[il];
+            for (int jb = 0; jb < n; jb += 64) {
+                const int j = jb + lane;
+                const bool live = j < n;
+                // the images are counted again (the table keeps one bit per pair of atoms): same arithmetic, same answer
+                int found = 0;
+                double dx0 = 0.0, dy0 = 0.0, dz0 = 0.0;
+                if (live && fnd[il * n + j]) {
+                    dx0 = pos[3 * j] - pix; dy0 = pos[3 * j + 1] - piy; dz0 = pos[3 * j + 2] - piz;
+                    for (int im = 0; im < nimg; im++) {
+                        if (j == il && im == si.zero_img) continue;
+                        const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                        const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                        if (r2 < a.rc2) found++;
+                    }
+                }
+                const int pincl = wave_incl_scan(found, lane);
+                const unsigned short lr = live ? li[il * n + j] : (unsigned short)0xffff;
+                if (lr != 0xffff) {
+                    const int row = row0 + lr;
+                    int p = pair_run + pincl - found;
+                    a.seq[2 * (size_t)row] = il; a.seq[2 * (size_t)row + 1] = j;
+                    a.rp0[row] = p;
+                    if (j == il) a.self_row[i] = row;
+                    if (found) {
+                        const int zj = num[j];
+                        const double wgt = (a.weight_on && zj != zi) ? -(double)zj : (double)zj;     // SO3.py:381-385
+                        for (int im = 0; im < nimg; im++) {
+                            if (j == il && im == si.zero_img) continue;
+                            const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                            const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                            if (r2 < a.rc2) {
+                                a.vec[3 * (size_t)p] = dx; a.vec[3 * (size_t)p + 1] = dy; a.vec[3 * (size_t)p + 2] = dz;
+                                a.w[p] = wgt;
+                                p++;
+                            }
+                        }
+                    }
+                }
+                pair_run += __shfl(pincl, 63);
+            }
+        }
+        if (a.dbg == 4) return;
+        // ---- force points: row k of point a (atom a) is the seq row (i, a) of a's k-th neighbour i
+        if (a.row_index) {
+            for (int e = tid; e < n * n; e += blockDim.x) {
+                const int al = e / n, il = e - al * n;
+                const unsigned short k = li[al * n + il];
+                if (k == 0xffff) continue;
+                const unsigned short back = li[il * n + al];
+                const int q = baseR + offR[al] + k;
+                a.row_index[q] = back == 0xffff ? -1 : baseR + offR[il] + back;
+                a.x_index[q] = si.atom0 + il;
+                if (back == 0xffff) missing++;
+            }
+        }
+    }
+    // ---- rows the symmetry check could not find (zero unless something is broken), summed by the last structure
+    for (int o = 32; o > 0; o >>= 1) missing += __shfl_xor(missing, o);
+    if (lane == 0 && missing) atomicAdd(&misc[5], missing);
+    __syncthreads();
+    if (tid == 0 && !misc[4]) misc[5] = 0x3fffffff;          // gave up waiting for a predecessor: fail loudly (the host reports the count)
+    __syncthreads();
+    if (tid == 0)
+        __hip_atomic_store(&a.agg[3 * s + 2], ((unsigned long long)a.epoch << 32) | (unsigned)misc[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s == a.nstruct - 1 && wave == 0) {
+        int tot = 0, ok = 1;
+        for (int b = 0; b < a.nstruct; b += 64) {
+            const int q = b + lane;
+            unsigned v = 0;
+            if (q < a.nstruct && !nbrf_wait(&a.agg[3 * q + 2], a.epoch, v)) ok = 0;
+            tot += (int)v;
+        }
+        for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o); ok &= __shfl_xor(ok, o); }
+        if (lane == 0) { a.info[0] = tot; if (!ok) a.info[1] = 1; }
+    }
+}
+
 namespace {
 struct stage_buf { void *p = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t ev = nullptr; bool pending = false; };   // dev: device alias of p
 // as many as a prediction session may have in flight (predict.hip: SESSION_SLOTS): a buffer is re-used only after the
@@ -398,9 +637,12 @@ thread_local stage_buf g_stage[NSTAGE];
 thread_local int g_stage_next = 0;
 }
 
+static std::atomic<unsigned> g_nbr_epoch{1};
+
 static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                  const double *cells, const int *pbc, const int *numbers, double rcut,
-                                 int weight_on, int cap_pairs, int cap_rows, int n_extra = 0, const int *extra = nullptr) {
+                                 int weight_on, int cap_pairs, int cap_rows, int n_extra = 0, const int *extra = nullptr,
+                                 int *row_index_dev = nullptr, int *x_index_dev = nullptr) {
     GPR_REQUIRE(out && atom0 && (nstruct == 0 || (positions && cells && pbc && numbers)), "gpr_nbr_build_device: null pointer");
     GPR_REQUIRE(rcut > 0.0, "gpr_nbr_build_device: rcut must be positive");
     hipStream_t st = (hipStream_t)stream;
@@ -459,13 +701,59 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     int rc;
     void *p;
     // one allocation for [geometry blob | offsets and counters | self rows]
-    const size_t sz_in = (b_total + 16 + 255) / 256 * 256, sz_off = ((size_t)(4 * natoms + 8) * sizeof(int) + 255) / 256 * 256;
+    const size_t sz_in = (b_total + 16 + 255) / 256 * 256,
+                 sz_off = ((size_t)(4 * natoms + 8) * sizeof(int) + (size_t)3 * (nstruct + 1) * sizeof(unsigned long long) + 16 + 255) / 256 * 256;
     if ((rc = gpr_dev_alloc(&p, sz_in + sz_off + (size_t)std::max(natoms, 1) * sizeof(int), st))) return fail(rc);
     nb->d_in = (char *)p;
     nb->d_off = (int *)(nb->d_in + sz_in);      // [cr0 | cp0 | cnt_rows | cnt_pairs | err | overflow, pairs, rows]
     nb->d_self = (int *)(nb->d_in + sz_in + sz_off);
     int *cnt_rows = nb->d_off + 2 * natoms + 2, *cnt_pairs = cnt_rows + natoms;
     nb->d_err = cnt_pairs + natoms;
+    // ---- everything in one launch (nbr_fused_kernel) when the sizes are guessed, every atom moves and the structures
+    // are of ordinary size; otherwise the launches below
+    int nmax_atoms = 0, nimg_max = 1;
+    for (int s = 0; s < nstruct; s++) { nmax_atoms = std::max(nmax_atoms, sinfo[s].n); nimg_max = std::max(nimg_max, sinfo[s].nimg); }
+    static const bool no_fused = getenv("GPR_NBR_NO_FUSED") != nullptr;
+    if (!no_fused && cap_pairs > 0 && cap_rows > 0 && natoms > 0 && n_extra == 0 && nstruct <= NBRF_MAX_STRUCT && nmax_atoms <= NBRF_MAX_N &&
+        nimg_max <= 512) {
+        if (!sb.dev && hipHostGetDevicePointer(&sb.dev, sb.p, 0) != hipSuccess) { gpr_set_error("gpr_nbr_build_device: no device alias of the staging buffer"); return fail(GPR_ERR_HIP); }
+        nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;
+        if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double) + ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
+        nb->d_vec = (double *)p; nb->d_w = nb->d_vec + 3 * (size_t)cap_pairs;
+        nb->d_seq = (int *)(nb->d_vec + 4 * (size_t)cap_pairs); nb->d_rp0 = nb->d_seq + 2 * (size_t)cap_rows;
+        nb->seq_in_vec = true;
+        nb->d_wpos = (const double *)nb->d_in;
+        nb->d_shift = (const double *)(nb->d_in + b_wpos);
+        nb->d_sinfo = (const nbr_sinfo *)(nb->d_in + b_wpos + b_shift);
+        nb->d_numbers = (const int *)(nb->d_in + b_wpos + b_shift + b_sinfo);
+        nb->d_sid = nb->d_numbers + natoms;
+        nb->d_atom0 = nb->d_sid + natoms;
+        nbrf_args fa{};
+        fa.blob_host = (const char *)sb.dev; fa.blob_dev = nb->d_in;
+        fa.off_shift = (long long)b_wpos; fa.off_sinfo = (long long)(b_wpos + b_shift); fa.off_num = (long long)(b_wpos + b_shift + b_sinfo);
+        fa.off_sid = fa.off_num + (long long)b_num; fa.off_a0 = fa.off_sid + (long long)b_num; fa.bytes = (long long)b_total;
+        fa.nstruct = nstruct; fa.natoms = natoms; fa.weight_on = weight_on; fa.cap_pairs = cap_pairs; fa.cap_rows = cap_rows;
+        fa.nmax = nmax_atoms; fa.nimg_max = nimg_max; fa.rc2 = rcut * rcut;
+        static const int nbr_dbg = getenv("GPR_NBR_DBG") ? atoi(getenv("GPR_NBR_DBG")) : 0;
+        fa.dbg = nbr_dbg;
+        unsigned ep = g_nbr_epoch.fetch_add(1);
+        if (ep == 0) ep = g_nbr_epoch.fetch_add(1);
+        fa.epoch = ep;
+        fa.cr0 = nb->d_off; fa.cp0 = nb->d_off + natoms + 1; fa.info = nb->d_err;
+        fa.agg = (unsigned long long *)(((uintptr_t)(nb->d_err + 4) + 7) & ~(uintptr_t)7);
+        fa.vec = nb->d_vec; fa.w = nb->d_w; fa.rp0 = nb->d_rp0; fa.self_row = nb->d_self; fa.seq = nb->d_seq;
+        fa.row_index = row_index_dev; fa.x_index = row_index_dev ? x_index_dev : nullptr;
+        for (int s = 0; s < nstruct; s++) fa.si[s] = sinfo[s];
+        const size_t lds = (size_t)(3 * nmax_atoms + 3 * nimg_max) * sizeof(double) + (size_t)(5 * nmax_atoms + 8) * sizeof(int) +
+                           (size_t)nmax_atoms * nmax_atoms * 3 + 16;
+        hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
+        if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fused launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
+        nb->fused_rows = row_index_dev != nullptr;
+        *out = nb;
+        return GPR_OK;
+    }
     {
         void *src_dev = nullptr;
         hipError_t e = hipSuccess;
@@ -578,6 +866,18 @@ extern "C" int gpr_nbr_build_device_extra(gpr_nbr **out, void *stream, int nstru
     GPR_REQUIRE((cap_pairs > 0) == (cap_rows > 0), "gpr_nbr_build_device_extra: capacities go together");
     return nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows,
                                  n_extra, extra_host);
+}
+// capped build of a batch in which every atom moves, with the force-point regrouping of gpr_nbr_force_rows(nb, natoms,
+// NULL, NULL, cap_rows, row_index, x_index) written by the same launch where the one-launch builder applies;
+// *rows_done tells whether it did (0: call gpr_nbr_force_rows as before)
+extern "C" int gpr_nbr_build_device_rows(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                                         const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
+                                         int cap_pairs, int cap_rows, int *row_index_dev, int *x_index_dev, int *rows_done) {
+    GPR_REQUIRE(cap_pairs > 0 && cap_rows > 0 && row_index_dev && x_index_dev && rows_done, "gpr_nbr_build_device_rows: bad arguments");
+    const int rc = nbr_build_device_impl(out, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows,
+                                         0, nullptr, row_index_dev, x_index_dev);
+    *rows_done = (rc == GPR_OK && *out && (*out)->fused_rows) ? 1 : 0;
+    return rc;
 }
 extern "C" const int *gpr_nbr_extra_ptr(const gpr_nbr *nb) { return (nb && nb->on_device) ? nb->d_extra : nullptr; }
 

@@ -48,32 +48,50 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         for (int a = 0; a < natoms; a++)
             if (free_mask[a]) fatoms.push_back(a);
     }
-    int rc = gpr_nbr_build_device_extra(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
-                                        capped ? cap_pairs : 0, capped ? cap_rows : 0, (int)fatoms.size(), fatoms.data());
-    if (rc) return rc;
     std::vector<void *> temps;
     auto cleanup = [&](int code) {
         for (void *p : temps) gpr_dev_free(p, st);
-        gpr_nbr_destroy(nb);
+        if (nb) gpr_nbr_destroy(nb);
         return code;
     };
     auto dalloc = [&](size_t bytes, void **p) { int r = gpr_dev_alloc(p, bytes, st); if (!r) temps.push_back(*p); return r; };
+    // one arena for everything this call needs besides the neighbour table: [psi | diag | x | dxdr | row indices | moving
+    // atoms and their row offsets] -- a single stream-ordered allocation, so the launches below go out back to back
+    auto up = [](size_t bytes) { return (bytes + 255) / 256 * 256; };
+    char *arena = nullptr;
+    size_t sz_psi = 0, sz_diag = 0, sz_x = 0, sz_dxdr = 0, sz_idx = 0;
+    int frows = 0;
+    auto make_arena = [&](int S) {
+        frows = S;                              // bound on the force rows (the regrouping stops at the true total)
+        sz_psi = up((size_t)m * F * sizeof(double)); sz_diag = up(want_std ? (size_t)m * sizeof(double) : 0);
+        sz_x = up((size_t)std::max(natoms, 1) * d * sizeof(double)); sz_dxdr = up((size_t)std::max(S, 1) * d * 3 * sizeof(double));
+        sz_idx = up((size_t)std::max(frows, 1) * 2 * sizeof(int));
+        const size_t sz_meta = up(free_mask ? ((size_t)nfree + 2) * sizeof(int) : 0);
+        void *p = nullptr;
+        const int r = dalloc(sz_psi + sz_diag + sz_x + sz_dxdr + sz_idx + sz_meta, &p);
+        arena = (char *)p;
+        return r;
+    };
+    int rc, rows_done = 0;
+    if (capped && !free_mask) {
+        // sizes guessed and every atom moving: the arena first, then the whole neighbour search -- regrouping of the force
+        // points included -- as ONE launch (gpr_nbr_build_device_rows)
+        if ((rc = make_arena(cap_rows))) return cleanup(rc);
+        int *ri = (int *)(arena + sz_psi + sz_diag + sz_x + sz_dxdr);
+        rc = gpr_nbr_build_device_rows(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on, cap_pairs, cap_rows,
+                                       ri, ri + std::max(frows, 1), &rows_done);
+    } else {
+        rc = gpr_nbr_build_device_extra(&nb, stream, nstruct, atom0, positions, cells, pbc, numbers, rcut, weight_on,
+                                        capped ? cap_pairs : 0, capped ? cap_rows : 0, (int)fatoms.size(), fatoms.data());
+    }
+    if (rc) return cleanup(rc);
 
     int P = 0, S = 0;
     gpr_nbr_sizes(nb, &P, &S);
     const double *d_vec, *d_w; const int *d_cp0, *d_cr0, *d_rp0, *d_self, *d_seq, *d_num, *d_atom0;
     if ((rc = gpr_nbr_device_arrays(nb, &d_vec, &d_w, &d_cp0, &d_cr0, &d_rp0, &d_self, &d_seq, &d_num, &d_atom0))) return cleanup(rc);
-
-    // one arena for everything this call needs besides the neighbour table: [psi | diag | x | dxdr | row indices | moving
-    // atoms and their row offsets] -- a single stream-ordered allocation, so the launches below go out back to back
+    if (!arena && (rc = make_arena(S))) return cleanup(rc);
     void *p;
-    const int frows = S;                        // bound on the force rows (the regrouping kernel stops at the true total)
-    auto up = [](size_t bytes) { return (bytes + 255) / 256 * 256; };
-    const size_t sz_psi = up((size_t)m * F * sizeof(double)), sz_diag = up(want_std ? (size_t)m * sizeof(double) : 0),
-                 sz_x = up((size_t)std::max(natoms, 1) * d * sizeof(double)), sz_dxdr = up((size_t)std::max(S, 1) * d * 3 * sizeof(double)),
-                 sz_idx = up((size_t)std::max(frows, 1) * 2 * sizeof(int)), sz_meta = up(free_mask ? ((size_t)nfree + 2) * sizeof(int) : 0);
-    if ((rc = dalloc(sz_psi + sz_diag + sz_x + sz_dxdr + sz_idx + sz_meta, &p))) return cleanup(rc);
-    char *arena = (char *)p;
     double *d_psi = (double *)arena, *d_diag = want_std ? (double *)(arena + sz_psi) : nullptr, *d_q = nullptr;
     double *d_x = (double *)(arena + sz_psi + sz_diag), *d_dxdr = (double *)(arena + sz_psi + sz_diag + sz_x);
     int *d_rowidx = (int *)(arena + sz_psi + sz_diag + sz_x + sz_dxdr), *d_xidx = d_rowidx + std::max(frows, 1);
@@ -87,7 +105,7 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
         if ((rc = gpr_nbr_point_rows(nb, nfree, d_fatoms, d_meta))) return cleanup(rc);
         d_frow0 = d_meta;
     }
-    if ((rc = gpr_nbr_force_rows(nb, nfree, d_fatoms, d_frow0, frows, d_rowidx, d_xidx))) return cleanup(rc);
+    if (!rows_done && (rc = gpr_nbr_force_rows(nb, nfree, d_fatoms, d_frow0, frows, d_rowidx, d_xidx))) return cleanup(rc);
 
     // descriptor
     if ((rc = gpr_so3_power_spectrum(stream, nmax, lmax, rcut, alpha, nseg, ncheb, so3_table, natoms, P, S, d_vec, d_w,

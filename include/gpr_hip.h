@@ -291,6 +291,14 @@ int gpr_nbr_build_device_extra(gpr_nbr **out, void *stream, int nstruct, const i
                                const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
                                int cap_pairs, int cap_rows, int n_extra, const int *extra_host);
 const int *gpr_nbr_extra_ptr(const gpr_nbr *nb);
+/* Capped build of a batch in which every atom moves AND the force-point regrouping (what gpr_nbr_force_rows(nb, natoms,
+ * NULL, NULL, cap_rows, row_index, x_index) writes) in one call: where the one-launch builder applies (<= 96 structures of
+ * <= 128 atoms) the whole neighbour search of a batch is ONE kernel launch -- geometry upload, count, offsets across the
+ * structures by look-back, fill and regrouping -- instead of five; *rows_done = 0 means the regrouping still has to be
+ * asked for with gpr_nbr_force_rows. */
+int gpr_nbr_build_device_rows(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
+                              const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
+                              int cap_pairs, int cap_rows, int *row_index_dev, int *x_index_dev, int *rows_done);
 /* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
 int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
 /* the four device ints gpr_nbr_info_to converts (for kernels that deliver them themselves, gpr_ws_tail_status) */

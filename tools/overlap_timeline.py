@@ -7,7 +7,7 @@ ev = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"].repl
 ev.sort()
 t_end = max(e for _, e, _ in ev)
 # the timed loop is the densest part: take the window_ms before the 60 % mark of the tail launches
-tails = [s for s, e, n in ev if "ws_tail_kernel" in n]
+tails = [s for s, e, n in ev if n.startswith("ws_tail") and "combine" not in n]
 win = float(sys.argv[2]) * 1e6 if len(sys.argv) > 2 else 10e6
 mid = tails[int(len(tails) * 0.5)]
 lo, hi = mid - win / 2, mid + win / 2
@@ -25,7 +25,7 @@ print(f"window {win * 1e-6:.1f} ms, {len(sel)} launches, {sum(1 for s, e, n in s
 for k in sorted(occ): print(f"  {k}{'+' if k == 4 else ' '} kernels running: {100.0 * occ[k] / tot:5.1f} %")
 by = collections.defaultdict(list)
 for s, e, n in sel: by[n].append((e - s) * 1e-3)
-nst = max(1, sum(1 for s, e, n in sel if "ws_tail_kernel" in n))
+nst = max(1, sum(1 for s, e, n in sel if n.startswith("ws_tail") and "combine" not in n))
 print(f"  step period {win * 1e-3 / nst:.1f} us")
 for n, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
     print(f"  {n[:48]:48s} n/step {len(v) / nst:4.1f}  avg {sum(v) / len(v):7.1f} us  busy/step {sum(v) / nst:7.1f} us")
