@@ -544,7 +544,8 @@ struct lookahead_ctx {
         if (failed) return GPR_ERR_HIP;
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);              // lo = least urgent: the bulk updates must not crowd out the chain
-        bool ok = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) == hipSuccess;
+        bool ok = false;
+        if (!ok) ok = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) == hipSuccess;
         if (!ok) side = nullptr;
         if (ok && hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; ok = false; }
         if (ok && hipMalloc((void **)&flag, 8 * sizeof(int)) != hipSuccess) { flag = nullptr; ok = false; }
@@ -662,6 +663,11 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         GPR_HIP_TRY(wait(g_la.mid, e0)); GPR_HIP_TRY(wait(g_la.side, e0));
     }
     int step = 0;
+    bool deferred = false;                                   // panel K - 1 has not been applied beyond column block K + 1 yet
+    // pairing pays where the bulk dominates (N = 24 250: 148 -> 127 ms); at N = 6063 the chain of diagonal blocks does, and
+    // a bulk launch twice as long beside it only lengthens the steps it overlaps (4.2 -> 4.4 ms): pairs from 8192 rows on
+    static const bool pair_env = !getenv("GPR_POTRF_NO_PAIR");
+    const bool pair_bulk = pair_env && n >= 8192;
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB, step++) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
         double *wop = (double *)scratch + (size_t)(step % 3) * ops_doubles, *lop = wop + 16 * TILE_DOUBLES;
@@ -713,12 +719,22 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         // side: the bulk
         GPR_HIP_TRY(wait(g_la.side, mid_last));
         const int KB2 = (Rrest < DB) ? Rrest : DB, c3 = c2 + KB2;
+        // The bulk of the trailing update is applied for TWO panels at a time: after an even step only the next two column
+        // blocks have received panel K (K + 1 on mid, K + 2 here); the odd step that follows brings block K + 2 up to date
+        // with both panels and then updates everything beyond with k = 512 -- the tiled GEMM runs at more than twice the
+        // rate there than at k = 256, and it has two steps of the chain to hide behind instead of one.
+        if (deferred) launch_narrow(g_la.side, Rrest, KB2, at(c2, K0 - DB), at(c2, K0 - DB), at(c2, c2), lda, 1);   // U_{K-1}(K + 2)
         launch_narrow(g_la.side, Rrest, KB2, at(c2, K0), at(c2, K0), at(c2, c2), lda, 1);     // U_K(K + 2)
         bulk_last = bulk_first = mark(g_la.side);
-        if (c3 < n) {                                                                          // U_K(K + 3 ...)
-            rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, KB, -1.0, at(c3, K0), lda, at(c3, K0), lda, 1.0, at(c3, c3), lda, 1);
-            bulk_last = mark(g_la.side);
-        }
+        if (c3 < n) {                                                                          // U(K + 3 ...)
+            if (!deferred && pair_bulk && KB == DB) deferred = true;                           // wait for the next panel
+            else {
+                const int k0 = deferred ? K0 - DB : K0, kk = deferred ? KB + DB : KB;
+                rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, kk, -1.0, at(c3, k0), lda, at(c3, k0), lda, 1.0, at(c3, c3), lda, 1);
+                bulk_last = mark(g_la.side);
+                deferred = false;
+            }
+        } else deferred = false;
     }
     if (la) { GPR_HIP_TRY(wait(st, mid_last)); GPR_HIP_TRY(wait(st, bulk_last)); }
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
