@@ -1036,6 +1036,96 @@ extern "C" int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, lo
 }
 
 // (the Cholesky factorisation itself lives in potrf.hip; it calls back into the tiled GEMM through this)
+// ---- trailing update of the Cholesky look-ahead as a PERSISTENT kernel that leaves CUs free:  C[lower 128 x 128 tiles] -= P P^T
+// (P = the panel(s) just solved, [m x k] row-major, k a multiple of 16).  The tiled GEMM above fills every CU with its
+// workgroups, and a diagonal-block kernel of the dependent chain that shares its CU with them runs three times longer
+// (its factor wavefront waits behind 64-cycle matrix instructions it cannot pre-empt).  Here `nwg` workgroups of eight
+// wavefronts, each too large for a second one to fit beside it (the LDS request), loop over the tiles: they settle on
+// nwg different CUs and the chain kernels are dispatched onto the CUs that stay free.
+constexpr int SB_T = 128, SB_K = 16, SB_LD = SB_K + 1;
+__global__ void __launch_bounds__(512) syrk_bulk_kernel(int m, int k, const double *__restrict__ P, long long ldp,
+                                                         double *__restrict__ C, long long ldc) {
+    __shared__ double As[2][SB_T * SB_LD];
+    __shared__ double Bs[2][SB_T * SB_LD];
+    extern __shared__ double sb_pad[];                       // never touched: keeps a second workgroup off the CU
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 64;
+    const int nbt = (m + SB_T - 1) / SB_T, ntile = nbt * (nbt + 1) / 2;
+    const int lk = tid & 15, lr = tid >> 4;                  // tile loads: k offset, row offset (+ 32 i)
+    for (int t = blockIdx.x; t < ntile; t += gridDim.x) {
+        int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+        while ((bi + 1) * (bi + 2) / 2 <= t) bi++;
+        while (bi * (bi + 1) / 2 > t) bi--;
+        const int bj = t - bi * (bi + 1) / 2;
+        const int bm0 = bi * SB_T, bn0 = bj * SB_T;
+        d4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+        double ra[4], rb[4];
+        auto load_tile = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int gm = bm0 + lr + 32 * i, gn = bn0 + lr + 32 * i;
+                ra[i] = gm < m ? P[(long long)gm * ldp + k0 + lk] : 0.0;
+                rb[i] = gn < m ? P[(long long)gn * ldp + k0 + lk] : 0.0;
+            }
+        };
+        auto store_tile = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) { As[buf][(lr + 32 * i) * SB_LD + lk] = ra[i]; Bs[buf][(lr + 32 * i) * SB_LD + lk] = rb[i]; }
+        };
+        const int nkt = k / SB_K;
+        load_tile(0); store_tile(0);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; kt++) {
+            const int buf = kt & 1;
+            if (kt + 1 < nkt) load_tile((kt + 1) * SB_K);
+#pragma unroll
+            for (int ks = 0; ks < SB_K / 4; ks++) {
+                const int kr = ks * 4 + (lane >> 4);
+                double a[2], b[4];
+#pragma unroll
+                for (int i = 0; i < 2; i++) a[i] = As[buf][(wm + 16 * i + (lane & 15)) * SB_LD + kr];
+#pragma unroll
+                for (int j = 0; j < 4; j++) b[j] = Bs[buf][(wn + 16 * j + (lane & 15)) * SB_LD + kr];
+#pragma unroll
+                for (int i = 0; i < 2; i++)
+#pragma unroll
+                    for (int j = 0; j < 4; j++) acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < nkt) store_tile(buf ^ 1);
+            __syncthreads();
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gm = bm0 + wm + 16 * i + (lane >> 4) + 4 * r, gn = bn0 + wn + 16 * j + (lane & 15);
+                    if (gm < m && gn < m) C[(long long)gm * ldc + gn] -= acc[i][j][r];
+                }
+    }
+}
+
+// C[m x m, lower tiles] -= P P^T on `nwg` CUs at most (see syrk_bulk_kernel)
+int gpr_syrk_bulk_internal(hipStream_t st, int m, int k, const double *P, long long ldp, double *C, long long ldc, int nwg) {
+    if (m <= 0 || k <= 0) return GPR_OK;
+    GPR_REQUIRE(k % SB_K == 0 && nwg >= 1, "gpr_syrk_bulk: k must be a multiple of %d", SB_K);
+    const int nbt = (m + SB_T - 1) / SB_T, ntile = nbt * (nbt + 1) / 2;
+    constexpr int pad_bytes = 16 * 1024;                      // static 69.6 KB + 16 KB: two of these do not fit 160 KB
+    static bool attr = false;
+    if (!attr) {
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)syrk_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_bytes));
+        attr = true;
+    }
+    hipLaunchKernelGGL(syrk_bulk_kernel, dim3(std::min(ntile, nwg)), dim3(512), pad_bytes, st, m, k, P, ldp, C, ldc);
+    LAUNCH_CHECK("syrk_bulk");
+    return GPR_OK;
+}
+
 int gpr_gemm_internal(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                       const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only) {
     return launch_gemm(st, ta, tb, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only);

@@ -111,6 +111,7 @@ void gpr_prof_end(hipStream_t st, int id);
 
 // tiled FP64 GEMM of dense.hip: C = alpha op(A) op(B) + beta C; lower_only bit 0: skip tiles above the diagonal,
 // bit 1: op(A) lower triangular, bit 2: op(B) = B^T with B lower triangular, bit 3: 64 x 64 tiles, bit 4: op(B) = B lower triangular
+int gpr_syrk_bulk_internal(hipStream_t st, int m, int k, const double *P, long long ldp, double *C, long long ldc, int nwg);   // C[lower tiles] -= P P^T on nwg CUs at most
 int gpr_gemm_internal(hipStream_t st, int ta, int tb, int m, int n, int k, double alpha, const double *a, long long lda,
                       const double *b, long long ldb, double beta, double *c, long long ldc, int lower_only);
 

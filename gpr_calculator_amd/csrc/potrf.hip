@@ -668,6 +668,7 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
     // a bulk launch twice as long beside it only lengthens the steps it overlaps (4.2 -> 4.4 ms): pairs from 8192 rows on
     static const bool pair_env = !getenv("GPR_POTRF_NO_PAIR");
     const bool pair_bulk = pair_env && n >= 8192;
+    static const int reserve_cus = getenv("GPR_POTRF_RESERVE_CUS") ? atoi(getenv("GPR_POTRF_RESERVE_CUS")) : 24;
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB, step++) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
         double *wop = (double *)scratch + (size_t)(step % 3) * ops_doubles, *lop = wop + 16 * TILE_DOUBLES;
@@ -730,7 +731,12 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
             if (!deferred && pair_bulk && KB == DB) deferred = true;                           // wait for the next panel
             else {
                 const int k0 = deferred ? K0 - DB : K0, kk = deferred ? KB + DB : KB;
-                rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, kk, -1.0, at(c3, k0), lda, at(c3, k0), lda, 1.0, at(c3, c3), lda, 1);
+                // where the chain of diagonal blocks decides the time (not pair_bulk) the bulk runs as a persistent kernel
+                // on all but a few CUs, which stay free for the chain; elsewhere the plain tiled GEMM on every CU
+                if (reserve_cus > 0 && !pair_bulk && kk % 16 == 0 && n - c3 >= 1024)
+                    rc = gpr_syrk_bulk_internal(g_la.side, n - c3, kk, at(c3, k0), lda, at(c3, c3), lda, 256 - reserve_cus);
+                else
+                    rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, kk, -1.0, at(c3, k0), lda, at(c3, k0), lda, 1.0, at(c3, c3), lda, 1);
                 bulk_last = mark(g_la.side);
                 deferred = false;
             }

@@ -7,7 +7,7 @@ import sys
 rows = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "?"), int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1))
                for r in csv.DictReader(open(sys.argv[1]))))
 short = lambda n: ("diag" if "potrf_diag256" in n else "panel" if "potrf_panel256" in n else "gemm128" if "gemm128" in n else
-                   "gemm64" if "gemm_kernel" in n else "syrk" if "syrk_narrow" in n else "triinv" if "tri_inv64" in n else None)
+                   "gemm64" if "gemm_kernel" in n else "bulk" if "syrk_bulk" in n else "syrk" if "syrk_narrow" in n else "triinv" if "tri_inv64" in n else None)
 # the last complete factorisation: from the last diag launch with the largest step count backwards
 diags = [i for i, r in enumerate(rows) if short(r[2]) == "diag"]
 ends = [i for i, r in enumerate(rows) if short(r[2]) == "triinv"]
