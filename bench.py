@@ -383,9 +383,9 @@ def main():
                    "95 flop per same-species row pair"),
             "trmm": ("gemm128_kernel via gpr_trmm_lower: V = L^-1 K_trans^T (predictive variance)", float(N) * N * m_rows,
                      "N^2 m (triangular-solve form of the variance)"),
-            "gemm": (("ws_tail_kernel (+ ws_tail_combine_kernel; gpr_ws_tail): mean = Psi* w and the weight-space variance "
-                      "|psi|^2 - |C^-1 psi|^2 from FP64 MFMA tiles of Psi* C^-T (C^-1 lower triangular: half of the m x F x F "
-                      "product; the product itself is never stored)",
+            "gemm": (("ws_tail_rows_kernel (gpr_ws_tail): mean = Psi* w and the weight-space variance |psi|^2 - |C^-1 psi|^2 from "
+                      "FP64 MFMA tiles of Psi* C^-T (C^-1 lower triangular: half of the m x F x F product; the product itself is "
+                      "never stored; 32 rows of Psi* resident in LDS per workgroup, C^-1 streamed from L2)",
                       float(m_rows) * F * (F + 1) + 4.0 * m_rows * F,
                       "m F (F + 1) + 4 m F for the m = %d predicted rows and F = %d features" % (m_rows, F))
                      if ws_native else
@@ -416,6 +416,14 @@ def main():
         roofline = {"bound": "fp64-vector" if dom in ("so3", "ee") else "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
                     "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "event_sampling": sample, "flop_per_step": flops,
+                    # the timed region keeps `batches_in_flight` device chains running side by side: a launch's duration there
+                    # includes what it waits for the kernels of the other chains (rocprofv3 of this command shows the same).
+                    # `solo`: the same kernel in the synchronous one-batch calls measured right after the timed region
+                    "batches_in_flight": depth if pipelined else 1,
+                    "solo": ({"avg_launch_ms": per_sync[dom][0] / max(per_sync[dom][1], 1e-9),
+                              "achieved": flops / max(per_step[dom][1], 1e-9) / (per_sync[dom][0] / max(per_sync[dom][1], 1e-9) * 1e-3) / 1e12,
+                              "frac": flops / max(per_step[dom][1], 1e-9) / (per_sync[dom][0] / max(per_sync[dom][1], 1e-9) * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS}
+                             if dom in per_sync and per_sync[dom][0] > 0 else None),
                     "work_unit": unit_note,
                     "kernel_ms_per_step": {k: round(v[0], 4) for k, v in sorted(per_step.items(), key=lambda kv: -kv[1][0])},
                     # the same figures for every profiled kernel kind of the step (the top two are often within a few
