@@ -86,6 +86,8 @@ _L1_SIGNATURES = {
     "gpr_nbr_sizes": ([_vp, c_int_p, c_int_p], _i),
     "gpr_nbr_export": ([_vp, c_double_p, c_double_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p, c_int_p], _i),
     "gpr_nbr_destroy": ([_vp], _i),
+    "gpr_nbr_build_device_rows": ([C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, C.POINTER(_i)], _i),
+    "gpr_nbr_set_fused": ([_i], _i),
     "gpr_dot2_features": ([_vp, _vp, _i, c_int_p, _d, _vp, _ll], _i),
     "gpr_set_shard": ([_i, _i], _i),
     "gpr_profile_enable": ([_i], _i),

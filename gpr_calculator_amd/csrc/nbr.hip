@@ -638,6 +638,10 @@ thread_local int g_stage_next = 0;
 }
 
 static std::atomic<unsigned> g_nbr_epoch{1};
+static std::atomic<int> g_nbr_fused{1};
+// tests / A-B timing: 0 keeps every capped build on the five-launch path, 1 (default) lets the one-launch builder take
+// the builds it can
+extern "C" int gpr_nbr_set_fused(int on) { g_nbr_fused.store(on ? 1 : 0); return GPR_OK; }
 
 static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                  const double *cells, const int *pbc, const int *numbers, double rcut,
@@ -714,7 +718,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     int nmax_atoms = 0, nimg_max = 1;
     for (int s = 0; s < nstruct; s++) { nmax_atoms = std::max(nmax_atoms, sinfo[s].n); nimg_max = std::max(nimg_max, sinfo[s].nimg); }
     static const bool no_fused = getenv("GPR_NBR_NO_FUSED") != nullptr;
-    if (!no_fused && cap_pairs > 0 && cap_rows > 0 && natoms > 0 && n_extra == 0 && nstruct <= NBRF_MAX_STRUCT && nmax_atoms <= NBRF_MAX_N &&
+    if (!no_fused && g_nbr_fused.load() && cap_pairs > 0 && cap_rows > 0 && natoms > 0 && n_extra == 0 && nstruct <= NBRF_MAX_STRUCT && nmax_atoms <= NBRF_MAX_N &&
         nimg_max <= 512) {
         if (!sb.dev && hipHostGetDevicePointer(&sb.dev, sb.p, 0) != hipSuccess) { gpr_set_error("gpr_nbr_build_device: no device alias of the staging buffer"); return fail(GPR_ERR_HIP); }
         nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;

@@ -299,6 +299,7 @@ const int *gpr_nbr_extra_ptr(const gpr_nbr *nb);
 int gpr_nbr_build_device_rows(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                               const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
                               int cap_pairs, int cap_rows, int *row_index_dev, int *x_index_dev, int *rows_done);
+int gpr_nbr_set_fused(int on);      /* tests / A-B timing: 0 keeps every capped build on the five-launch path */
 /* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
 int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
 /* the four device ints gpr_nbr_info_to converts (for kernels that deliver them themselves, gpr_ws_tail_status) */

@@ -1,0 +1,101 @@
+"""GPU: the one-launch neighbour search (nbr_fused_kernel behind gpr_nbr_build_device_rows: geometry upload, count,
+offsets across structures by look-back, fill, force-point regrouping by table look-up) against the five-launch path it
+replaces -- bit for bit, array by array -- on batches that reach its corners: more structures than lanes of a wavefront,
+clusters without periodic images next to small cells with 125 of them, 108 atoms (two passes of 64 lanes per centre), two
+species with the sign-flipping weights; and the all-or-nothing overflow answer."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _arrays(strucs):
+    from gpr_calculator_amd.neighbors import atoms_arrays
+    arrs = [atoms_arrays(s) for s in strucs]
+    atom0 = np.concatenate(([0], np.cumsum([len(a[0]) for a in arrs]))).astype(np.int32)
+    num = np.ascontiguousarray(np.concatenate([a[0] for a in arrs]).astype(np.int32))
+    pos = np.ascontiguousarray(np.concatenate([a[1] for a in arrs]).astype(np.float64))
+    cells = np.ascontiguousarray(np.stack([np.asarray(a[2], dtype=np.float64).reshape(9) for a in arrs]))
+    pbc = np.ascontiguousarray(np.stack([np.asarray(a[3], dtype=np.int32).reshape(3) for a in arrs]).astype(np.int32))
+    return atom0, pos, cells, pbc, num
+
+
+def _build(strucs, capP, capR, fused, weight_on=0):
+    import torch
+    from gpr_calculator_amd import _lib, device as dev
+    L = _lib.lib()
+    vp = C.c_void_p
+    atom0, pos, cells, pbc, num = _arrays(strucs)
+    natoms = int(atom0[-1])
+    ri = torch.full((2 * capR,), -7, dtype=torch.int32, device=dev.device())
+    h, done = vp(), C.c_int(0)
+    L.gpr_nbr_set_fused(int(fused))
+    try:
+        dev.check(L.gpr_nbr_build_device_rows(C.byref(h), dev.stream_ptr(), len(strucs), atom0.ctypes.data, pos.ctypes.data, cells.ctypes.data,
+                                              pbc.ctypes.data, num.ctypes.data, 5.0, weight_on, capP, capR, ri.data_ptr(),
+                                              ri.data_ptr() + 4 * capR, C.byref(done)), "gpr_nbr_build_device_rows")
+    finally:
+        L.gpr_nbr_set_fused(1)
+    assert done.value == int(fused)
+    if not done.value:
+        dev.check(L.gpr_nbr_force_rows(h, natoms, None, None, capR, ri.data_ptr(), ri.data_ptr() + 4 * capR), "gpr_nbr_force_rows")
+    info = torch.zeros(4, dtype=torch.float64, device=dev.device())
+    dev.check(L.gpr_nbr_info_to(h, info.data_ptr()), "gpr_nbr_info_to")
+    p = [vp() for _ in range(9)]
+    dev.check(L.gpr_nbr_device_arrays(h, *[C.byref(x) for x in p]), "gpr_nbr_device_arrays")
+    info = info.cpu().numpy()
+    over, P, S = int(info[1]), int(info[2]), int(info[3])
+
+    def grab(ptr, n, dtype):
+        t = torch.empty(n, dtype=dtype, device=dev.device())
+        if n:
+            dev.check(L.gpr_memcpy_dtod(dev.stream_ptr(), t.data_ptr(), ptr, n * t.element_size()), "gpr_memcpy_dtod")
+        return t.cpu().numpy()
+    out = {"info": info, "cr0": grab(p[3], natoms + 1, torch.int32), "cp0": grab(p[2], natoms + 1, torch.int32)}
+    if not over:
+        out.update(vec=grab(p[0], 3 * P, torch.float64), w=grab(p[1], P, torch.float64), rp0=grab(p[4], S + 1, torch.int32),
+                   self_row=grab(p[5], natoms, torch.int32), seq=grab(p[6], 2 * S, torch.int32), numbers=grab(p[7], natoms, torch.int32),
+                   atom0=grab(p[8], len(strucs) + 1, torch.int32), row_index=ri[:S].cpu().numpy(), x_index=ri[capR:capR + S].cpu().numpy())
+    L.gpr_nbr_destroy(h)
+    return out
+
+
+def _batches():
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    from gpr_calculator_amd.synthetic import fcc_cell, neb_images
+    rng = np.random.default_rng(5)
+    many = neb_images(70, seed=300)                                             # more structures than lanes
+    small = [fcc_cell(seed=k, reps=1, species=(46, 78), sigma=0.1) for k in range(6)]      # 4 atoms, 125 images
+    big = [fcc_cell(seed=9, reps=3, species=(46,), sigma=0.05)]                 # 108 atoms
+    clusters = [SimpleAtoms(rng.choice([8, 12, 46], n), rng.normal(0.0, 2.2, (n, 3)), np.eye(3) * 30.0, [False] * 3) for n in (5, 13, 1, 9)]
+    slab = [SimpleAtoms(s.numbers, s.positions, s.cell, [True, True, False]) for s in small[:2]]
+    return {"many": many, "mixed": small + big + clusters + slab + many[:3]}
+
+
+@pytest.mark.parametrize("name", ["many", "mixed"])
+@pytest.mark.parametrize("weight_on", [0, 1])
+def test_one_launch_build_is_the_five_launch_build(name, weight_on):
+    strucs = _batches()[name]
+    natoms = sum(len(s) for s in strucs)
+    capP, capR = natoms * 140, natoms * 40
+    a, b = _build(strucs, capP, capR, True, weight_on), _build(strucs, capP, capR, False, weight_on)
+    assert a["info"][1] == 0 and b["info"][1] == 0 and a["info"][0] == 0
+    assert set(a) == set(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert a["info"][3] == a["cr0"][-1] and a["info"][2] == a["cp0"][-1]
+
+
+def test_overflow_is_all_or_nothing():
+    strucs = _batches()["mixed"]
+    natoms = sum(len(s) for s in strucs)
+    full = _build(strucs, natoms * 140, natoms * 40, True)
+    P, S = int(full["info"][2]), int(full["info"][3])
+    for capP, capR in ((P - 1, S), (P, S - 1), (64, 64)):
+        o = _build(strucs, capP, capR, True)
+        assert o["info"][1] == 1 and int(o["info"][2]) == P and int(o["info"][3]) == S          # flag up, true sizes reported
+        assert not o["cr0"].any() and not o["cp0"].any()                                      # every range empty
+    exact = _build(strucs, P, S, True)                                                         # capacities that just fit
+    assert exact["info"][1] == 0 and np.array_equal(exact["seq"], full["seq"])

@@ -14,8 +14,6 @@ pbc = np.ascontiguousarray(np.stack([np.asarray(s.pbc, dtype=np.int32) for s in 
 num = np.ascontiguousarray(np.concatenate([s.numbers for s in b]).astype(np.int32))
 natoms = int(atom0[-1]); capP, capR = natoms * 48, natoms * 32
 ri = torch.empty(2 * capR, dtype=torch.int32, device=dev.device())
-L.gpr_nbr_build_device_rows.argtypes = [C.POINTER(C.c_void_p), C.c_void_p] + [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
-L.gpr_nbr_build_device_rows.restype = C.c_int
 def call():
     h, done = C.c_void_p(), C.c_int(0)
     rc = L.gpr_nbr_build_device_rows(C.byref(h), dev.stream_ptr(), 64, atom0.ctypes.data, pos.ctypes.data, cells.ctypes.data, pbc.ctypes.data,
