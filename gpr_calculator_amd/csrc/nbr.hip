@@ -411,7 +411,7 @@ struct nbrf_args {
     const char *blob_host;           // device alias of the page-locked blob [wpos | shifts | sinfo | numbers | sid | atom0]
     char *blob_dev;                  // its device copy
     long long off_shift, off_sinfo, off_num, off_sid, off_a0, bytes;
-    int nstruct, natoms, weight_on, cap_pairs, cap_rows, nmax, nimg_max, dbg;
+    int nstruct, natoms, weight_on, cap_pairs, cap_rows, nmax, nimg_max, dbg, use_mask, mask_off;
     unsigned epoch;
     double rc2;
     int *cr0, *cp0, *info;           // [natoms + 1] each; info = [missing, overflow, pairs, rows]
@@ -422,6 +422,12 @@ struct nbrf_args {
     nbr_sinfo si[96];
 };
 constexpr int NBRF_WAVES = 16, NBRF_MAX_N = 128, NBRF_MAX_STRUCT = 96, NBRF_POLLS = 1 << 22;
+
+__device__ __forceinline__ void so3_nbr_wave_lds_sync() {
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 
 __device__ __forceinline__ bool nbrf_wait(const unsigned long long *p, unsigned epoch, unsigned &value) {
     for (int polls = 0; polls < NBRF_POLLS; polls++) {
@@ -445,6 +451,8 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
     int *misc = offP + a.nmax;                               // [8]: TR, TP, baseR, baseP, ok, missing
     unsigned short *li = (unsigned short *)(misc + 8);       // [n][n] local row of neighbour j among centre i's rows, 0xffff: none
     unsigned char *fnd = (unsigned char *)(li + a.nmax * a.nmax);   // [n][n] images of j within the cutoff of i
+    // [n][n] which images, when they fit a 64-bit mask and the table fits LDS (else NULL: the fill counts again)
+    unsigned long long *msk = a.use_mask ? (unsigned long long *)(nf_smem + a.mask_off) : nullptr;
     // ---- geometry: host blob -> LDS (+ device copy)
     {
         const double *hw = (const double *)a.blob_host + 3 * (size_t)si.atom0, *hs = (const double *)(a.blob_host + a.off_shift) + 3 * (size_t)si.img0;
@@ -454,7 +462,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
         for (int e = tid; e < 3 * n; e += blockDim.x) { const double v = hw[e]; pos[e] = v; dw[e] = v; }
         for (int e = tid; e < 3 * nimg; e += blockDim.x) sh[e] = hs[e];
         for (int e = tid; e < n; e += blockDim.x) { const int z = hn[e]; num[e] = z; dn[e] = z; dsid[e] = s; }
-        for (int e = tid; e < n * n; e += blockDim.x) li[e] = 0xffff;
+        for (int e = tid; e < n * n; e += blockDim.x) { li[e] = 0xffff; fnd[e] = 0; }
         if (s == 0) {            // what is shared by all structures: shift table, structure table, atom offsets
             const long long lo = a.off_shift, hi = a.off_num;
             for (long long e = lo + 8LL * tid; e < hi; e += 8LL * blockDim.x) *(double *)(a.blob_dev + e) = *(const double *)(a.blob_host + e);
@@ -464,7 +472,8 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
     }
     __syncthreads();
     if (a.dbg == 1) return;
-    // ---- count: one wavefront per centre
+    // ---- count: one wavefront per centre, a lane per neighbour j walking its images; which images are inside the cutoff is
+    // kept as a bit mask per (centre, neighbour) where it fits (<= 64 images, <= 64 atoms): the fill then tests nothing twice
     for (int il = wave; il < n; il += NBRF_WAVES) {
         const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
         int pair_run = 0, row_run = 0;
@@ -472,6 +481,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
             const int j = jb + lane;
             const bool live = j < n;
             int found = 0;
+            unsigned long long bits = 0ull;
             if (live) {
                 const double dx0 = pos[3 * j] - pix, dy0 = pos[3 * j + 1] - piy, dz0 = pos[3 * j + 2] - piz;
                 for (int im = 0; im < nimg; im++) {
@@ -479,9 +489,10 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
                     const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
                     // no fused multiply-add: the predicate has to agree with the host builder to the bit
                     const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-                    if (r2 < a.rc2) found++;
+                    if (r2 < a.rc2) { found++; bits |= 1ull << (im & 63); }
                 }
                 fnd[il * n + j] = (unsigned char)(found > 0);
+                if (msk) msk[il * n + j] = bits;
             }
             const int isrow = (live && (found > 0 || j == il)) ? 1 : 0;
             const int pincl = wave_incl_scan(found, lane), rincl = wave_incl_scan(isrow, lane);
@@ -546,50 +557,88 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
     int missing = 0;
     if (!over) {
         // ---- fill: pairs ordered by (j, image), rows by j
-        for (int il = wave; il < n; il += NBRF_WAVES) {
-            const int i = si.atom0 + il, zi = num[il];
-            const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
-            int pair_run = baseP + offP[il];
-            const int row0 = baseR + offR[il];
-            for (int jb = 0; jb < n; jb += 64) {
-                const int j = jb + lane;
-                const bool live = j < n;
-                // the images are counted again (the table keeps one bit per pair of atoms): same arithmetic, same answer
-                int found = 0;
-                double dx0 = 0.0, dy0 = 0.0, dz0 = 0.0;
-                if (live && fnd[il * n + j]) {
-                    dx0 = pos[3 * j] - pix; dy0 = pos[3 * j + 1] - piy; dz0 = pos[3 * j + 2] - piz;
-                    for (int im = 0; im < nimg; im++) {
-                        if (j == il && im == si.zero_img) continue;
-                        const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
-                        const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-                        if (r2 < a.rc2) found++;
-                    }
-                }
-                const int pincl = wave_incl_scan(found, lane);
-                const unsigned short lr = live ? li[il * n + j] : (unsigned short)0xffff;
-                if (lr != 0xffff) {
-                    const int row = row0 + lr;
-                    int p = pair_run + pincl - found;
-                    a.seq[2 * (size_t)row] = il; a.seq[2 * (size_t)row + 1] = j;
-                    a.rp0[row] = p;
-                    if (j == il) a.self_row[i] = row;
-                    if (found) {
-                        const int zj = num[j];
-                        const double wgt = (a.weight_on && zj != zi) ? -(double)zj : (double)zj;     // SO3.py:381-385
-                        for (int im = 0; im < nimg; im++) {
-                            if (j == il && im == si.zero_img) continue;
-                            const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
-                            const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
-                            if (r2 < a.rc2) {
-                                a.vec[3 * (size_t)p] = dx; a.vec[3 * (size_t)p + 1] = dy; a.vec[3 * (size_t)p + 2] = dz;
+        if (msk) {
+            for (int il = wave; il < n; il += NBRF_WAVES) {
+                const int i = si.atom0 + il, zi = num[il];
+                const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
+                int pair_run = baseP + offP[il];
+                const int row0 = baseR + offR[il];
+                for (int jb = 0; jb < n; jb += 64) {
+                    const int j = jb + lane;
+                    const bool live = j < n;
+                    unsigned long long bits = live ? msk[il * n + j] : 0ull;
+                    const int found = __popcll(bits);
+                    const int pincl = wave_incl_scan(found, lane);
+                    const unsigned short lr = live ? li[il * n + j] : (unsigned short)0xffff;
+                    if (lr != 0xffff) {
+                        const int row = row0 + lr;
+                        int p = pair_run + pincl - found;
+                        a.seq[2 * (size_t)row] = il; a.seq[2 * (size_t)row + 1] = j;
+                        a.rp0[row] = p;
+                        if (j == il) a.self_row[i] = row;
+                        if (found) {
+                            const int zj = num[j];
+                            const double wgt = (a.weight_on && zj != zi) ? -(double)zj : (double)zj;     // SO3.py:381-385
+                            const double dx0 = pos[3 * j] - pix, dy0 = pos[3 * j + 1] - piy, dz0 = pos[3 * j + 2] - piz;
+                            while (bits) {                        // images in ascending order: the order of the pairs
+                                const int im = __ffsll((long long)bits) - 1;
+                                bits &= bits - 1;
+                                a.vec[3 * (size_t)p] = dx0 + sh[3 * im]; a.vec[3 * (size_t)p + 1] = dy0 + sh[3 * im + 1];
+                                a.vec[3 * (size_t)p + 2] = dz0 + sh[3 * im + 2];
                                 a.w[p] = wgt;
                                 p++;
                             }
                         }
                     }
+                    pair_run += __shfl(pincl, 63);
                 }
-                pair_run += __shfl(pincl, 63);
+            }
+        } else {
+            for (int il = wave; il < n; il += NBRF_WAVES) {
+                const int i = si.atom0 + il, zi = num[il];
+                const double pix = pos[3 * il], piy = pos[3 * il + 1], piz = pos[3 * il + 2];
+                int pair_run = baseP + offP[il];
+                const int row0 = baseR + offR[il];
+                for (int jb = 0; jb < n; jb += 64) {
+                    const int j = jb + lane;
+                    const bool live = j < n;
+                    // the images are counted again (the table keeps one bit per pair of atoms): same arithmetic, same answer
+                    int found = 0;
+                    double dx0 = 0.0, dy0 = 0.0, dz0 = 0.0;
+                    if (live && fnd[il * n + j]) {
+                        dx0 = pos[3 * j] - pix; dy0 = pos[3 * j + 1] - piy; dz0 = pos[3 * j + 2] - piz;
+                        for (int im = 0; im < nimg; im++) {
+                            if (j == il && im == si.zero_img) continue;
+                            const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                            const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                            if (r2 < a.rc2) found++;
+                        }
+                    }
+                    const int pincl = wave_incl_scan(found, lane);
+                    const unsigned short lr = live ? li[il * n + j] : (unsigned short)0xffff;
+                    if (lr != 0xffff) {
+                        const int row = row0 + lr;
+                        int p = pair_run + pincl - found;
+                        a.seq[2 * (size_t)row] = il; a.seq[2 * (size_t)row + 1] = j;
+                        a.rp0[row] = p;
+                        if (j == il) a.self_row[i] = row;
+                        if (found) {
+                            const int zj = num[j];
+                            const double wgt = (a.weight_on && zj != zi) ? -(double)zj : (double)zj;     // SO3.py:381-385
+                            for (int im = 0; im < nimg; im++) {
+                                if (j == il && im == si.zero_img) continue;
+                                const double dx = dx0 + sh[3 * im], dy = dy0 + sh[3 * im + 1], dz = dz0 + sh[3 * im + 2];
+                                const double r2 = __dadd_rn(__dadd_rn(__dmul_rn(dx, dx), __dmul_rn(dy, dy)), __dmul_rn(dz, dz));
+                                if (r2 < a.rc2) {
+                                    a.vec[3 * (size_t)p] = dx; a.vec[3 * (size_t)p + 1] = dy; a.vec[3 * (size_t)p + 2] = dz;
+                                    a.w[p] = wgt;
+                                    p++;
+                                }
+                            }
+                        }
+                    }
+                    pair_run += __shfl(pincl, 63);
+                }
             }
         }
         if (a.dbg == 4) return;
@@ -748,8 +797,12 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.vec = nb->d_vec; fa.w = nb->d_w; fa.rp0 = nb->d_rp0; fa.self_row = nb->d_self; fa.seq = nb->d_seq;
         fa.row_index = row_index_dev; fa.x_index = row_index_dev ? x_index_dev : nullptr;
         for (int s = 0; s < nstruct; s++) fa.si[s] = sinfo[s];
-        const size_t lds = (size_t)(3 * nmax_atoms + 3 * nimg_max) * sizeof(double) + (size_t)(5 * nmax_atoms + 8) * sizeof(int) +
-                           (size_t)nmax_atoms * nmax_atoms * 3 + 16;
+        size_t lds = (size_t)(3 * nmax_atoms + 3 * nimg_max) * sizeof(double) + (size_t)(5 * nmax_atoms + 8) * sizeof(int) +
+                     (size_t)nmax_atoms * nmax_atoms * 3 + 16;
+        fa.use_mask = (nmax_atoms <= 64 && nimg_max <= 64) ? 1 : 0;
+        lds = (lds + 7) / 8 * 8;
+        fa.mask_off = (int)(lds / 8);                        // in doubles from the start of the dynamic LDS
+        if (fa.use_mask) lds += (size_t)nmax_atoms * nmax_atoms * 8;
         hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
         hipError_t e = hipGetLastError();
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
