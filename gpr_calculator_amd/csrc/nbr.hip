@@ -459,10 +459,18 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
         const int *hn = (const int *)(a.blob_host + a.off_num) + si.atom0;
         double *dw = (double *)a.blob_dev + 3 * (size_t)si.atom0;
         int *dn = (int *)(a.blob_dev + a.off_num) + si.atom0, *dsid = (int *)(a.blob_dev + a.off_sid) + si.atom0;
-        for (int e = tid; e < 3 * n; e += blockDim.x) { const double v = hw[e]; pos[e] = v; dw[e] = v; }
-        for (int e = tid; e < 3 * nimg; e += blockDim.x) sh[e] = hs[e];
-        for (int e = tid; e < n; e += blockDim.x) { const int z = hn[e]; num[e] = z; dn[e] = z; dsid[e] = s; }
+        // the three reads cross PCIe: all of them are requested before anything waits for one (the usual structure needs
+        // one pass of each loop), and the LDS tables are cleared while they are on their way
+        const bool p0 = tid < 3 * n, p1 = tid < 3 * nimg, p2 = tid < n;
+        const double v0 = p0 ? hw[tid] : 0.0, v1 = p1 ? hs[tid] : 0.0;
+        const int z0 = p2 ? hn[tid] : 0;
         for (int e = tid; e < n * n; e += blockDim.x) { li[e] = 0xffff; fnd[e] = 0; }
+        if (p0) { pos[tid] = v0; dw[tid] = v0; }
+        if (p1) sh[tid] = v1;
+        if (p2) { num[tid] = z0; dn[tid] = z0; dsid[tid] = s; }
+        for (int e = tid + blockDim.x; e < 3 * n; e += blockDim.x) { const double v = hw[e]; pos[e] = v; dw[e] = v; }
+        for (int e = tid + blockDim.x; e < 3 * nimg; e += blockDim.x) sh[e] = hs[e];
+        for (int e = tid + blockDim.x; e < n; e += blockDim.x) { const int z = hn[e]; num[e] = z; dn[e] = z; dsid[e] = s; }
         if (s == 0) {            // what is shared by all structures: shift table, structure table, atom offsets
             const long long lo = a.off_shift, hi = a.off_num;
             for (long long e = lo + 8LL * tid; e < hi; e += 8LL * blockDim.x) *(double *)(a.blob_dev + e) = *(const double *)(a.blob_host + e);
