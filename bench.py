@@ -227,7 +227,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-route", action="store_true", help="skip the extra pair-kernel measurement of the Dot run")
     ap.add_argument("--mode", default="predict", choices=["predict", "fit"])
-    ap.add_argument("--depth", type=int, default=3, help="batches in flight in the timed region (1 = the synchronous call)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the timed region (1 = the synchronous call)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the untimed sustained leg after the timed region")
     ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report (no GPU work): checks the launch path")
     args = ap.parse_args()

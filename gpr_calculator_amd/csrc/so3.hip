@@ -208,17 +208,27 @@ __device__ __forceinline__ void cheb_eval2(const double *cheb, int nseg, int NF,
     const double inv_half = 2.0 * nseg / rcut, mid = (seg + 0.5) * rcut / nseg;
     const double t = (r - mid) * inv_half, t2 = 2.0 * t;
     const double2 *c = (const double2 *)(cheb + (size_t)seg * SO3_NCHEB * NF + f);
-    double2 cf[SO3_NCHEB];
+    // the coefficients come in two halves of eight (the upper one first: the recurrence runs downwards): sixteen 16-byte
+    // loads in flight at once cost 64 registers, which is what pushed the kernel into scratch
+    constexpr int H = SO3_NCHEB / 2;
+    double2 hi[H], lo[H];
 #pragma unroll
-    for (int k = 0; k < SO3_NCHEB; k++) cf[k] = c[k * (NF / 2)];    // all loads in flight before the recurrences
+    for (int k = 0; k < H; k++) hi[k] = c[(H + k) * (NF / 2)];
     double a1 = 0.0, a2 = 0.0, b1 = 0.0, b2 = 0.0;
 #pragma unroll
-    for (int k = SO3_NCHEB - 1; k >= 1; k--) {
-        const double a0 = cf[k].x + t2 * a1 - a2; a2 = a1; a1 = a0;
-        const double b0 = cf[k].y + t2 * b1 - b2; b2 = b1; b1 = b0;
+    for (int k = 0; k < H; k++) lo[k] = c[k * (NF / 2)];
+#pragma unroll
+    for (int k = H - 1; k >= 0; k--) {
+        const double a0 = hi[k].x + t2 * a1 - a2; a2 = a1; a1 = a0;
+        const double b0 = hi[k].y + t2 * b1 - b2; b2 = b1; b1 = b0;
     }
-    v0 = cf[0].x + t * a1 - a2;
-    v1 = cf[0].y + t * b1 - b2;
+#pragma unroll
+    for (int k = H - 1; k >= 1; k--) {
+        const double a0 = lo[k].x + t2 * a1 - a2; a2 = a1; a1 = a0;
+        const double b0 = lo[k].y + t2 * b1 - b2; b2 = b1; b1 = b0;
+    }
+    v0 = lo[0].x + t * a1 - a2;
+    v1 = lo[0].y + t * b1 - b2;
 }
 
 __global__ void so3_radial_eval_kernel(const double *cheb, int nseg, int ncheb, int NF, double rcut, int nr, const double *rs,
