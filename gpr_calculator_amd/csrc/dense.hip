@@ -548,28 +548,35 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
         double q2 = 0.0;
 #pragma unroll
         for (int wv = 0; wv < NW; wv++) q2 += red[wv * WT_R + tid];                    // wavefront order
-        part[(size_t)blockIdx.x * m + bm0 + tid] = q2;
+        // SPLIT 1: the sums travel between workgroups that are running at the same time, possibly on different XCDs (each
+        // with an L2 of its own): stores that go through, loads that do not stop at a cache (as in potrf.hip's hand-overs)
+        if (SPLIT == 1) __hip_atomic_store(&part[(size_t)blockIdx.x * m + bm0 + tid], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else part[(size_t)blockIdx.x * m + bm0 + tid] = q2;
     }
     if ((SPLIT == 2 ? (int)blockIdx.x == 0 : (int)blockIdx.x == ncb - 1) && lk == 0)     // owner of the last column block: full k range seen
 #pragma unroll
         for (int i = 0; i < AI; i++) {
             const int row = bm0 + lr + LR * i;
-            if (row < m) { mn[row] = mean2[i]; mn[(size_t)m + row] = norm2[i]; }
+            if (row < m) {
+                if (SPLIT == 1) {
+                    __hip_atomic_store(&mn[row], mean2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(&mn[(size_t)m + row], norm2[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else { mn[row] = mean2[i]; mn[(size_t)m + row] = norm2[i]; }
+            }
         }
     if (SPLIT == 2) return;                                      // ws_tail_combine_kernel adds the parts
-    // last workgroup of this row block: what the others wrote is visible after the fence / counter handshake
-    __threadfence();
+    // last workgroup of this row block: every workgroup counts itself in only after its own stores have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(&cnt[blockIdx.y], 1) == ncb - 1;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncb - 1;
     __syncthreads();
     if (!s_last) return;
-    __threadfence();
     if (tid < WT_R && bm0 + tid < m) {
         const int row = bm0 + tid;
         double q2 = 0.0;
-        for (int x = 0; x < ncb; x++) q2 += __builtin_nontemporal_load(&part[(size_t)x * m + row]);
-        out[row] = __builtin_nontemporal_load(&mn[row]);
-        { const double v = fmax(diag[row] - vsq * (__builtin_nontemporal_load(&mn[(size_t)m + row]) - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
+        for (int x = 0; x < ncb; x++) q2 += __hip_atomic_load(&part[(size_t)x * m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        out[row] = __hip_atomic_load(&mn[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        { const double v = fmax(diag[row] - vsq * (__hip_atomic_load(&mn[(size_t)m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
     }
 }
 
@@ -757,22 +764,87 @@ __global__ void __launch_bounds__(64 * TRW_NW) ws_tail_rows_kernel(int m, int n,
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int bm0 = blockIdx.x * TRW_ROWS;
     const int rows = min(TRW_ROWS, m - bm0);
-    // ---- the row block: rows bm0 .. bm0 + 31 are one contiguous range of P
+    // ---- the row block by LDS DMA, in COLUMN chunks of 128: a wavefront's first tile of a pair is the short one (k < 16 (j + 1)
+    // <= 256 for j <= 15), so it may start when the first two chunks of every row have landed, while the other half of
+    // the block (coming from HBM when the feature kernel has just written it) is still on its way.  One DMA instruction
+    // moves 128 columns of one row (1 KB, contiguous on both sides); the last chunk of a row is shorter and the lanes
+    // beyond it are switched off (they would land in the next row).  Wavefront w issues rows w and w + 16, chunk by chunk.
+    const int nchunk = (n + 127) / 128;
     {
-        const long long valid = (long long)rows * n / 2;            // 16-byte pieces that exist
-        const int npiece = TRW_ROWS * n / 2 + 64;                    // + the slack pieces (zeros)
-        const double *base = P + (long long)bm0 * n;
-        for (int e0 = wave * 64; e0 < npiece; e0 += 64 * TRW_NW) {
-            const int e = e0 + lane;
-            const double *g = e < valid ? base + 2 * (long long)e : g_tail_zero;
-            __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_t *)(sA + 2 * (size_t)e0), 16, 0, 0);
+        for (int k = tid; k < 128; k += 64 * TRW_NW) sA[(size_t)TRW_ROWS * n + k] = 0.0;      // the slack behind the last row
+        for (int ch = 0; ch < nchunk; ch++) {
+            const int c0 = 128 * ch, np = min(64, (n - c0) / 2);          // 16-byte pieces of this chunk
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const int r = wave + 16 * rr;
+                if (lane < np) {
+                    const double *g = r < rows ? P + (long long)(bm0 + r) * n + c0 + 2 * lane : g_tail_zero;
+                    __builtin_amdgcn_global_load_lds((const void *)g, (lds_void_t *)(sA + (size_t)r * n + c0), 16, 0, 0);
+                }
+            }
         }
     }
     for (int k = tid; k < n + 8; k += 64 * TRW_NW) sW[k] = k < n ? w[k] : 0.0;
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // the first two chunks of this wavefront's rows (all but the DMA instructions of the later chunks), then everybody's
+    if (nchunk > 2) {
+        if (nchunk == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    // ---- P w and |p|^2: 32 lanes per row
+    // ---- column tiles
+    const int c = lane & 15, q = lane >> 4;
+    const int ntile = (n + 15) / 16, npair = (ntile + 1) / 2, ntmax = (n + 7) / 8;
+    double sq[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
+    const double *a0p = sA + (size_t)c * n + 2 * q, *a1p = sA + (size_t)(16 + c) * n + 2 * q;
+    auto tile = [&](int j) {
+        const int col = 16 * j + c;
+        const int nts = min(2 * (j + 1), ntmax);                     // steps of 8 columns: k < 16 (j + 1)
+        const bool cok = col < n;
+        const double *bp = Ci + (long long)min(col, n - 1) * ldc + 2 * q;
+        auto loadb = [&](int t) -> d2v {
+            // columns beyond the row's end are zeros by predicate (the pair never straddles n: n is even)
+            return (cok && 8 * t + 2 * q < n) ? *(const d2v *)(bp + 8 * t) : d2v{0.0, 0.0};
+        };
+        d2v ring[TRW_D];
+#pragma unroll
+        for (int u = 0; u < TRW_D; u++) ring[u] = u < nts ? loadb(u) : d2v{0.0, 0.0};
+        d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        for (int t0 = 0; t0 < nts; t0 += TRW_D) {
+#pragma unroll
+            for (int u = 0; u < TRW_D; u++) {
+                const int t = t0 + u;
+                if (t < nts) {
+                    const d2v b = ring[u];
+                    if (t + TRW_D < nts) ring[u] = loadb(t + TRW_D);
+                    const d2v a0 = *(const d2v *)(a0p + 8 * t), a1 = *(const d2v *)(a1p + 8 * t);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.y, acc1, 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) { sq[0][r] += acc0[r] * acc0[r]; sq[1][r] += acc1[r] * acc1[r]; }
+    };
+    // first the tiles that need the first two column chunks only (the short one of every pair, j <= 15) ...
+    const bool early = nchunk > 2;
+    auto is_early = [&](int j) { return early && 16 * (j + 1) <= 256; };
+    for (int pr = wave; pr < npair; pr += TRW_NW)
+        if (is_early(pr)) tile(pr);
+    // ... then, once the whole block is there (every wavefront passes here exactly once), all the others
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int pr = wave; pr < npair; pr += TRW_NW) {
+        if (!is_early(pr)) tile(pr);
+        const int j2 = ntile - 1 - pr;
+        if (j2 != pr) tile(j2);                                      // odd number of tiles: the middle one stands alone
+    }
+    // ---- P w and |p|^2: 32 lanes per row (after the products: the wavefronts that finish their tiles early do it while
+    // the others still multiply)
     {
         const int row = tid >> 5, l32 = tid & 31;
         double mean = 0.0, nrm = 0.0;
@@ -780,46 +852,6 @@ __global__ void __launch_bounds__(64 * TRW_NW) ws_tail_rows_kernel(int m, int n,
         for (int k = l32; k < n; k += 32) { const double v = ar[k]; mean += v * sW[k]; nrm += v * v; }
         for (int o = 16; o > 0; o >>= 1) { mean += __shfl_xor(mean, o, 64); nrm += __shfl_xor(nrm, o, 64); }
         if (l32 == 0) { sMN[row] = mean; sMN[TRW_ROWS + row] = nrm; }
-    }
-    // ---- column tiles
-    const int c = lane & 15, q = lane >> 4;
-    const int ntile = (n + 15) / 16, npair = (ntile + 1) / 2, ntmax = (n + 7) / 8;
-    double sq[2][4] = {{0.0, 0.0, 0.0, 0.0}, {0.0, 0.0, 0.0, 0.0}};
-    const double *a0p = sA + (size_t)c * n + 2 * q, *a1p = sA + (size_t)(16 + c) * n + 2 * q;
-    for (int pr = wave; pr < npair; pr += TRW_NW) {
-        for (int half = 0; half < 2; half++) {
-            const int j = half == 0 ? pr : ntile - 1 - pr;
-            if (half == 1 && j == pr) break;                         // odd number of tiles: the middle one stands alone
-            const int col = 16 * j + c;
-            const int nts = min(2 * (j + 1), ntmax);                 // steps of 8 columns: k < 16 (j + 1)
-            const bool cok = col < n;
-            const double *bp = Ci + (long long)min(col, n - 1) * ldc + 2 * q;
-            auto loadb = [&](int t) -> d2v {
-                // columns beyond the row's end are zeros by predicate (the pair never straddles n: n is even)
-                return (cok && 8 * t + 2 * q < n) ? *(const d2v *)(bp + 8 * t) : d2v{0.0, 0.0};
-            };
-            d2v ring[TRW_D];
-#pragma unroll
-            for (int u = 0; u < TRW_D; u++) ring[u] = u < nts ? loadb(u) : d2v{0.0, 0.0};
-            d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-            for (int t0 = 0; t0 < nts; t0 += TRW_D) {
-#pragma unroll
-                for (int u = 0; u < TRW_D; u++) {
-                    const int t = t0 + u;
-                    if (t < nts) {
-                        const d2v b = ring[u];
-                        if (t + TRW_D < nts) ring[u] = loadb(t + TRW_D);
-                        const d2v a0 = *(const d2v *)(a0p + 8 * t), a1 = *(const d2v *)(a1p + 8 * t);
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.y, acc0, 0, 0, 0);
-                        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.y, acc1, 0, 0, 0);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; r++) { sq[0][r] += acc0[r] * acc0[r]; sq[1][r] += acc1[r] * acc1[r]; }
-        }
     }
     // rows of sq: the 16 lanes of a q group hold 16 columns of rows 16 i + q + 4 r
 #pragma unroll
@@ -1356,7 +1388,12 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         attr_set = true;
     }
     const int nrb = (m + R - 1) / R, ncb = (n + WT_C - 1) / WT_C;
-    if (nrb * 2 <= 128 && ncb > 1) {
+    // The row-resident kernel needs no exchange between workgroups, so it also serves a handful of rows (one structure:
+    // four workgroups) whenever the shape allows it; the split form below stays for the other shapes.
+    const bool rows_ok = ncb >= 2 && n % 2 == 0 && n <= TRW_NMAX && ldp == n && ldc % 2 == 0 && ((uintptr_t)P & 15) == 0 &&
+                         ((uintptr_t)Cinv & 15) == 0;
+    static const bool want_few = getenv("GPR_TAIL_FEW") != nullptr;        // A/B: the split form for few rows even so
+    if (nrb * 2 <= 128 && ncb > 1 && (!rows_ok || want_few)) {
         // few rows (a single structure): one workgroup per (column block, row block) and a last-arriver reduction
         void *wsp;
         const size_t ws_bytes = (size_t)(ncb + 2) * m * sizeof(double) + (size_t)nrb * sizeof(int);
@@ -1376,8 +1413,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         return status_only();
     }
     static const int tail_form = getenv("GPR_TAIL_FORM") ? atoi(getenv("GPR_TAIL_FORM")) : 0;   // 1: paired blocks (LDS DMA), 2: register-staged
-    if (ncb >= 2 && tail_form == 0 && n % 2 == 0 && n <= TRW_NMAX && ldp == n && ldc % 2 == 0 && ((uintptr_t)P & 15) == 0 &&
-        ((uintptr_t)Cinv & 15) == 0) {
+    if (rows_ok && (tail_form == 0 || nrb * 2 <= 128)) {
         // many rows, row-resident form: one launch, P read once, no barrier in the product loop
         const size_t lds = trw_lds_doubles(n) * sizeof(double);
         static bool attr3 = false;

@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <thread>
+#include <unordered_map>
 #include "gpr_internal.h"
 
 struct nbr_sinfo { int atom0, n, img0, nimg, zero_img, pad; };
@@ -399,7 +401,7 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 //   geometry of the structure from the page-locked blob into LDS (and on to the device copy later kernels read),
 //   count per centre (one wavefront per centre, the loops of nbr_centre_kernel), exclusive scan inside the workgroup,
 //   the structure's offsets among all structures by LOOKING BACK: every workgroup publishes its totals (tagged with the
-//   call's epoch, so that nobody has to clear the slots) right after its count, and sums the totals of its predecessors
+//   call's epoch, so that nobody has to clear the slots -- which are memory of their own and never hold anything else) right after its count, and sums the totals of its predecessors
 //   and of everybody else (the grand totals decide, identically everywhere, whether the guessed capacities hold); all
 //   workgroups reach that point at about the same time, the wait is bounded, and giving up fails loudly,
 //   fill (pairs ordered by (j, image), rows by j: bit-identical to the other builders), and -- the neighbour relation
@@ -801,7 +803,25 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         if (ep == 0) ep = g_nbr_epoch.fetch_add(1);
         fa.epoch = ep;
         fa.cr0 = nb->d_off; fa.cp0 = nb->d_off + natoms + 1; fa.info = nb->d_err;
-        fa.agg = (unsigned long long *)(((uintptr_t)(nb->d_err + 4) + 7) & ~(uintptr_t)7);
+        // The look-back slots are tagged with the call's epoch instead of being cleared, so they must never hold anything
+        // but earlier calls' tags: memory of their own, one small array per stream (launches of a stream are ordered),
+        // zeroed once.  (They used to sit in the call's recycled temporaries, where an old row count in the upper half of
+        // a word could equal a small epoch: a stale total was then taken for a published one.)
+        {
+            static std::mutex mu;
+            static std::unordered_map<hipStream_t, unsigned long long *> slots;
+            std::lock_guard<std::mutex> lk(mu);
+            unsigned long long *&ag = slots[st];
+            if (!ag) {
+                if (hipMalloc((void **)&ag, 3 * NBRF_MAX_STRUCT * sizeof(unsigned long long)) != hipSuccess ||
+                    hipMemset(ag, 0, 3 * NBRF_MAX_STRUCT * sizeof(unsigned long long)) != hipSuccess) {
+                    ag = nullptr;
+                    gpr_set_error("gpr_nbr_build_device: cannot allocate the look-back slots");
+                    return fail(GPR_ERR_HIP);
+                }
+            }
+            fa.agg = ag;
+        }
         fa.vec = nb->d_vec; fa.w = nb->d_w; fa.rp0 = nb->d_rp0; fa.self_row = nb->d_self; fa.seq = nb->d_seq;
         fa.row_index = row_index_dev; fa.x_index = row_index_dev ? x_index_dev : nullptr;
         for (int s = 0; s < nstruct; s++) fa.si[s] = sinfo[s];

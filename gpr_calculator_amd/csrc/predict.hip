@@ -5,6 +5,7 @@
 // the single synchronisation is the size download inside gpr_nbr_build_device, and none with guessed capacities.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include "gpr_internal.h"
 
 // set by the session call around gpr_predict_dot2_batch: the tail kernel then writes standard deviations (the session
@@ -318,6 +319,19 @@ extern "C" int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E,
             if ((spin & 0xfffff) == 0xfffff && hipStreamQuery(sl.st) == hipSuccess) break;
         }
         if (!seen) GPR_HIP_TRY(hipStreamSynchronize(sl.st));
+        {
+            // The status words tell that the last kernel has ISSUED all its stores; that they have all LANDED in host memory
+            // is something only the queue's own completion signal vouches for (writes of different XCDs reach the host on
+            // different paths: a late result row behind the status words was seen once in a few hundred calls).  The words
+            // end the long wait cheaply; the short rest is a busy query of the slot's stream -- no sleep, unlike a blocking
+            // synchronisation.
+            static const bool trust_words = getenv("GPR_SESSION_TRUST_WORDS") != nullptr;
+            if (seen && !trust_words) {
+                hipError_t q;
+                while ((q = hipStreamQuery(sl.st)) == hipErrorNotReady) {}
+                if (q != hipSuccess) { gpr_set_error("gpr_dot2_session_wait: %s", hipGetErrorString(q)); return GPR_ERR_HIP; }
+            }
+        }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);
         if (tail[1] == 0.0) break;                       // no overflow
         GPR_REQUIRE(attempt == 0, "gpr_dot2_session_wait: neighbour table overflow with exact sizes");
@@ -329,7 +343,8 @@ extern "C" int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E,
         s->pairs_per_atom = std::max(s->pairs_per_atom, tail[2] / natoms);
         s->rows_per_atom = std::max(s->rows_per_atom, tail[3] / natoms);
     }
-    GPR_REQUIRE(tail[0] == 0.0, "neighbour table is not symmetric: %d force rows missing", (int)tail[0]);
+    GPR_REQUIRE(tail[0] == 0.0, "neighbour table is not symmetric: %d force rows missing (%d structures, %d atoms, %s, pairs %d, rows %d, slot %d)",
+                (int)tail[0], nstruct, natoms, sl.masked ? "fixed atoms" : "all atoms moving", (int)tail[2], (int)tail[3], ticket);
     // unpack [mean | var]: energies per atom -> total energies, force rows -> [natoms, 3] with zeros at fixed atoms
     const double *mean = sl.pin, *var = sl.pin + m;
     const int *atom0 = sl.atom0;

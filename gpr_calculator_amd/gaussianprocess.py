@@ -1098,8 +1098,7 @@ class GP():
                 float(self.kernel.sigma), float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std)),
                 caps[0], caps[1], dev.ptr(out), int(out.numel())), "gpr_predict_dot2_batch")
             # the status words are written by the last kernel of the call: poll them in host memory (a blocking stream
-            # synchronisation sleeps and wakes tens of microseconds late); everything queued before that kernel has
-            # completed, in stream order, when they appear
+            # synchronisation sleeps and wakes tens of microseconds late), then confirm with a busy query of the stream
             if tr is not None:
                 tr.append(("native:queued", time.perf_counter_ns()))
             polled = self._poll_results
@@ -1117,6 +1116,13 @@ class GP():
                         break
             if not polled:
                 torch.cuda.current_stream().synchronize()
+            else:
+                # the words say that the last kernel has issued all its stores; that every result row has LANDED in host
+                # memory is what the queue's completion vouches for (seen once in a few hundred calls: a row behind the
+                # words).  A busy query, no sleep.
+                stream = torch.cuda.current_stream()
+                while not stream.query():
+                    pass
             if tr is not None:
                 tr.append(("native:results", time.perf_counter_ns()))
             host = view.copy()                        # the pinned buffer is reused by the next call
