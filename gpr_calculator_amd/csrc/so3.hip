@@ -82,7 +82,10 @@ __device__ void sph_in_table(double x, int lt, double *b) {
 //   CG   [L][M][6]           the six coefficients of grad Y_l^m (SO3.py:682-707)
 //   NL   [L]                 norm_l = sqrt(2 sqrt2 pi / sqrt(2l+1)) (SO3.py:206)
 //   RI   [(lmax+3)^2]        1 / (l - m) for l > m (Legendre recurrence without divisions)
-struct so3_tab { int NF, oNY, oCG, oNL, oRI, total; };
+//   GT   [(L^2+L) 3][22]     the linear map c_tot -> gradient tables T of one n (SO3.py:682-707 folded): per compact T entry
+//                            [l, nterm, 4 x (source m, p, q, r, s)]:  T.re += p c.re + q c.im,  T.im += r c.re + s c.im
+struct so3_tab { int NF, oNY, oCG, oNL, oRI, oGT, total; };
+constexpr int SO3_GT_W = 22;
 __host__ __device__ inline so3_tab so3_table_layout(int nmax, int lmax, int nseg, int ncheb) {
     const int L = lmax + 1, M = 2 * lmax + 1, YW = lmax + 3;
     so3_tab t;
@@ -92,6 +95,7 @@ __host__ __device__ inline so3_tab so3_table_layout(int nmax, int lmax, int nseg
     t.oCG = off; off += L * M * 6;
     t.oNL = off; off += L;
     t.oRI = off; off += YW * YW;
+    t.oGT = off; off += (L * L + L) * 3 * SO3_GT_W;
     t.total = off;
     return t;
 }
@@ -182,6 +186,68 @@ __global__ void so3_const_tables_kernel(int lmax, double *NY, double *CG, double
         for (int k = 0; k < 6; k++) CG[e * 6 + k] = c[k];
     }
     for (int e = tid; e < L; e += blockDim.x) NL[e] = sqrt(2.0 * sqrt(2.0) * M_PI / sqrt(2.0 * e + 1.0));
+}
+
+// One entry of the per-centre gradient tables: the coefficient of Y_{l', mp} (l' = l -/+ 1 for side 0 / 1, mp >= 0, the
+// m' < 0 half folded on) in  sum_m (grad Y_lm)_k conj(ctot_nlm)  -- SO3.py:682-707.  ctv(m): c_tot[n, l, m] (zero beyond
+// |m| <= l), cgv(m, which): the six coupling coefficients of (l, m).
+template <class CT, class CG>
+__device__ __forceinline__ cplx so3_T_entry(int l, int side, int k, int mp, CT ctv, CG cgv) {
+    auto Tval = [&](int m1) -> cplx {                          // coefficient of Y_{lp, m1}, any sign of m1
+        const double is2 = 0.70710678118654752440;
+        if (k == 2) return cscale(ctv(m1), cgv(m1, side ? 0 : 1));
+        const cplx up = cscale(ctv(m1 + 1), cgv(m1 + 1, side ? 4 : 5) * is2);      // from gm of (l, m1+1)
+        const cplx dn = cscale(ctv(m1 - 1), cgv(m1 - 1, side ? 2 : 3) * is2);      // from gp of (l, m1-1)
+        if (k == 0) return {up.re - dn.re, up.im - dn.im};
+        const cplx sm = {up.re + dn.re, up.im + dn.im};
+        return {sm.im, -sm.re};                                // -i (up + dn)
+    };
+    cplx out = Tval(mp);
+    if (mp > 0) {
+        const cplx t2 = Tval(-mp);
+        const double sg = (mp & 1) ? -1.0 : 1.0;
+        out.re += sg * t2.re; out.im -= sg * t2.im;
+    }
+    return out;
+}
+
+// compact index inside one n-block of the T tables -> (l, k, side, mp); false for the unused l = 0 entries
+__host__ __device__ inline bool so3_tf_decode(int idx, int L, int &l, int &k, int &side, int &mp) {
+    l = 0;
+    while (l + 1 < L && 3 * (l + 1) * (l + 2) <= idx) l++;
+    const int rem = idx - 3 * l * (l + 1), w = 2 * l + 2;
+    k = rem / w;
+    const int r2 = rem - k * w;
+    side = r2 >= l ? 1 : 0;
+    mp = side ? r2 - l : r2;
+    return l >= 1;
+}
+
+// The map c_tot -> T is real-linear and the same for every n and every centre: it is extracted ONCE per descriptor
+// configuration by probing so3_T_entry with unit inputs (c = 1 and c = i at every source m), so that the descriptor kernel
+// evaluates each table entry as at most four 2 x 2 real products instead of walking the case analysis per entry.
+__global__ void so3_grad_map_kernel(int lmax, const double *CG, double *GT) {
+    const int L = lmax + 1, M = 2 * lmax + 1, NB = (L * L + L) * 3;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= NB) return;
+    double *g = GT + (size_t)idx * SO3_GT_W;
+    int l, k, side, mp;
+    const bool used = so3_tf_decode(idx, L, l, k, side, mp);
+    int nterm = 0;
+    for (int t = 0; t < 4; t++) { g[2 + 5 * t] = 0.0; g[3 + 5 * t] = 0.0; g[4 + 5 * t] = 0.0; g[5 + 5 * t] = 0.0; g[6 + 5 * t] = 0.0; }
+    if (used) {
+        auto cgv = [&](int m, int which) -> double { return (m >= -l && m <= l) ? CG[(l * M + (m + lmax)) * 6 + which] : 0.0; };
+        for (int ms = -l; ms <= l; ms++) {
+            const cplx a = so3_T_entry(l, side, k, mp, [&](int m) -> cplx { return m == ms ? cplx{1.0, 0.0} : cplx{0.0, 0.0}; }, cgv);
+            const cplx b = so3_T_entry(l, side, k, mp, [&](int m) -> cplx { return m == ms ? cplx{0.0, 1.0} : cplx{0.0, 0.0}; }, cgv);
+            if (a.re != 0.0 || a.im != 0.0 || b.re != 0.0 || b.im != 0.0) {
+                if (nterm < 4) { double *t = g + 2 + 5 * nterm; t[0] = (double)ms; t[1] = a.re; t[2] = b.re; t[3] = a.im; t[4] = b.im; }
+                nterm++;
+            }
+        }
+    }
+    g[0] = (double)l;
+    g[1] = (double)nterm;                                      // > 4 would not fit: the descriptor kernel then takes the formula itself
 }
 
 // Clenshaw evaluation of function f of the piecewise Chebyshev table at radius r
@@ -458,33 +524,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
     // ---- gradient coefficients contracted with c_tot (SO3.py:682-707 folded into per-centre tables):
     //      S_nlk(pair) = (1/r) sum_{side} sum_{m' >= 0} Re[Y_{l', m'} conj(Tf[nl][k][side][m'])], l' = l -/+ 1
     {
-        const int W = LT + 1, ntf = NL * 3 * 2 * W;
+        const int NB = (L * L + L) * 3, ntf = (P.dbg == 5) ? 0 : P.nmax * NB;      // dbg 5: timing without the tables (wrong numbers)
+        const double *GT = P.table + tab.oGT;
         for (int e = tid; e < ntf; e += 256) {
-            const int mp = e % W, side = (e / W) % 2, k = (e / (2 * W)) % 3, nl = e / (6 * W), l = nl % L;
-            const int lp = side ? l + 1 : l - 1;
+            const int n = e / NB, idx = e - n * NB;
+            const double *g = GT + (size_t)idx * SO3_GT_W;
+            const int l = (int)g[0], nterm = (int)g[1];
+            if (l < 1) continue;                                  // the l = 0 slots of the compact layout are never read
+            const int nl = n * L + l;
             cplx out = {0.0, 0.0};
-            if (lp >= 0 && mp <= lp && l >= 1) {
-                auto ctv = [&](int m) -> cplx { return (m >= -l && m <= l) ? ctot[nl * M + P.lmax + m] : cplx{0.0, 0.0}; };
-                auto cgv = [&](int m, int which) -> double {
-                    return (m >= -l && m <= l) ? sCG[(l * M + (m + P.lmax)) * 6 + which] : 0.0;
-                };
-                auto Tval = [&](int m1) -> cplx {                      // coefficient of Y_{lp, m1}, any sign of m1
-                    const double is2 = 0.70710678118654752440;
-                    if (k == 2) return cscale(ctv(m1), cgv(m1, side ? 0 : 1));
-                    const cplx up = cscale(ctv(m1 + 1), cgv(m1 + 1, side ? 4 : 5) * is2);      // from gm of (l, m1+1)
-                    const cplx dn = cscale(ctv(m1 - 1), cgv(m1 - 1, side ? 2 : 3) * is2);      // from gp of (l, m1-1)
-                    if (k == 0) return {up.re - dn.re, up.im - dn.im};
-                    const cplx sm = {up.re + dn.re, up.im + dn.im};
-                    return {sm.im, -sm.re};                                // -i (up + dn)
-                };
-                out = Tval(mp);
-                if (mp > 0) {
-                    const cplx t2 = Tval(-mp);
-                    const double sg = (mp & 1) ? -1.0 : 1.0;
-                    out.re += sg * t2.re; out.im -= sg * t2.im;
-                }
+            if (nterm <= 4) {
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nterm) {
+                        const double *q = g + 2 + 5 * t;
+                        const cplx c = ctot[nl * M + P.lmax + (int)q[0]];
+                        out.re += q[1] * c.re + q[2] * c.im;
+                        out.im += q[3] * c.re + q[4] * c.im;
+                    }
+            } else {
+                int l2, k, side, mp;
+                so3_tf_decode(idx, L, l2, k, side, mp);
+                out = so3_T_entry(l, side, k, mp,
+                                  [&](int m) -> cplx { return (m >= -l && m <= l) ? ctot[nl * M + P.lmax + m] : cplx{0.0, 0.0}; },
+                                  [&](int m, int which) -> double { return (m >= -l && m <= l) ? sCG[(l * M + (m + P.lmax)) * 6 + which] : 0.0; });
             }
-            if (lp >= 0 && mp <= lp && l >= 1) sTf[so3_tf_base(nl / L, l, L) + k * (2 * l + 2) + (side ? l : 0) + mp] = out;
+            sTf[n * NB + idx] = out;
         }
     }
     __syncthreads();
@@ -785,6 +850,10 @@ extern "C" int gpr_so3_tables(void *stream, int nmax, int lmax, double rcut, dou
     hipLaunchKernelGGL(so3_radial_direct_kernel, dim3(nr), dim3(64), 0, st, nmax, lmax, alpha, nq, G, rq, nr, rs, vals);
     hipLaunchKernelGGL(so3_cheb_coef_kernel, dim3((nr * tab.NF + 255) / 256), dim3(256), 0, st, nseg, ncheb, tab.NF, vals, table);
     hipLaunchKernelGGL(so3_const_tables_kernel, dim3(1), dim3(256), 0, st, lmax, table + tab.oNY, table + tab.oCG, table + tab.oNL, table + tab.oRI);
+    {
+        const int NB = ((lmax + 1) * (lmax + 1) + lmax + 1) * 3;
+        hipLaunchKernelGGL(so3_grad_map_kernel, dim3((NB + 63) / 64), dim3(64), 0, st, lmax, (const double *)(table + tab.oCG), table + tab.oGT);
+    }
     hipError_t e = hipGetLastError();
     gpr_dev_free(p, st);
     if (e != hipSuccess) { gpr_set_error("gpr_so3_tables: launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
