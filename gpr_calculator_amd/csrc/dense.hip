@@ -4,8 +4,10 @@
 // gaussianprocess.py:128-131, 288-299, 880, 903-907.  Row-major storage throughout.
 #include <cstdlib>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <unordered_map>
+#include <utility>
 #include "gpr_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -395,6 +397,7 @@ __global__ void __launch_bounds__(256) ws_finish_kernel(int m, int n, const doub
 #ifndef WT_ROWS
 #define WT_ROWS 32
 #endif
+constexpr int WT_FEW_MAX_RB = 64;                        // row blocks of the few-rows form (its per-stream arrival counters)
 constexpr int WT_C = 128, WT_K = 32, WT_LD = WT_K + 2;   // row stride 34: operand reads of a half-wave hit 32 distinct bank pairs
 template <int WT_R, int NW = 4> constexpr size_t wt_lds_bytes() { return (size_t)(2 * (WT_R + WT_C) * WT_LD + NW * WT_R) * sizeof(double); }
 
@@ -412,7 +415,8 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
                                                        const double *__restrict__ Ci, long long ldc,
                                                        const double *__restrict__ w, const double *__restrict__ diag,
                                                        double *__restrict__ out, double vsq, double *__restrict__ part,
-                                                       double *__restrict__ mn, int *__restrict__ cnt, int std_out) {
+                                                       double *__restrict__ mn, int *__restrict__ cnt, int std_out,
+                                                       const int *status_src, double *status_dst) {
     constexpr int RT = WT_R / 16, AI = WT_R / (2 * NW);          // 16-row MFMA tiles, A loads per thread and tile
     constexpr int NC = WT_C / (16 * NW), BI = WT_C / (2 * NW), LR = 2 * NW;   // column tiles per wavefront, B loads per thread and tile, rows per load pass
     __shared__ int s_last;
@@ -571,13 +575,29 @@ __global__ void __launch_bounds__(64 * NW) ws_tail_kernel(int m, int n, const do
     if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ncb - 1;
     __syncthreads();
     if (!s_last) return;
+    // the counters belong to the stream (launches of a stream are ordered): the last arriver leaves them at zero
+    if (tid == 0) __hip_atomic_store(&cnt[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (tid < WT_R && bm0 + tid < m) {
         const int row = bm0 + tid;
         double q2 = 0.0;
         for (int x = 0; x < ncb; x++) q2 += __hip_atomic_load(&part[(size_t)x * m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        out[row] = __hip_atomic_load(&mn[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        { const double v = fmax(diag[row] - vsq * (__hip_atomic_load(&mn[(size_t)m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q2), 0.0); out[m + row] = std_out ? sqrt(v) : v; }
+        const double mu = __hip_atomic_load(&mn[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double v = fmax(diag[row] - vsq * (__hip_atomic_load(&mn[(size_t)m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - q2), 0.0);
+        const double sd = std_out ? sqrt(v) : v;
+        if (status_dst) {                                        // a host may be polling for these (page-locked memory)
+            __hip_atomic_store(&out[row], mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out[m + row], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else { out[row] = mu; out[m + row] = sd; }
     }
+    if (!status_dst) return;
+    // status words by the row block whose results go out last (as in ws_tail_rows_kernel): own stores acknowledged, then
+    // counted in; cnt[WT_FEW_MAX_RB] is that second counter
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[WT_FEW_MAX_RB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (s_last && tid < 4) __hip_atomic_store(&status_dst[tid], (double)status_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (s_last && tid == 0) __hip_atomic_store(&cnt[WT_FEW_MAX_RB], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- the many-row form again, with the tiles brought into LDS by the DMA path (global_load_lds_dwordx4) instead of
@@ -1367,6 +1387,27 @@ extern "C" int gpr_ws_tail_status(void *stream, int m, int n, const double *P, l
 }
 
 // std_out: the second half of `out` holds standard deviations (square roots of the clamped variances) instead of variances
+// Arrival counters of the tail kernels: a block per (device, stream) -- launches of a stream are ordered and the last
+// arriver leaves a counter at zero, so two predictions in flight (two streams) never share one and no launch has to
+// clear them.  [0, WT_FEW_MAX_RB): row blocks of the few-rows form, [WT_FEW_MAX_RB]: its status delivery,
+// [WT_FEW_MAX_RB + 1]: status delivery of the row-resident form.
+static int *tail_stream_counters(hipStream_t st) {
+    static std::mutex mu;
+    static std::map<std::pair<int, hipStream_t>, int *> counters;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { gpr_set_error("gpr_ws_tail: hipGetDevice failed"); return nullptr; }
+    std::lock_guard<std::mutex> lk(mu);
+    int *&slot = counters[{dev, st}];
+    if (!slot) {
+        const size_t bytes = (WT_FEW_MAX_RB + 2) * sizeof(int);
+        if (hipMalloc((void **)&slot, bytes) != hipSuccess || hipMemset(slot, 0, bytes) != hipSuccess) {
+            gpr_set_error("gpr_ws_tail: arrival counters could not be allocated");
+            slot = nullptr;
+        }
+    }
+    return slot;
+}
+
 int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long ldp, const double *Cinv, long long ldc,
                          const double *w, const double *diag, double *out, double vsq, const int *status_src,
                          double *status_dst, int std_out) {
@@ -1392,28 +1433,30 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
     // four workgroups) whenever the shape allows it; the split form below stays for the other shapes.
     const bool rows_ok = ncb >= 2 && n % 2 == 0 && n <= TRW_NMAX && ldp == n && ldc % 2 == 0 && ((uintptr_t)P & 15) == 0 &&
                          ((uintptr_t)Cinv & 15) == 0;
-    static const bool want_few = getenv("GPR_TAIL_FEW") != nullptr;        // A/B: the split form for few rows even so
-    if (nrb * 2 <= 128 && ncb > 1 && (!rows_ok || want_few)) {
-        // few rows (a single structure): one workgroup per (column block, row block) and a last-arriver reduction
+    // few rows (one structure: m = 97): the split form spreads a row block's column blocks over workgroups (33 us against 43
+    // for four row-resident workgroups); GPR_TAIL_NO_FEW sends them through the row-resident kernel as well
+    static const bool no_few = getenv("GPR_TAIL_NO_FEW") != nullptr;
+    if (nrb <= WT_FEW_MAX_RB && ncb > 1 && (!rows_ok || !no_few)) {
+        // few rows (a single structure): one workgroup per (column block, row block) and a last-arriver reduction; one
+        // launch -- arrival counters that belong to the stream, status words by the last row block
+        int *cnt = tail_stream_counters(st);
+        if (!cnt) return GPR_ERR_HIP;
         void *wsp;
-        const size_t ws_bytes = (size_t)(ncb + 2) * m * sizeof(double) + (size_t)nrb * sizeof(int);
+        const size_t ws_bytes = (size_t)(ncb + 2) * m * sizeof(double);
         int rc = gpr_dev_alloc(&wsp, ws_bytes, st);
         if (rc) return rc;
         double *part = (double *)wsp, *mn = part + (size_t)ncb * m;
-        int *cnt = (int *)(mn + 2 * (size_t)m);
-        const hipError_t me = hipMemsetAsync(cnt, 0, (size_t)nrb * sizeof(int), st);
-        if (me != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: memset failed: %s", hipGetErrorString(me)); return GPR_ERR_HIP; }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, cnt, std_out);
+                           out, vsq, part, mn, cnt, std_out, status_src, status_dst);
         gpr_prof_end(st, pid);
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
         if (le != hipSuccess) { gpr_set_error("ws_tail launch failed: %s", hipGetErrorString(le)); return GPR_ERR_HIP; }
-        return status_only();
+        return GPR_OK;
     }
     static const int tail_form = getenv("GPR_TAIL_FORM") ? atoi(getenv("GPR_TAIL_FORM")) : 0;   // 1: paired blocks (LDS DMA), 2: register-staged
-    if (rows_ok && (tail_form == 0 || nrb * 2 <= 128)) {
+    if (rows_ok && tail_form == 0) {
         // many rows, row-resident form: one launch, P read once, no barrier in the product loop
         const size_t lds = trw_lds_doubles(n) * sizeof(double);
         static bool attr3 = false;
@@ -1424,17 +1467,9 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         }
         int *done = nullptr;
         if (status_dst) {
-            // arrival counter of the status delivery: one per stream (launches of a stream are ordered; the last arriver
-            // leaves it at zero), never shared by two predictions in flight
-            static std::mutex mu;
-            static std::unordered_map<hipStream_t, int *> counters;
-            std::lock_guard<std::mutex> lk(mu);
-            int *&slot = counters[st];
-            if (!slot) {
-                GPR_HIP_TRY(hipMalloc((void **)&slot, sizeof(int)));
-                GPR_HIP_TRY(hipMemset(slot, 0, sizeof(int)));
-            }
-            done = slot;
+            done = tail_stream_counters(st);
+            if (!done) return GPR_ERR_HIP;
+            done += WT_FEW_MAX_RB + 1;
         }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
         hipLaunchKernelGGL(ws_tail_rows_kernel, dim3((m + TRW_ROWS - 1) / TRW_ROWS), dim3(64 * TRW_NW), lds, st, m, n, P, Cinv, ldc, w,
@@ -1472,7 +1507,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
                                part, mn, done, tail_dbg);
         else
             hipLaunchKernelGGL((ws_tail_kernel<R2, 2, NW2>), dim3(npart, nrb2), dim3(64 * NW2), lds2, st, m, n, P, ldp, Cinv, ldc, w, diag,
-                               out, vsq, part, mn, done, std_out);
+                               out, vsq, part, mn, done, std_out, (const int *)nullptr, (double *)nullptr);
         hipLaunchKernelGGL(ws_tail_combine_kernel, dim3((m + 255) / 256), dim3(256), 0, st, m, npart, (const double *)part,
                            (const double *)mn, diag, out, vsq, status_src, status_dst, done, std_out);
         gpr_prof_end(st, pid2);
@@ -1483,7 +1518,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
     hipLaunchKernelGGL((ws_tail_kernel<R, 0>), dim3(nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag, out, vsq,
-                       (double *)nullptr, (double *)nullptr, (int *)nullptr, std_out);
+                       (double *)nullptr, (double *)nullptr, (int *)nullptr, std_out, (const int *)nullptr, (double *)nullptr);
     gpr_prof_end(st, pid);
     LAUNCH_CHECK("ws_tail");
     return status_only();

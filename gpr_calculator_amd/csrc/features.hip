@@ -249,9 +249,13 @@ __device__ __forceinline__ void fm_lds_sync() {
 // factors only (a~_eps = s a~, A'_eps = s (D/n - s^2 a~ proj), s = n / (n + 1e-8)).  The accumulators hold S = M + M^T
 // directly -- S_ab += A~_a^T A'_b + A'_a^T A~_b: an LDS operand tile serves as the A or the B operand of the MFMA alike
 // -- so a component needs three tiles (S_00, S_01, S_11) instead of the four of M, and both sets fit the register file.
-template <bool P0, bool P1>
+//
+// SPLIT: the four wavefronts of the workgroup share ONE point (each takes a quarter of its rows, [r0, r1) is that
+// quarter) and their partial S tiles are summed on the way out -- the form for a handful of points (one structure: 32
+// force points), where the time of the launch is the time of one point's chain and the chip is empty anyway.
+template <bool P0, bool P1, bool SPLIT>
 __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int si, int zs, int r0, int r1, double *sm,
-                                                 const int *km, double (&dacc)[3]) {
+                                                 const double *sm_all, const int *km, double (&dacc)[3]) {
     const int lane = threadIdx.x & 63;
     const int slot = lane >> 4, g = lane & 15;
     double *opA0 = sm, *opB0 = sm + 4 * FM_LD, *opA1 = sm + 16 * FM_LD, *opB1 = sm + 20 * FM_LD;   // op?[row][k], opB?[q][row][k]
@@ -377,68 +381,91 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
                 for (int r = 0; r < 4; r++)
                     sm[(ra + (lane >> 4) + 4 * r) * FM_LD + cbq + (lane & 15)] = (pass == 0) ? acc0[q][t][r] : acc1[q][t][r];
             }
-            fm_lds_sync();
+            if (SPLIT) __syncthreads(); else fm_lds_sync();
             double part = 0.0;
+            const int t0 = (int)(threadIdx.x >> 6);                                  // SPLIT: the wavefronts share the entries
 #pragma unroll
-            for (int t = 0; t < 9; t++) {
+            for (int tt = 0; tt < 9; tt++) {
+                if (SPLIT && (tt & 3) != t0) continue;
+                const int t = tt;
                 const int kmt = km[64 * t + lane];
                 if (kmt >= 0) {
                     const int k = kmt >> 8, m = kmt & 255, e = lane + 64 * t;         // m <= k
-                    const double sv = (k >= 16 && m < 16) ? sm[m * FM_LD + k] : sm[k * FM_LD + m];
+                    const int at = (k >= 16 && m < 16) ? m * FM_LD + k : k * FM_LD + m;
+                    double sv;
+                    if (SPLIT) sv = (sm_all[at] + sm_all[32 * FM_LD + at]) + (sm_all[2 * 32 * FM_LD + at] + sm_all[3 * 32 * FM_LD + at]);
+                    else sv = sm[at];
                     if (pass == 0) A.out[(long long)(p * 3 + q) * A.ld + si * A.npair + e] = -((k == m) ? sv : 1.4142135623730951 * sv);
                     else part += (k == m) ? sv * sv : 2.0 * sv * sv;
                 }
             }
             if (pass == 1) dacc[q] += part;
-            fm_lds_sync();
+            if (SPLIT) __syncthreads(); else fm_lds_sync();
         }
     }
 }
 
+template <bool SPLIT>
 __device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &A, int blk, double (*smem)[32 * FM_LD], int (*skm)[9 * 64]) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int p = blk * 4 + wave;
-    if (p >= A.npts) return;                                    // wavefront-uniform; no block barriers below
+    const int p = SPLIT ? blk : blk * 4 + wave;
+    if (p >= A.npts) return;                                    // wavefront-uniform (SPLIT: workgroup-uniform, never taken)
     double *sm = smem[wave];
-    const int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
+    int r0 = A.pt_row0[p], r1 = A.pt_row0[p + 1];
+    if (SPLIT) {                                                // this wavefront's quarter of the rows, whole steps of four
+        const int per = ((r1 - r0 + 15) >> 4) << 2;
+        r0 = min(r1, r0 + wave * per);
+        r1 = min(r1, r0 + per);
+    }
     double dacc[3] = {0.0, 0.0, 0.0};                           // sum over species and (k, m) of (M_km + M_mk)^2, eps operands
     // this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once (kept in LDS: nine registers
     // decide between one and two wavefronts per SIMD)
     int *km = skm[wave];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
+        if (SPLIT && (t & 3) != wave) continue;                 // only the entries this wavefront writes out
         const int e = lane + 64 * t;
         int k = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((k + 1) * (k + 2) / 2 <= e) k++;
         while (k * (k + 1) / 2 > e) k--;
         km[64 * t + lane] = (e < A.npair) ? ((k << 8) | (e - k * (k + 1) / 2)) : -1;
     }
-    for (int q = 0; q < 3; q++) {                               // the constant column of force rows is zero
-        double *o = A.out + (long long)(p * 3 + q) * A.ld;
-        if (lane < A.ns) o[A.ns * A.npair + lane] = 0.0;
-    }
+    if (!SPLIT || wave == 0)
+        for (int q = 0; q < 3; q++) {                           // the constant column of force rows is zero
+            double *o = A.out + (long long)(p * 3 + q) * A.ld;
+            if (lane < A.ns) o[A.ns * A.npair + lane] = 0.0;
+        }
     for (int si = 0; si < A.ns; si++) {                         // species of the model: Psi rows (+ their share of the prior variance)
-        if (A.diag) fm_species_block<true, true>(A, p, si, A.species[si], r0, r1, sm, km, dacc);
-        else fm_species_block<true, false>(A, p, si, A.species[si], r0, r1, sm, km, dacc);
+        if (A.diag) fm_species_block<true, true, SPLIT>(A, p, si, A.species[si], r0, r1, sm, smem[0], km, dacc);
+        else fm_species_block<true, false, SPLIT>(A, p, si, A.species[si], r0, r1, sm, smem[0], km, dacc);
     }
     if (A.diag)
         for (int sx = 0; sx < A.nsx; sx++)                      // species the model does not know: prior variance only
-            fm_species_block<false, true>(A, p, A.ns + sx, A.species_x[sx], r0, r1, sm, km, dacc);
+            fm_species_block<false, true, SPLIT>(A, p, A.ns + sx, A.species_x[sx], r0, r1, sm, smem[0], km, dacc);
     if (A.diag) {
 #pragma unroll
         for (int q = 0; q < 3; q++) {
             double t = dacc[q];
 #pragma unroll
             for (int o = 32; o >= 1; o >>= 1) t += __shfl_xor(t, o);
-            if (lane == 0) A.diag[3 * (size_t)p + q] = A.sigma2 * t;
+            if (!SPLIT) { if (lane == 0) A.diag[3 * (size_t)p + q] = A.sigma2 * t; }
+            else if (lane == 0) sm[q] = t;                      // the species blocks end on a workgroup barrier: sm is free
+        }
+        if (SPLIT) {
+            __syncthreads();
+            if (threadIdx.x < 3) {
+                const int q = threadIdx.x;
+                A.diag[3 * (size_t)p + q] = A.sigma2 * ((smem[0][q] + smem[1][q]) + (smem[2][q] + smem[3][q]));
+            }
         }
     }
 }
 
+template <bool SPLIT>
 __global__ void __launch_bounds__(256) dot2_force_features_mfma_kernel(dfeat_args A) {
     __shared__ double smem[4][32 * FM_LD];                     // per wavefront: operands of one step / transpose buffer
     __shared__ int skm[4][9 * 64];
-    dot2_force_features_mfma_body(A, blockIdx.x, smem, skm);
+    dot2_force_features_mfma_body<SPLIT>(A, blockIdx.x, smem, skm);
 }
 
 // energy-point feature rows with 256 threads (thread t owns monomials t, t + 256, t + 512): the block role of the
@@ -518,17 +545,25 @@ __device__ __forceinline__ void dot2_features_direct256_body(const dfeat_args &A
 // cores), the next AE.npts blocks one energy point each, the last AE.npts blocks the prior variance of one energy
 // point.  The three roles have nothing in common but their inputs; side by side they fill the chip where three
 // launches in a row each left most of it idle (64 energy points = 64 workgroups).
-template <int NS>
+template <int NS, bool SPLIT>                                  // SPLIT: a workgroup per force point (few points)
 __global__ void __launch_bounds__(256, 2) dot2_features_ef_kernel(dfeat_args AF, dfeat_args AE, int nblkF) {
     __shared__ double smem[4][32 * FM_LD];
     __shared__ int skm[4][9 * 64];
     const int b = blockIdx.x;
-    if (b < nblkF) dot2_force_features_mfma_body(AF, b, smem, skm);
+    if (b < nblkF) dot2_force_features_mfma_body<SPLIT>(AF, b, smem, skm);
     else if (b < nblkF + AE.npts) dot2_features_direct256_body<NS>(AE, b - nblkF, &smem[0][0], (int *)&smem[1][0]);
     else dot2_diag_ee_body(AE, b - nblkF - AE.npts, &smem[0][0]);
 }
 
 }  // namespace
+
+// A workgroup per force point (its rows split over the four wavefronts) when the points are few enough that a
+// wavefront per point leaves the chip empty: up to 256 points (a workgroup per CU; equal at 512, slower beyond).  GPR_FEAT_SPLIT=0/1 forces it.
+static bool fm_split_points(int npts) {
+    static const int force = getenv("GPR_FEAT_SPLIT") ? atoi(getenv("GPR_FEAT_SPLIT")) : -1;
+    if (force >= 0) return force != 0;
+    return npts <= 256;
+}
 
 // Psi rows of the points of a STREAM-packed set: energy set -> out[npts, F]; force set -> out[3*npts, F]
 // (row 3*j+q), F = ns * (d(d+1)/2 + 1), in the caller's point order.  species[ns] lists the atomic numbers
@@ -587,7 +622,8 @@ extern "C" int gpr_dot2_features_direct(void *stream, int d, int width, int npts
     A.sigma0 = sigma0; A.sigma2 = sigma * sigma; A.out = psi; A.ld = ld; A.diag = diag;
     const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
     if (width == 3) {       // force points: symmetric rank-2k update on the matrix cores, one wavefront per point
-        hipLaunchKernelGGL(dot2_force_features_mfma_kernel, dim3((npts + 3) / 4), dim3(256), 0, st, A);
+        if (fm_split_points(npts)) hipLaunchKernelGGL(dot2_force_features_mfma_kernel<true>, dim3(npts), dim3(256), 0, st, A);
+        else hipLaunchKernelGGL(dot2_force_features_mfma_kernel<false>, dim3((npts + 3) / 4), dim3(256), 0, st, A);
         gpr_prof_end(st, pid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { gpr_set_error("dot2_force_features_mfma launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
@@ -643,14 +679,21 @@ extern "C" int gpr_dot2_features_ef(void *stream, int d, int nE, const int *e_ro
     AF = AE;
     AF.dxdr = dxdr_dev; AF.pt_row0 = f_row0_dev; AF.x_index = x_index_dev; AF.d_index = dxdr_index_dev;
     AF.npts = nF; AF.nc = 4; AF.sigma0 = 0.0; AF.out = psi + (size_t)nE * ld; AF.diag = diag ? diag + nE : nullptr;
-    const int nblkF = (nF + 3) / 4, nblk = nblkF + nE * (diag ? 2 : 1);
+    const int split = fm_split_points(nF) ? 1 : 0;
+    const int nblkF = split ? nF : (nF + 3) / 4, nblk = nblkF + nE * (diag ? 2 : 1);
     const int pid = gpr_prof_begin(st, GPR_PROF_FEATURES);
+#define GPR_EF_LAUNCH(NSV)                                                                                         \
+    do {                                                                                                           \
+        if (split) hipLaunchKernelGGL((dot2_features_ef_kernel<NSV, true>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF);   \
+        else hipLaunchKernelGGL((dot2_features_ef_kernel<NSV, false>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF);      \
+    } while (0)
     switch (ns) {
-        case 1: hipLaunchKernelGGL((dot2_features_ef_kernel<1>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
-        case 2: hipLaunchKernelGGL((dot2_features_ef_kernel<2>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
-        case 3: hipLaunchKernelGGL((dot2_features_ef_kernel<3>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
-        default: hipLaunchKernelGGL((dot2_features_ef_kernel<4>), dim3(nblk), dim3(256), 0, st, AF, AE, nblkF); break;
+        case 1: GPR_EF_LAUNCH(1); break;
+        case 2: GPR_EF_LAUNCH(2); break;
+        case 3: GPR_EF_LAUNCH(3); break;
+        default: GPR_EF_LAUNCH(4); break;
     }
+#undef GPR_EF_LAUNCH
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { gpr_set_error("dot2_features_ef launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
