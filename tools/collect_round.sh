@@ -23,6 +23,8 @@ GPR_TAIL_FORM=1 GPR_TAIL_NO_GLDS=1 python tools/tail_bench.py >> $O/${R}_tail_be
 python tools/nbr_bench.py > $O/${R}_nbr_bench.log 2>&1
 GPR_NBR_NO_FUSED=1 python tools/nbr_bench.py >> $O/${R}_nbr_bench.log 2>&1
 python tools/pipeline_split.py 3 > $O/${R}_pipeline_split.log 2>&1
+python tools/single_latency.py 1 500 > $O/${R}_single_latency.log 2>&1
+python tools/single_latency.py 8 >> $O/${R}_single_latency.log 2>&1
 python tools/cfg5_loop.py > $O/${R}_cfg5_loop.log 2>&1
 python tools/fit_opt_time.py > $O/${R}_fit_opt_time.log 2>&1 || true
 echo "micro done"
