@@ -259,7 +259,7 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
     const int lane = threadIdx.x & 63;
     const int slot = lane >> 4, g = lane & 15;
     double *opA0 = sm, *opB0 = sm + 4 * FM_LD, *opA1 = sm + 16 * FM_LD, *opB1 = sm + 20 * FM_LD;   // op?[row][k], opB?[q][row][k]
-    fm_d4 acc0[3][3], acc1[3][3];                               // [component q][tile 00, 01, 11]
+    fm_d4 acc0[3][3], acc1[3][3];                               // [component q][tile 00, 10, 11] (lower triangle of S)
 #pragma unroll
     for (int q = 0; q < 3; q++)
 #pragma unroll
@@ -346,8 +346,8 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
                     const double b0 = opB0[(q * 4 + krow) * FM_LD + col], b1 = opB0[(q * 4 + krow) * FM_LD + 16 + col];
                     acc0[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc0[q][0], 0, 0, 0);
                     acc0[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av0, acc0[q][0], 0, 0, 0);
-                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc0[q][1], 0, 0, 0);
-                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av1, acc0[q][1], 0, 0, 0);
+                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b0, acc0[q][1], 0, 0, 0);
+                    acc0[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av0, acc0[q][1], 0, 0, 0);
                     acc0[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc0[q][2], 0, 0, 0);
                     acc0[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av1, acc0[q][2], 0, 0, 0);
                 }
@@ -359,8 +359,8 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
                     const double b0 = opB1[(q * 4 + krow) * FM_LD + col], b1 = opB1[(q * 4 + krow) * FM_LD + 16 + col];
                     acc1[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b0, acc1[q][0], 0, 0, 0);
                     acc1[q][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av0, acc1[q][0], 0, 0, 0);
-                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av0, b1, acc1[q][1], 0, 0, 0);
-                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b0, av1, acc1[q][1], 0, 0, 0);
+                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b0, acc1[q][1], 0, 0, 0);
+                    acc1[q][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av0, acc1[q][1], 0, 0, 0);
                     acc1[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1, b1, acc1[q][2], 0, 0, 0);
                     acc1[q][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(b1, av1, acc1[q][2], 0, 0, 0);
                 }
@@ -369,14 +369,48 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
         }
 #undef FM_FETCH
     }
-    // ---- vech(S_q) with sqrt(2) on the off-diagonal entries, through LDS (tile layout -> packed (k, m) order)
+    // ---- vech(S_q) with sqrt(2) on the off-diagonal entries.  A lane holds S[k][m] for k = tile row base + (lane >> 4) + 4 r,
+    // m = tile column base + (lane & 15): the sixteen lanes of a row write sixteen consecutive entries of the packed lower
+    // triangle (k (k + 1) / 2 + m), so the three tiles go out straight from the accumulators -- no transpose through LDS, no
+    // index table.  The prior variance is the sum over the FULL symmetric matrix: tiles 00 and 11 as they are, tile 10 twice.
+    if (!SPLIT) {
+        const int rl = lane >> 4, cl = lane & 15;
+        if (P0) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double *o = A.out + (long long)(p * 3 + q) * A.ld + si * A.npair;
+#pragma unroll
+                for (int t = 0; t < 3; t++) {
+                    const int kb = (t == 0) ? 0 : 16, mb = (t == 2) ? 16 : 0;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const int k = kb + rl + 4 * r, m = mb + cl;
+                        const double sv = acc0[q][t][r];
+                        if (m <= k && k < A.d) o[k * (k + 1) / 2 + m] = -((k == m) ? sv : 1.4142135623730951 * sv);
+                    }
+                }
+            }
+        }
+        if (P1) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) {
+                double part = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    part += acc1[q][0][r] * acc1[q][0][r] + 2.0 * acc1[q][1][r] * acc1[q][1][r] + acc1[q][2][r] * acc1[q][2][r];
+                dacc[q] += part;
+            }
+        }
+        return;
+    }
+    // SPLIT: the partial tiles of the four wavefronts meet in LDS, entry by entry in packed order
 #pragma unroll
     for (int pass = 0; pass < 2; pass++) {
         if ((pass == 0 && !P0) || (pass == 1 && !P1)) continue;
         for (int q = 0; q < 3; q++) {
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                const int ra = (t == 2) ? 16 : 0, cbq = (t == 0) ? 0 : 16;
+                const int ra = (t == 0) ? 0 : 16, cbq = (t == 2) ? 16 : 0;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
                     sm[(ra + (lane >> 4) + 4 * r) * FM_LD + cbq + (lane & 15)] = (pass == 0) ? acc0[q][t][r] : acc1[q][t][r];
@@ -391,7 +425,7 @@ __device__ __forceinline__ void fm_species_block(const dfeat_args &A, int p, int
                 const int kmt = km[64 * t + lane];
                 if (kmt >= 0) {
                     const int k = kmt >> 8, m = kmt & 255, e = lane + 64 * t;         // m <= k
-                    const int at = (k >= 16 && m < 16) ? m * FM_LD + k : k * FM_LD + m;
+                    const int at = k * FM_LD + m;
                     double sv;
                     if (SPLIT) sv = (sm_all[at] + sm_all[32 * FM_LD + at]) + (sm_all[2 * 32 * FM_LD + at] + sm_all[3 * 32 * FM_LD + at]);
                     else sv = sm[at];
@@ -418,12 +452,11 @@ __device__ __forceinline__ void dot2_force_features_mfma_body(const dfeat_args &
         r1 = min(r1, r0 + per);
     }
     double dacc[3] = {0.0, 0.0, 0.0};                           // sum over species and (k, m) of (M_km + M_mk)^2, eps operands
-    // this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once (kept in LDS: nine registers
-    // decide between one and two wavefronts per SIMD)
+    // SPLIT: this lane's packed (k, m) indices e = lane + 64 t of the vech layout, decoded once (kept in LDS)
     int *km = skm[wave];
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-        if (SPLIT && (t & 3) != wave) continue;                 // only the entries this wavefront writes out
+        if (!SPLIT || (t & 3) != wave) continue;                // SPLIT only: the entries this wavefront writes out
         const int e = lane + 64 * t;
         int k = (int)((sqrt(8.0 * e + 1.0) - 1.0) * 0.5);
         while ((k + 1) * (k + 2) / 2 <= e) k++;
