@@ -936,6 +936,162 @@ __global__ void __launch_bounds__(256) ws_tail_combine_kernel(int m, int npart, 
     if (s_last && threadIdx.x < 4) status_dst[threadIdx.x] = (double)status_src[threadIdx.x];
 }
 
+// ---- few rows (one structure per call: m = 97): the time of the tail is the latency of one workgroup's chain, so the chain is
+// made short.  Grid (column slices of 32, row blocks of 32); the eight wavefronts of a workgroup take the k steps of its 2 x 2
+// tiles in turn (k step ks belongs to wavefront ks mod 8), request ALL their operands at once -- straight from global memory in
+// MFMA operand order, up to 16 k steps per wavefront and batch: one memory latency for the whole product where a staged k loop
+// pays one per tile --, multiply, and add their partial Q tiles through LDS in wavefront order before the squares are taken.
+// The workgroups of the last slice (full k range) also produce P w and |p|^2.  Row blocks are completed by the last arriver,
+// which adds the slices in order, and the status words by the last row block -- the hand-over of ws_tail_kernel<., 1>.
+constexpr int TF_NW = 8, TF_KB = 16, TF_R = 32, TF_C = 32;
+constexpr size_t tf_lds_bytes() { return (size_t)(TF_NW * 4 * 256 + TF_R * (TF_C + 1) + TF_NW * 2 * 2 * 16) * sizeof(double); }
+__global__ void __launch_bounds__(64 * TF_NW) ws_tail_few_kernel(int m, int n, const double *__restrict__ P, long long ldp,
+                                                                 const double *__restrict__ Ci, long long ldc,
+                                                                 const double *__restrict__ w, const double *__restrict__ diag,
+                                                                 double *__restrict__ out, double vsq, double *__restrict__ part,
+                                                                 double *__restrict__ mn, int *__restrict__ cnt, int std_out,
+                                                                 const int *status_src, double *status_dst) {
+    extern __shared__ __attribute__((aligned(16))) double tf_smem[];
+    double *red = tf_smem;                                   // [wavefront][tile][r * 64 + lane]
+    double *sq = red + TF_NW * 4 * 256;                      // [row][TF_C + 1]
+    double *mred = sq + TF_R * (TF_C + 1);                   // [wavefront][mean | norm][row tile][16]
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kq = lane >> 4;
+    const int nslice = gridDim.x, sl = blockIdx.x;
+    const int bm0 = blockIdx.y * TF_R, bn0 = sl * TF_C;
+    const int kend = min(n, bn0 + TF_C);                     // C^-1[j][k] = 0 for k > j
+    const int nks = (kend + 3) >> 2;
+    const bool last = sl == nslice - 1;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = d4{0.0, 0.0, 0.0, 0.0};
+    double mean_p[2] = {0.0, 0.0}, norm_p[2] = {0.0, 0.0};
+    const double *prow[2], *crow[2];
+    bool rok[2], cok[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const int row = bm0 + 16 * t + i, col = bn0 + 16 * t + i;
+        rok[t] = row < m; cok[t] = col < n;
+        prow[t] = P + (long long)(rok[t] ? row : 0) * ldp;
+        crow[t] = Ci + (long long)(cok[t] ? col : 0) * ldc;
+    }
+    for (int ks0 = wave; ks0 < nks; ks0 += TF_NW * TF_KB) {
+        double av[TF_KB][2], bv[TF_KB][2], wv[TF_KB];
+        const int kbase = 4 * ks0 + kq;
+        // every operand of the batch is requested before the first product.  A k step that exists (wavefront-uniform test)
+        // starts inside the range; only the lanes of its upper quarters can lie beyond kend (kend not a multiple of four):
+        // they read the last valid element instead and are zeroed afterwards, so no load is predicated per lane.
+#pragma unroll
+        for (int u = 0; u < TF_KB; u++) {
+            if (ks0 + TF_NW * u < nks) {
+                const int kc = min(kbase + 4 * TF_NW * u, kend - 1);
+#pragma unroll
+                for (int t = 0; t < 2; t++) { av[u][t] = prow[t][kc]; bv[u][t] = crow[t][kc]; }
+                wv[u] = last ? w[kc] : 0.0;
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; t++) { av[u][t] = 0.0; bv[u][t] = 0.0; }
+                wv[u] = 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < TF_KB; u++) {
+            if (ks0 + TF_NW * u < nks) {                      // wavefront-uniform
+                const bool kin = kbase + 4 * TF_NW * u < kend;
+#pragma unroll
+                for (int t = 0; t < 2; t++) { av[u][t] = (kin && rok[t]) ? av[u][t] : 0.0; bv[u][t] = (kin && cok[t]) ? bv[u][t] : 0.0; }
+#pragma unroll
+                for (int a = 0; a < 2; a++)
+#pragma unroll
+                    for (int b = 0; b < 2; b++) acc[a][b] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][a], bv[u][b], acc[a][b], 0, 0, 0);
+                if (last) {
+#pragma unroll
+                    for (int a = 0; a < 2; a++) { mean_p[a] = fma(av[u][a], wv[u], mean_p[a]); norm_p[a] = fma(av[u][a], av[u][a], norm_p[a]); }
+                }
+            }
+        }
+    }
+    // partial tiles -> LDS; P w and |p|^2: the four k quarters of a row sit in lanes i, i + 16, i + 32, i + 48
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[(wave * 4 + a * 2 + b) * 256 + r * 64 + lane] = acc[a][b][r];
+    if (last) {
+#pragma unroll
+        for (int a = 0; a < 2; a++) {
+            mean_p[a] += __shfl_xor(mean_p[a], 16, 64); mean_p[a] += __shfl_xor(mean_p[a], 32, 64);
+            norm_p[a] += __shfl_xor(norm_p[a], 16, 64); norm_p[a] += __shfl_xor(norm_p[a], 32, 64);
+            if (lane < 16) { mred[((wave * 2 + 0) * 2 + a) * 16 + lane] = mean_p[a]; mred[((wave * 2 + 1) * 2 + a) * 16 + lane] = norm_p[a]; }
+        }
+    }
+    __syncthreads();
+    // Q entries: sum over the wavefronts in order, squared, placed by (row, column)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int e = tid + 512 * h, tile = e >> 8, idx = e & 255, r = idx >> 6, ln = idx & 63;
+        double q = 0.0;
+#pragma unroll
+        for (int wv_ = 0; wv_ < TF_NW; wv_++) q += red[(wv_ * 4 + tile) * 256 + idx];
+        const int row = 16 * (tile >> 1) + (ln >> 4) + 4 * r, col = 16 * (tile & 1) + (ln & 15);
+        sq[row * (TF_C + 1) + col] = q * q;
+    }
+    __syncthreads();
+    if (tid < TF_R && bm0 + tid < m) {
+        double q2 = 0.0;
+#pragma unroll
+        for (int c = 0; c < TF_C; c++) q2 += sq[tid * (TF_C + 1) + c];
+        __hip_atomic_store(&part[(size_t)sl * m + bm0 + tid], q2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (last) {
+            double mu = 0.0, nn = 0.0;
+            const int a = tid >> 4, ii = tid & 15;
+#pragma unroll
+            for (int wv_ = 0; wv_ < TF_NW; wv_++) { mu += mred[((wv_ * 2 + 0) * 2 + a) * 16 + ii]; nn += mred[((wv_ * 2 + 1) * 2 + a) * 16 + ii]; }
+            __hip_atomic_store(&mn[bm0 + tid], mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&mn[(size_t)m + bm0 + tid], nn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    // last workgroup of this row block: every workgroup counts itself in only after its own stores have been acknowledged
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[blockIdx.y], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nslice - 1;
+    __syncthreads();
+    if (!s_last) return;
+    if (tid == 0) __hip_atomic_store(&cnt[blockIdx.y], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < TF_R && bm0 + tid < m) {
+        const int row = bm0 + tid;
+        double q2 = 0.0;
+        const double mu = __hip_atomic_load(&mn[row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double nn = __hip_atomic_load(&mn[(size_t)m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the slices' sums in order, eight loads in flight at a time (one after the other they were a third of the kernel)
+        for (int x0 = 0; x0 < nslice; x0 += 8) {
+            double pv[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                pv[u] = __hip_atomic_load(&part[(size_t)min(x0 + u, nslice - 1) * m + row], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; u++) q2 += (x0 + u < nslice) ? pv[u] : 0.0;
+        }
+        const double v = fmax(diag[row] - vsq * (nn - q2), 0.0);
+        const double sd = std_out ? sqrt(v) : v;
+        if (status_dst) {
+            __hip_atomic_store(&out[row], mu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(&out[m + row], sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else { out[row] = mu; out[m + row] = sd; }
+    }
+    if (!status_dst) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) s_last = __hip_atomic_fetch_add(&cnt[WT_FEW_MAX_RB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (s_last && tid < 4) __hip_atomic_store(&status_dst[tid], (double)status_src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (s_last && tid == 0) __hip_atomic_store(&cnt[WT_FEW_MAX_RB], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void ws_status_kernel(const int *src, double *dst) { if (threadIdx.x < 4) dst[threadIdx.x] = (double)src[threadIdx.x]; }
 
 // partial[b][j] = sum_{i in row block b} a[i*lda+j] * x[i]; fixed-order second pass sums the blocks
@@ -1441,14 +1597,29 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         // launch -- arrival counters that belong to the stream, status words by the last row block
         int *cnt = tail_stream_counters(st);
         if (!cnt) return GPR_ERR_HIP;
+        // the short-chain form (operands straight from memory, k steps spread over eight wavefronts); GPR_TAIL_FEW_STAGED=1
+        // selects the staged k loop of ws_tail_kernel<., 1> (A/B, tests)
+        static const bool staged_env = getenv("GPR_TAIL_FEW_STAGED") != nullptr;
+        const bool staged = staged_env || nrb > 32;              // from about sixteen structures on the staged loop is ahead
+        const int nslice = (n + TF_C - 1) / TF_C, nparts = staged ? ncb : nslice;
         void *wsp;
-        const size_t ws_bytes = (size_t)(ncb + 2) * m * sizeof(double);
+        const size_t ws_bytes = (size_t)(nparts + 2) * m * sizeof(double);
         int rc = gpr_dev_alloc(&wsp, ws_bytes, st);
         if (rc) return rc;
-        double *part = (double *)wsp, *mn = part + (size_t)ncb * m;
+        double *part = (double *)wsp, *mn = part + (size_t)nparts * m;
+        static bool attrf = false;
+        if (!attrf) {
+            const hipError_t ae = hipFuncSetAttribute((const void *)ws_tail_few_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tf_lds_bytes());
+            if (ae != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: %s", hipGetErrorString(ae)); return GPR_ERR_HIP; }
+            attrf = true;
+        }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
-        hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
-                           out, vsq, part, mn, cnt, std_out, status_src, status_dst);
+        if (staged)
+            hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
+                               out, vsq, part, mn, cnt, std_out, status_src, status_dst);
+        else
+            hipLaunchKernelGGL(ws_tail_few_kernel, dim3(nslice, (m + TF_R - 1) / TF_R), dim3(64 * TF_NW), tf_lds_bytes(), st, m, n, P, ldp,
+                               Cinv, ldc, w, diag, out, vsq, part, mn, cnt, std_out, status_src, status_dst);
         gpr_prof_end(st, pid);
         const hipError_t le = hipGetLastError();
         gpr_dev_free(wsp, st);
