@@ -169,7 +169,10 @@ def test_dense_linear_algebra(gpu):
     assert int(dev.potrf_lower_(bad).item()) == 2          # not positive definite: pivot 2
 
 
-@pytest.mark.parametrize("m,n", [(1, 1), (5, 3), (33, 130), (100, 257), (70, 466), (200, 932)])
+# shapes: one workgroup; the short-chain form for few rows (up to 32 row blocks; n = 1864: four operand batches per wavefront);
+# the staged split form (33..64 row blocks); the row-resident and the paired forms for many rows
+@pytest.mark.parametrize("m,n", [(1, 1), (5, 3), (33, 130), (100, 257), (70, 466), (200, 932), (97, 1864), (1024, 131),
+                                 (1200, 466), (2048, 257), (2100, 466), (2100, 932)])
 def test_ws_tail_matches_numpy(m, n):
     """gpr_ws_tail (fused weight-space tail: P w and diag - vsq (|p|^2 - |p C^-T|^2) from MFMA tiles that are never
     stored) against numpy, at sizes that are not multiples of its 32 x 128 x 32 tiles, and against the two-call route
