@@ -7,7 +7,10 @@ installed both functions hand over to ase.mep.NEB and ase.optimize exactly as th
 build's containers) the band is a `Band` of `Image`s: linear interpolation (optionally minimum-image), improved-tangent
 nudged elastic band forces with spring constant k and an optional climbing image (Henkelman & Jonsson, J. Chem. Phys.
 113, 9978 (2000); Henkelman, Uberuaga & Jonsson, ibid. 9901 -- what ase.mep.NEB implements), relaxed by FIRE.  IDPP
-interpolation is ASE's own algorithm and needs ASE.
+interpolation (`get_images(..., IDPP=True)`, which the reference delegates to ase.mep.NEB.interpolate(method='idpp')) is
+provided the same way: the image-dependent pair potential of Smidstrup et al. (J. Chem. Phys. 140, 214106 (2014)) with
+linearly interpolated pair distances as targets, the linearly interpolated band relaxed on it to fmax = 0.1 in at most 100
+steps -- ASE's procedure and defaults, with the built-in FIRE in place of ASE's MDMin.
 """
 import os
 from copy import copy
@@ -98,8 +101,6 @@ def get_images(init, final, num_images=5, vaccum=0.0, traj=None, IDPP=False, mic
         else:
             neb.interpolate(apply_constraint=apply_constraint, mic=mic)
         return images
-    if IDPP:
-        raise ImportError("IDPP interpolation is ASE's (ase.mep.NEB.interpolate(method='idpp')); install ASE or use IDPP=False")
     initial, final = Image.of(initial), Image.of(final)
     if initial.pbc[-1] and vaccum > 0:
         for atoms in (initial, final):
@@ -117,7 +118,61 @@ def get_images(init, final, num_images=5, vaccum=0.0, traj=None, IDPP=False, mic
         if apply_constraint and len(initial.fixed):
             step[initial.fixed] = 0.0
         images[i].positions = initial.positions + step
+    if IDPP:
+        idpp_interpolate(images, mic=mic)
     return images
+
+
+def _all_distances(atoms, mic):
+    """D[i, j] = r_j - r_i (minimum image if asked) and their lengths"""
+    P = atoms.positions
+    n = len(P)
+    D = P[None, :, :] - P[:, None, :]
+    if mic:
+        D = _minimum_image(D.reshape(-1, 3), atoms.cell, atoms.pbc).reshape(n, n, 3)
+    return D, np.sqrt((D ** 2).sum(axis=-1))
+
+
+class PairDistancePotential:
+    """Image-dependent pair potential: S = sum_{i<j} w(d_ij) (d_ij - target_ij)^2 with w = d^-4, and its forces
+    -dS/dr (the objective ase.mep.neb.IDPP evaluates).  Calculator-shaped: one instance per image."""
+    name = 'idpp'
+
+    def __init__(self, target, mic=False):
+        self.target, self.mic = target, mic
+
+    def evaluate(self, atoms):
+        D, d = _all_distances(atoms, self.mic)
+        dd = d - self.target
+        np.fill_diagonal(d, 1.0)                                   # no self-pairs: dd is zero there
+        e = 0.5 * (dd ** 2 / d ** 4).sum()
+        f = -2.0 * ((dd * (1.0 - 2.0 * dd / d) / d ** 5)[..., None] * D).sum(axis=0)
+        return e, f
+
+    def get_potential_energy(self, atoms):
+        return self.evaluate(atoms)[0]
+
+    def get_forces(self, atoms):
+        return self.evaluate(atoms)[1]
+
+
+def idpp_interpolate(images, mic=False, fmax=0.1, steps=100, k=0.1):
+    """Refine an (already linearly interpolated) band in place on the image-dependent pair potential: the target pair
+    distances of image i are those of the first image plus i / (n - 1) of the change to the last; the interior images
+    relax under nudged-elastic-band forces of that objective (fixed atoms stay where they are).  The images' own
+    calculators are put back afterwards.  Returns the band object (`.nsteps`, `.converged`)."""
+    n = len(images)
+    d1, d2 = _all_distances(images[0], mic)[1], _all_distances(images[-1], mic)[1]
+    saved = [im.calc for im in images]
+    for i, im in enumerate(images):
+        im.calc = PairDistancePotential(d1 + (d2 - d1) * (i / (n - 1.0)), mic=mic)
+    band = Band(images, k=k)
+    try:
+        _fire(band, fmax, steps)
+    finally:
+        for im, c in zip(images, saved):
+            im.calc = c
+    return band
 
 
 class Band:
