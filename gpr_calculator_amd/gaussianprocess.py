@@ -1179,8 +1179,11 @@ class GP():
                 C.byref(h), dev.stream_ptr(), des.nmax, des.lmax, float(des.rcut), float(des.alpha), nseg, ncheb, dev.ptr(table),
                 int(bool(des.weight_on)), len(sp), sp.ctypes.data_as(_lib.c_int_p), float(self.kernel.sigma),
                 float(self.kernel.sigma0), dev.ptr(w), dev.ptr(M), dev.ptr(Cinv), int(bool(return_std))), "gpr_dot2_session_create")
-            dev.check(_lib.lib().gpr_dot2_session_set_depth(h, int(self.session_depth)), "gpr_dot2_session_set_depth")
             ses = self._session = (key, h, (table, w, M, Cinv), ws)      # the tuple keeps the device arrays alive
+            self._session_depth_set = None
+        if self._session_depth_set != int(self.session_depth):           # follows the attribute, also on a live session
+            dev.check(_lib.lib().gpr_dot2_session_set_depth(ses[1], int(self.session_depth)), "gpr_dot2_session_set_depth")
+            self._session_depth_set = int(self.session_depth)
         a0 = np.frombuffer(got[0], dtype=np.int32)
         nS, natoms = len(strucs), int(a0[-1])
         fixed = None
@@ -1273,6 +1276,7 @@ class GP():
     native_batch = True
     session_batch = True        # one rank: the host-in / host-out session call (False: the Python-side unpacking route)
     session_depth = 2           # batches predict_structures_submit may have in flight (1 .. 8)
+    _session_depth_set = None   # the depth the live session was told
     device_single = True
 
     def predict_structures(self, strucs, return_std=True, f_tol=1e-8):
