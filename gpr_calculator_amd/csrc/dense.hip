@@ -118,7 +118,20 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
                                                        int lower_only, int ksplit, double *__restrict__ ws, cyc_rule cyc) {
     __shared__ double As[2][GBUF];
     __shared__ double Bs[2][GBUF];
-    const int bm0 = blockIdx.y * GM, bn0 = blockIdx.x * GN;
+    // With a triangular operand the k range of a tile depends on its row or column block: the tiles are handed out longest
+    // first (a tile with the full k range started in the last round of workgroups was the tail of the launch -- the two
+    // top-level products of the triangular inverse at n = 6063 ran at 33 TF): rows in descending order when k ends at
+    // the row block (2), column-major with the long columns first when it ends (4) or begins (16) at the column block.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (ksplit == 0 && cyc.nb == 0) {
+        if (lower_only & 2) by = (int)gridDim.y - 1 - by;
+        else if (lower_only & (4 | 16)) {
+            const int lin = by * (int)gridDim.x + bx, c = lin / (int)gridDim.y;
+            by = lin - c * (int)gridDim.y;
+            bx = (lower_only & 4) ? (int)gridDim.x - 1 - c : c;
+        }
+    }
+    const int bm0 = by * GM, bn0 = bx * GN;
     if (cyc.nb > 0) {            // rows are the block-cyclic rows of one rank: skip tiles above the GLOBAL diagonal
         const int last = min(bm0 + GM, m) - 1;                                   // last local row of the tile
         const long long grow = ((long long)(cyc.lb0 + last / cyc.nb) * cyc.nranks + cyc.rank) * cyc.nb + last % cyc.nb;
