@@ -501,6 +501,7 @@ __global__ void pipe_probe_set_kernel(int *flag) { __hip_atomic_store(flag, 1, _
 #include <chrono>
 struct lookahead_ctx {
     hipStream_t side = nullptr, mid = nullptr;
+    hipStream_t aux[3] = {nullptr, nullptr, nullptr};   // more lanes for the independent joins of the triangular inverse
     std::vector<hipEvent_t> ev;
     hipEvent_t end_ev = nullptr;         // end of the last factorisation that used this context
     bool end_valid = false;
@@ -522,6 +523,7 @@ struct lookahead_ctx {
         if (flag) (void)hipFree(flag);
         if (mid) { (void)gpr_dev_cache_drop_stream(mid); (void)hipStreamDestroy(mid); }
         if (side) { (void)gpr_dev_cache_drop_stream(side); (void)hipStreamDestroy(side); }
+        for (hipStream_t &a : aux) { if (a) { (void)gpr_dev_cache_drop_stream(a); (void)hipStreamDestroy(a); } a = nullptr; }
         end_ev = nullptr; flag = nullptr; mid = side = nullptr; ready = false; end_valid = false;
         (void)hipGetLastError();
     }
@@ -548,6 +550,8 @@ struct lookahead_ctx {
         if (!ok) ok = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, lo) == hipSuccess;
         if (!ok) side = nullptr;
         if (ok && hipStreamCreateWithPriority(&mid, hipStreamNonBlocking, hi) != hipSuccess) { mid = nullptr; ok = false; }
+        for (hipStream_t &a : aux)
+            if (ok && hipStreamCreateWithFlags(&a, hipStreamNonBlocking) != hipSuccess) { a = nullptr; ok = false; }
         if (ok && hipMalloc((void **)&flag, 8 * sizeof(int)) != hipSuccess) { flag = nullptr; ok = false; }
         ok = ok && hipMemset(flag, 0, 8 * sizeof(int)) == hipSuccess;
         ok = ok && hipEventCreateWithFlags(&end_ev, hipEventDisableTiming) == hipSuccess;
@@ -887,7 +891,7 @@ static void trtri_collect(int b0, int b1, size_t depth, std::vector<std::vector<
 }
 // The halves are joined level by level, deepest first.  The joins of one level touch disjoint blocks, and below the top
 // they are small products (at n = 6063: 4, 8, 36, 144 workgroups on 256 CUs, 3.6 of the routine's 5.6 ms one after the
-// other), so they are spread over three streams -- the caller's and the two private ones of the device's look-ahead
+// other), so they are spread over up to six streams -- the caller's and the private ones of the device's look-ahead
 // context -- between a fork and a join event per level; each gets its own piece of `tmp` (cap doubles in all).
 static int trtri_levels(hipStream_t st, lookahead_ctx *la, int n, const double *l, long long ldl, double *x, long long ldx, int nblk,
                         double *tmp, size_t cap) {
@@ -898,25 +902,27 @@ static int trtri_levels(hipStream_t st, lookahead_ctx *la, int n, const double *
         size_t need = 0;
         for (const trtri_node &nd : nodes) need += (size_t)(std::min(nd.b1 * DB, n) - nd.mid * DB) * (size_t)((nd.mid - nd.b0) * DB);
         const bool spread = la && nodes.size() > 1 && need <= cap;
-        hipStream_t lanes[3] = {st, spread ? la->mid : st, spread ? la->side : st};
+        hipStream_t lanes[6] = {st, st, st, st, st, st};
+        int nlanes = 1;
         if (spread) {
+            lanes[1] = la->mid; lanes[2] = la->side; lanes[3] = la->aux[0]; lanes[4] = la->aux[1]; lanes[5] = la->aux[2];
+            nlanes = (int)std::min<size_t>(6, nodes.size());
             hipEvent_t e = la->take();
             GPR_HIP_TRY(hipEventRecord(e, st));
-            GPR_HIP_TRY(hipStreamWaitEvent(la->mid, e, 0)); GPR_HIP_TRY(hipStreamWaitEvent(la->side, e, 0));
+            for (int q = 1; q < nlanes; q++) GPR_HIP_TRY(hipStreamWaitEvent(lanes[q], e, 0));
         }
         size_t off = 0;
         for (size_t i = 0; i < nodes.size(); i++) {
             const trtri_node &nd = nodes[i];
-            const int rc = trtri_join(lanes[i % 3], n, l, ldl, x, ldx, nd, tmp + (spread ? off : 0));
+            const int rc = trtri_join(lanes[i % nlanes], n, l, ldl, x, ldx, nd, tmp + (spread ? off : 0));
             if (rc) return rc;
             off += (size_t)(std::min(nd.b1 * DB, n) - nd.mid * DB) * (size_t)((nd.mid - nd.b0) * DB);
         }
-        if (spread)
-            for (hipStream_t aux : {la->mid, la->side}) {
-                hipEvent_t e = la->take();
-                GPR_HIP_TRY(hipEventRecord(e, aux));
-                GPR_HIP_TRY(hipStreamWaitEvent(st, e, 0));
-            }
+        for (int q = 1; q < nlanes; q++) {
+            hipEvent_t e = la->take();
+            GPR_HIP_TRY(hipEventRecord(e, lanes[q]));
+            GPR_HIP_TRY(hipStreamWaitEvent(st, e, 0));
+        }
     }
     return GPR_OK;
 }
