@@ -1406,6 +1406,105 @@ __global__ void __launch_bounds__(256) trsv_step_kernel(const double *__restrict
     }
 }
 
+// The same solve as ONE launch: workgroup `id` owns the id-th 64-row block in the order of the substitution, applies the blocks
+// solved before it as their solutions appear, solves its own block with the stored inverse and publishes it.  Publication needs
+// no flag and no acknowledgement: the solutions go to a side buffer `xs` that starts out as NaNs (0xFF bytes), written with
+// agent-scope stores (the workgroups run on different XCDs), and a consumer polls the very elements it needs until they are
+// numbers.  The L tile of the next step and the inverse of the own diagonal block depend on no solution and are requested ahead;
+// between two publications sit one poll, the last 64 x 64 update and the diagonal product.  A step of the launch-per-block form
+// costs a launch (15 us, 95 of them at N = 6063).  Workgroups only wait for lower ids, which the dispatcher starts first; a wait
+// that outlasts TRSV_CHAIN_POLLS or finds the abort word set gives up, raises it, and its rows end as NaNs (as do all later ones).
+constexpr int TRSV_CHAIN_POLLS = 1 << 22;
+template <bool TRANS>
+__global__ void __launch_bounds__(256) trsv_chain_kernel(const double *__restrict__ dinv, const double *__restrict__ l, long long ldl,
+                                                          double *b, long long ldb, int nrhs, int n, double *xs, int *abort_word) {
+    __shared__ double T[NB][NB + 1];
+    __shared__ double X[NB][TRSV_MAX_RHS + 1];
+    __shared__ int s_bad;
+    const int nblk = gridDim.x, id = blockIdx.x, blk = TRANS ? nblk - 1 - id : id;
+    const int k0 = blk * NB, kb = min(NB, n - k0);
+    const int tid = threadIdx.x, c = tid & 63, jg = tid >> 6;
+    const int lrow = tid >> 2, lcol = (tid & 3) * 16;            // tile loads: 16 consecutive elements of one row per thread
+    const int j0 = jg, j1 = jg + 4;
+    if (tid == 0) s_bad = 0;
+    double acc0 = (c < kb && j0 < nrhs) ? b[(long long)(k0 + c) * ldb + j0] : 0.0;
+    double acc1 = (c < kb && j1 < nrhs) ? b[(long long)(k0 + c) * ldb + j1] : 0.0;
+    double regs[16], wreg[16];
+    auto load_tile = [&](int kk) {                               // forward: L[k0 + i][64 kk + q]; backward: L[64 kk + q][k0 + i]
+        const int grow = (TRANS ? kk * NB : k0) + lrow, gcol = (TRANS ? k0 : kk * NB) + lcol;
+        const double *src = l + (long long)grow * ldl + gcol;
+#pragma unroll
+        for (int u = 0; u < 16; u++) regs[u] = (grow < n && gcol + u < n) ? src[u] : 0.0;
+    };
+#pragma unroll
+    for (int u = 0; u < 16; u++) wreg[u] = dinv[(size_t)blk * NB * NB + lrow * NB + lcol + u];
+    if (id > 0) load_tile(TRANS ? nblk - 1 : 0);
+    __syncthreads();
+    for (int step = 0; step < id; step++) {
+        const int kk = TRANS ? nblk - 1 - step : step;
+#pragma unroll
+        for (int u = 0; u < 16; u++) T[lrow][lcol + u] = regs[u];
+        for (int e = tid; e < NB * nrhs; e += 256) {            // the solution of block kk, element by element as it lands
+            const int q = e / nrhs, j = e - q * nrhs, row = kk * NB + q;
+            double v = 0.0;
+            if (row < n) {
+                int polls = 0;
+                v = __hip_atomic_load(&xs[(size_t)row * nrhs + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (v != v) {
+                    if (++polls > TRSV_CHAIN_POLLS || ((polls & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                        s_bad = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                    v = __hip_atomic_load(&xs[(size_t)row * nrhs + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+            X[q][j] = v;
+        }
+        if (step + 1 < id) load_tile(TRANS ? kk - 1 : kk + 1);
+        __syncthreads();
+        if (s_bad) break;                                        // (uniform: written before the barrier)
+        if (j0 < nrhs) {
+            double a0 = 0.0, a1 = 0.0;
+#pragma unroll 8
+            for (int q = 0; q < NB; q++) {
+                const double t = TRANS ? T[q][c] : T[c][q];
+                a0 = fma(t, X[q][j0], a0);
+                if (j1 < nrhs) a1 = fma(t, X[q][j1], a1);
+            }
+            acc0 -= a0; acc1 -= a1;
+        }
+        __syncthreads();                                         // T and X are rewritten by the next step
+    }
+    const bool ok = s_bad == 0;
+    // x = W acc (forward) / W^T acc (backward), W the stored inverse of the diagonal block
+    if (j0 < nrhs) X[c][j0] = acc0;
+    if (j1 < nrhs) X[c][j1] = acc1;
+#pragma unroll
+    for (int u = 0; u < 16; u++) T[lrow][lcol + u] = wreg[u];
+    __syncthreads();
+    if (c < kb) {
+        double x0 = 0.0, x1 = 0.0;
+        for (int q = 0; q < NB; q++) {
+            const double t = TRANS ? T[q][c] : T[c][q];
+            if (j0 < nrhs) x0 = fma(t, X[q][j0], x0);
+            if (j1 < nrhs) x1 = fma(t, X[q][j1], x1);
+        }
+        // a NaN of the data itself (a factor that is not one) is published as an infinity: "not there yet" stays unambiguous
+        // and the consumers end with non-finite numbers instead of waiting
+        const double bad = __builtin_nan(""), inf = __builtin_inf();
+        if (j0 < nrhs) {
+            b[(long long)(k0 + c) * ldb + j0] = ok ? x0 : bad;
+            if (ok) __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j0], x0 == x0 ? x0 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (j1 < nrhs) {
+            b[(long long)(k0 + c) * ldb + j1] = ok ? x1 : bad;
+            if (ok) __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j1], x1 == x1 ? x1 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    if (!ok && tid == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ void trsv_copy_kernel(int n, int nrhs, const double *xs, double *b, long long ldb) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e < n * nrhs) b[(long long)(e / nrhs) * ldb + e % nrhs] = xs[e];
@@ -1418,7 +1517,26 @@ extern "C" int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, con
     if (n == 0 || nrhs == 0) return GPR_OK;
     GPR_REQUIRE(l && b && ldl >= n && ldb >= nrhs, "gpr_trsm_lower: bad arguments");
     const int nblk = (n + NB - 1) / NB;
-    if (dinv && nrhs <= TRSV_MAX_RHS) {              // few right-hand sides: one fused launch per block
+    static const bool no_chain = getenv("GPR_TRSV_NO_CHAIN") != nullptr;
+    if (dinv && nrhs <= TRSV_MAX_RHS && nblk >= 2 && nblk <= 1024 && !no_chain) {   // few right-hand sides: the whole solve in one launch
+        void *p;
+        const size_t xs_bytes = (size_t)n * nrhs * sizeof(double);
+        int rc = gpr_dev_alloc(&p, xs_bytes + 16, st);
+        if (rc) return rc;
+        double *xs = (double *)p;
+        int *abort_word = (int *)((char *)p + xs_bytes);
+        hipError_t me = hipMemsetAsync(xs, 0xFF, xs_bytes, st);  // NaNs: "not published yet"
+        if (me == hipSuccess) me = hipMemsetAsync(abort_word, 0, sizeof(int), st);
+        if (me == hipSuccess) {
+            if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word);
+            else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word);
+        }
+        const hipError_t e = me != hipSuccess ? me : hipGetLastError();
+        gpr_dev_free(p, st);
+        if (e != hipSuccess) { gpr_set_error("trsv_chain launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+        return GPR_OK;
+    }
+    if (dinv && nrhs <= TRSV_MAX_RHS) {              // (GPR_TRSV_NO_CHAIN, one block, very large n) one fused launch per block
         void *p;
         int rc = gpr_dev_alloc(&p, (size_t)n * nrhs * sizeof(double), st);
         if (rc) return rc;
