@@ -203,3 +203,31 @@ def test_ws_tail_matches_numpy(m, n):
     dev.check(_lib.lib().gpr_ws_finish(dev.stream_ptr(), m, n, dev.ptr(dP), n, dev.ptr(dQ), n, dev.ptr(dw), dev.ptr(dd),
                                        dev.ptr(out2), vsq), "finish")
     assert np.abs(out2.cpu().numpy() - got).max() < 1e-12 * scale
+
+
+@pytest.mark.parametrize("n", [65, 129, 200, 466, 1516])
+def test_few_rhs_triangular_solves_in_one_launch(n):
+    """gpr_trsm_lower_dinv with <= 8 right-hand sides (alpha = K^-1 y): the chained one-launch form against
+    torch.linalg.solve_triangular, both directions, sizes around the 64-row block edges; a NaN in the data ends as
+    non-finite numbers in the rows that depend on it, not as a wait"""
+    import torch
+    from gpr_calculator_amd import device as dev
+    torch.manual_seed(n)
+    d = dev.device()
+    B = torch.randn(n, max(n // 2, 4), dtype=torch.float64, device=d)
+    A = B @ B.T + torch.eye(n, dtype=torch.float64, device=d) * (0.01 * n + 1.0)
+    L = A.clone()
+    info, dinv = dev.potrf_lower_(L, want_dinv=True)
+    assert int(info.item()) == 0
+    Lt = torch.tril(L)
+    for nrhs in (1, 3, 8):
+        y = torch.randn(n, nrhs, dtype=torch.float64, device=d)
+        for trans in (False, True):
+            x = dev.trsm_lower_(L, y.clone(), trans=trans, dinv=dinv)
+            ref = torch.linalg.solve_triangular(Lt.T if trans else Lt, y, upper=trans)
+            assert float((x - ref).abs().max() / ref.abs().max()) < 1e-12
+    y = torch.randn(n, 2, dtype=torch.float64, device=d)
+    y[n // 3, 0] = float("nan")
+    x = dev.trsm_lower_(L, y.clone(), trans=False, dinv=dinv).cpu().numpy()
+    assert np.isfinite(x[:, 1]).all()                      # the other right-hand side is untouched by it
+    assert not np.isfinite(x[n // 3:, 0]).all() and np.isfinite(x[:(n // 3 // 64) * 64, 0]).all()
