@@ -83,6 +83,16 @@ def force_point_rows(seq, atom):
     return np.argwhere(seq[:, 1] == atom).flatten()
 
 
+def force_point_rows_all(seq, natoms):
+    """force_point_rows(seq, i) for every atom i at once: one stable sort of the second column instead of natoms scans of
+    it (220 scans of 5 000 rows per labelled Pd4 / MgO structure were 7 ms of the 13 an add_structure took).  Same row
+    indices in the same (ascending) order as the scans give."""
+    col = np.asarray(seq[:, 1])
+    order = np.argsort(col, kind="stable")
+    bounds = np.searchsorted(col[order], np.arange(natoms + 1))
+    return [order[bounds[i]:bounds[i + 1]] for i in range(natoms)]
+
+
 def convert_train_data(data, des, N_force=100000):
     """structures -> {"energy": [(x, E/n, ele)], "force": [(x_rows, dxdr_rows, F_i, ele_rows)], "db": [...]}
     (gpr_calc/utilities.py:97-129; its dedup branch is unreachable, so every atom becomes a force
@@ -92,9 +102,10 @@ def convert_train_data(data, des, N_force=100000):
         d = des.calculate(struc)
         ele = species_numbers(d["elements"])
         f_ids = []
+        rows_of = force_point_rows_all(d["seq"], len(struc))
         for i in range(len(struc)):
             if len(force_data) < N_force:
-                ids = force_point_rows(d["seq"], i)
+                ids = rows_of[i]
                 _i = d["seq"][ids, 0]
                 force_data.append((d["x"][_i, :], d["dxdr"][ids], forces[i], ele[_i]))
                 f_ids.append(i)
