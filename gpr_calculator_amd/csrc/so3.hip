@@ -32,6 +32,7 @@
 namespace {
 
 constexpr int SO3_LCAP = 7;      // lmax <= 6  (tables hold l = 0 .. lmax+1)
+constexpr int SO3_NCAP = 6;      // nmax <= 6  (nmax = 5, 6 with lmax <= 3: the <4, 6> instance of the centre kernel)
 constexpr int SO3_NQCAP = 128;   // quadrature nodes: 10*(nmax+lmax+1) <= 128
 constexpr int SO3_WAVES = 4;
 constexpr int SO3_NCHEB = 16;    // Chebyshev coefficients per segment (compile-time: the Clenshaw sum is fully unrolled)
@@ -108,9 +109,9 @@ __global__ void __launch_bounds__(64) so3_radial_direct_kernel(int nmax, int lma
     if (ir >= nr) return;
     const double r = rs[ir];
     const int lt = lmax > 1 ? lmax : 1;
-    double s0[SO3_LCAP * 4], s1[SO3_LCAP * 4];          // [n][l], nmax <= 4 here (checked on the host)
+    double s0[SO3_LCAP * SO3_NCAP], s1[SO3_LCAP * SO3_NCAP];          // [n][l], nmax <= SO3_NCAP (checked on the host)
 #pragma unroll
-    for (int e = 0; e < SO3_LCAP * 4; e++) { s0[e] = 0.0; s1[e] = 0.0; }
+    for (int e = 0; e < SO3_LCAP * SO3_NCAP; e++) { s0[e] = 0.0; s1[e] = 0.0; }
     for (int q = lane; q < nq; q += 64) {
         double b[SO3_LCAP + 1];
         const double rqq = rq[q], xarg = 2.0 * alpha * r * rqq, chain = 2.0 * alpha * rqq, ixarg = 1.0 / xarg;
@@ -120,13 +121,13 @@ __global__ void __launch_bounds__(64) so3_radial_direct_kernel(int nmax, int lma
             if (l <= lmax) {
                 const double db = ((l == 0) ? b[1] : b[l - 1] - (l + 1) * ixarg * b[l]) * chain;   // scipy _spherical_in_d
 #pragma unroll
-                for (int n = 0; n < 4; n++)
+                for (int n = 0; n < SO3_NCAP; n++)
                     if (n < nmax) { const double g = G[n * nq + q]; s0[n * SO3_LCAP + l] += g * b[l]; s1[n * SO3_LCAP + l] += g * db; }
             }
     }
     const double E = 4.0 * M_PI * exp(-alpha * r * r);
 #pragma unroll
-    for (int n = 0; n < 4; n++)
+    for (int n = 0; n < SO3_NCAP; n++)
 #pragma unroll
         for (int l = 0; l < SO3_LCAP; l++)
             if (n < nmax && l <= lmax) {
@@ -817,11 +818,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
 
 int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char *who) {
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1;
-    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > 4 || nq > SO3_NQCAP || nmax * L > so3_nlp(nmax, lmax) ||
+    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > SO3_NCAP || (nmax > 4 && lmax > 3) || nq > SO3_NQCAP || nmax * L > so3_nlp(nmax, lmax) ||
         d * 3 > SO3_SELFW || nmax * L * (L + 1) / 2 > 256 || nseg < 1 || ncheb != SO3_NCHEB) {
         gpr_set_error("%s: (nmax=%d, lmax=%d, nq=%d, nseg=%d, ncheb=%d) outside this build's limits "
-                      "(nmax <= 4, lmax <= %d, nq <= %d, ncoef <= 64, ncheb == %d)",
-                      who, nmax, lmax, nq, nseg, ncheb, SO3_LCAP - 1, SO3_NQCAP, SO3_NCHEB);
+                      "(nmax <= 4 with lmax <= %d, nmax <= %d with lmax <= 3, nq <= %d, ncoef <= 64, ncheb == %d)",
+                      who, nmax, lmax, nq, nseg, ncheb, SO3_LCAP - 1, SO3_NCAP, SO3_NQCAP, SO3_NCHEB);
         return GPR_ERR_UNSUPPORTED;
     }
     return GPR_OK;
@@ -911,6 +912,10 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     }
     int rc = so3_check_limits(nmax, lmax, 1, nseg, ncheb, "gpr_so3_power_spectrum");
     if (rc) return rc;
+    if (rdxdr && nmax > 4) {
+        gpr_set_error("gpr_so3_power_spectrum_stress: stress rows are built for nmax <= 4 (nmax=%d)", nmax);
+        return GPR_ERR_UNSUPPORTED;
+    }
     if (ncentres <= 0) return GPR_OK;
     GPR_REQUIRE(table && centre_pair0 && centre_row0 && row_pair0 && self_row && x && dxdr,
                 "gpr_so3_power_spectrum: null pointer");
@@ -934,6 +939,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
+        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<4, SO3_NCAP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         attr_set = true;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
@@ -943,7 +949,8 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
     } else {
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
-        else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+        else if (nmax <= 4) hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
+        else hipLaunchKernelGGL((so3_centre_kernel<4, SO3_NCAP, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);   // nmax 5, 6: lmax <= 3
     }
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();

@@ -85,6 +85,11 @@ def structures():
     cell = np.array([[4.2, 0, 0], [1.3, 3.9, 0], [0.4, 0.7, 4.4]])
     out["triclinic_mgo"] = dict(numbers=[12, 8, 12, 8], positions=rng.uniform(0, 1, (4, 3)) @ cell, cell=cell,
                                 pbc=[True] * 3, nmax=3, lmax=4, rcut=4.5, alpha=2.0, stress=False)
+    # nmax = 5 and 6 (ncoef = 60 and 63: what the 64-column operand plane leaves beyond nmax = 4)
+    out["cluster_n5l3"] = dict(numbers=[46, 8, 12, 8, 46, 12], positions=clu, cell=np.zeros((3, 3)),
+                               pbc=[False] * 3, nmax=5, lmax=3, rcut=4.0, alpha=2.0, stress=False)
+    out["fcc4_n6l2"] = dict(numbers=[46, 78, 46, 46], positions=fcc + np.random.default_rng(7).normal(0, 0.1, (4, 3)),
+                            cell=np.eye(3) * a, pbc=[True] * 3, nmax=6, lmax=2, rcut=5.0, alpha=2.0, stress=False)
     return out
 
 
@@ -105,10 +110,14 @@ def main():
     payload["K_ff_dot"] = dot.K_ff(x1, x1, dx1, dx1, 2.0 ** 2, 2.0 ** 2, 2.0, mask)
     payload["K_ee_RBF_z3"] = base.K_ee_RBF(x1, x1, 1.7 ** 2, 0.9 ** 2, 3.0, mask=mask)
     payload["K_ff_dot_z3"] = dot.K_ff(x1, x1, dx1, dx1, 1.7 ** 2, 1.5 ** 2, 3.0, mask)
-    np.savez_compressed(os.path.join(HERE, "diag_helpers.npz"), **payload)
-    print("diag_helpers.npz", payload["K_ee_RBF"], payload["K_ee_dot"], payload["K_ff_dot"][0])
+    if not sys.argv[1:]:
+        np.savez_compressed(os.path.join(HERE, "diag_helpers.npz"), **payload)
+        print("diag_helpers.npz", payload["K_ee_RBF"], payload["K_ee_dot"], payload["K_ff_dot"][0])
     # ---- SO3
+    only = sys.argv[1:]                                          # fixture names: write just these (the others stay as committed)
     for name, s in structures().items():
+        if only and name not in only:
+            continue
         atoms = SimpleAtoms(s["numbers"], s["positions"], s["cell"], s["pbc"])
         des = so3.SO3(nmax=s["nmax"], lmax=s["lmax"], rcut=s["rcut"], alpha=s["alpha"], derivative=True,
                       stress=s["stress"])

@@ -183,12 +183,13 @@ def test_so3_other_configurations_match_oracle(cfg):
             assert rel(out["rdxdr"], ref["rdxdr"]) < REL
 
 
-@pytest.mark.parametrize("cfg", [(4, 4, 4.0, 2.0), (3, 6, 4.2, 1.5), (4, 5, 4.0, 2.0), (4, 3, 5.0, 2.0)],
-                         ids=["n4l4_d50", "n3l6_d42", "n4l5_d60", "n4l3_d40"])
+@pytest.mark.parametrize("cfg", [(4, 4, 4.0, 2.0), (3, 6, 4.2, 1.5), (4, 5, 4.0, 2.0), (4, 3, 5.0, 2.0), (5, 3, 4.0, 2.0),
+                                 (6, 2, 5.0, 2.0), (5, 1, 5.0, 1.5), (6, 0, 4.0, 2.0)],
+                         ids=["n4l4_d50", "n3l6_d42", "n4l5_d60", "n4l3_d40", "n5l3_d60", "n6l2_d63", "n5l1_d30", "n6l0_d21"])
 def test_so3_long_descriptors_match_oracle(cfg):
     """more than 32 power-spectrum components (up to 64) and more than 16 radial-angular channels (up to 28): the wider
-    record layout of the general kernel instance, periodic cell; the reference's own SO3 pins the (4, 4) case through
-    tests/golden/so3_*_n4l4.npz"""
+    record layout of the general kernel instance, periodic cell; nmax = 5 and 6 (lmax <= 3) take the third instance.  The
+    reference's own SO3 pins (4, 4), (5, 3) and (6, 2) through tests/golden/so3_*_n4l4 / _n5l3 / _n6l2.npz"""
     from gpr_calculator_amd.SO3 import SO3
     from gpr_calculator_amd.synthetic import fcc_cell
     from oracle.so3_numpy import so3_calculate
@@ -218,6 +219,9 @@ def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
     assert nod["dxdr"] is None and nod["rdxdr"] is None and "seq" not in nod and np.array_equal(nod["x"], full["x"])
     with pytest.raises(NotImplementedError):
         SO3(nmax=4, lmax=6, rcut=5.0)             # ncoef = 70: beyond the device kernels, said at construction
+    with pytest.raises(NotImplementedError):
+        SO3(nmax=7, lmax=0, rcut=5.0)             # nmax > 6
+    assert SO3(nmax=6, lmax=2, rcut=5.0).ncoefs == 63
     assert SO3(nmax=4, lmax=4, rcut=5.0).ncoefs == 50
 
 
