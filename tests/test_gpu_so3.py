@@ -225,10 +225,13 @@ def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
     assert SO3(nmax=4, lmax=4, rcut=5.0).ncoefs == 50
 
 
-def test_gp_end_to_end_with_a_50_component_descriptor(port_natives):
-    """SO3(nmax=4, lmax=4) -> 64-column operand planes of the covariance kernels -> fit -> predict, against the oracle
-    (numpy descriptor + plain-C natives + scipy) on the same structures; RBF and Dot (pair route: the degree-2 feature map
-    covers 32 columns)"""
+@pytest.mark.parametrize("nl", [(4, 4), (6, 2)], ids=["n4l4_d50", "n6l2_d63"])
+def test_gp_end_to_end_with_a_long_descriptor(port_natives, nl):
+    """SO3(nmax=4, lmax=4) / SO3(nmax=6, lmax=2) -> 64-column operand planes of the covariance kernels -> fit -> predict,
+    against the oracle (numpy descriptor + plain-C natives + scipy) on the same structures; RBF and Dot (pair route: the
+    degree-2 feature map covers 32 columns)"""
+    NMAX, LMAX = nl
+    NCOEF = NMAX * (NMAX + 1) // 2 * (LMAX + 1)
     from gpr_calculator_amd.gaussianprocess import GP
     from gpr_calculator_amd.SO3 import SO3
     from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
@@ -243,13 +246,13 @@ def test_gp_end_to_end_with_a_50_component_descriptor(port_natives):
     test = fcc_cell(seed=9, reps=1, species=(46, 78), sigma=0.08)
 
     def odesc(a):
-        d = so3_calculate(a.numbers, a.positions, a.cell, a.pbc, 4, 4, 5.0, 2.0)
+        d = so3_calculate(a.numbers, a.positions, a.cell, a.pbc, NMAX, LMAX, 5.0, 2.0)
         return d, species_numbers([symbol_of(z) for z in a.numbers])
     for kern, okern in ((RBF_mb(para=[2.5, 1.3], zeta=2.0), og.OracleRBF(para=(2.5, 1.3), zeta=2.0, natives=port_natives)),
                         (Dot_mb(para=[2.0, 2.0], zeta=2.0), og.OracleDot(para=(2.0, 2.0), zeta=2.0, natives=port_natives))):
-        gp = GP(kernel=kern, descriptor=SO3(nmax=4, lmax=4, rcut=5.0), noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
+        gp = GP(kernel=kern, descriptor=SO3(nmax=NMAX, lmax=LMAX, rcut=5.0), noise_e=0.002, noise_f=0.1, log_file="/tmp/gpr_test.log")
         gp.fit(gp.points_from_structures([(a, E, F, True, [0, 2]) for a, (E, F) in zip(strucs, labels)]), show=False, opt=False)
-        assert gp.train_x["force"][0].shape[1] == 50
+        assert gp.train_x["force"][0].shape[1] == NCOEF
         energy, force, y = [], [], []
         for a, (E, F) in zip(strucs, labels):
             d, ele = odesc(a)
