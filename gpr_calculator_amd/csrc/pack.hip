@@ -9,6 +9,7 @@
 // a~^T B' = dd/dx2^T dx2dr -- so one 4x4 product [A'^T; a~^T][B', b~] carries everything the
 // reference's O(d^2) loop nest computes.
 #include <algorithm>
+#include <cstring>
 #include <cstdarg>
 #include <numeric>
 #include <mutex>
@@ -357,16 +358,8 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     s->nchunks = (int)chunks.size();
 
     int rc = GPR_OK;
-    long long bytes = 0;
-    int *d_src = nullptr;
     auto fail = [&](int code) { gpr_set_destroy(s, stream); return code; };
-    if ((rc = upload(&d_src, src_row, st, &bytes))) return fail(rc);
-    bytes -= (long long)(src_row.size() * sizeof(int));   // temporary
-    if ((rc = upload(&s->perm, s->h_perm, st, &bytes))) return fail(rc);
-    if ((rc = upload(&s->inv_cnt, inv_cnt, st, &bytes))) return fail(rc);
     if (role == GPR_ROLE_STREAM) {
-        if ((rc = upload(&s->chunks, chunks, st, &bytes))) return fail(rc);
-        if ((rc = upload(&s->pt_chunk0, s->h_pt_chunk0, st, &bytes))) return fail(rc);
         // launch ranges: consecutive packed points, about 128 tiles each (one task = range x resident block); small
         // sets are cut finer (down to 8 tiles) so that a launch against them still has a few dozen ranges to spread
         // over the CUs -- the resident side contributes only npts / (points per wave unit) / NW blocks
@@ -380,24 +373,54 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
         }
         irc.push_back(s->nchunks); irp.push_back(npts);
         s->nranges = (int)irc.size() - 1;
-        if ((rc = upload(&s->ir_chunk0, irc, st, &bytes))) return fail(rc);
-        if ((rc = upload(&s->ir_pt0, irp, st, &bytes))) return fail(rc);
-    } else {
-        if ((rc = upload(&s->rpts, rpts, st, &bytes))) return fail(rc);
-        if ((rc = upload(&s->wu_pt0, wu_pt0, st, &bytes))) return fail(rc);
-        if ((rc = upload(&s->rowpt, rowpt, st, &bytes))) return fail(rc);
     }
-    size_t planes = (size_t)s->nunits * (role == GPR_ROLE_RESIDENT ? s->nc : 1);
-    size_t ops_bytes = planes * plane * sizeof(double);
+    // one allocation: [index arrays, uploaded in one copy | ele | norms | operand planes]
+    std::vector<char> &hb = s->hk_blob;
+    hb.clear();
+    auto put = [&](const void *src, size_t nbytes) {              // 16-byte aligned pieces; returns the offset
+        const size_t off = (hb.size() + 15) & ~(size_t)15;
+        hb.resize(off + nbytes);
+        if (nbytes) memcpy(hb.data() + off, src, nbytes);
+        return off;
+    };
+    const size_t o_src = put(src_row.data(), src_row.size() * sizeof(int));
+    const size_t o_perm = put(s->h_perm.data(), s->h_perm.size() * sizeof(int));
+    const size_t o_inv = put(inv_cnt.data(), inv_cnt.size() * sizeof(double));
+    size_t o_a = 0, o_b = 0, o_c = 0, o_d = 0;
+    if (role == GPR_ROLE_STREAM) {
+        o_a = put(chunks.data(), chunks.size() * sizeof(gpr_chunk));
+        o_b = put(s->h_pt_chunk0.data(), s->h_pt_chunk0.size() * sizeof(int));
+        o_c = put(s->hk_irc.data(), s->hk_irc.size() * sizeof(int));
+        o_d = put(s->hk_irp.data(), s->hk_irp.size() * sizeof(int));
+    } else {
+        o_a = put(rpts.data(), rpts.size() * sizeof(gpr_rpoint));
+        o_b = put(wu_pt0.data(), wu_pt0.size() * sizeof(int));
+        o_c = put(rowpt.data(), rowpt.size() * sizeof(int));
+    }
+    const size_t up_bytes = hb.size();
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t planes = (size_t)s->nunits * (role == GPR_ROLE_RESIDENT ? s->nc : 1);
+    const size_t ops_bytes = planes * plane * sizeof(double);
+    const size_t o_ele = al(up_bytes), o_norms = al(o_ele + (size_t)s->rpad * sizeof(int));
+    const size_t o_ops = al(o_norms + (size_t)s->rpad * sizeof(double)), total = o_ops + ops_bytes;
     void *p;
-    if ((rc = gpr_dev_alloc(&p, ops_bytes, st))) return fail(rc);
-    s->ops = (double *)p; bytes += (long long)ops_bytes;
-    if ((rc = gpr_dev_alloc(&p, (size_t)s->rpad * sizeof(int), st))) return fail(rc);
-    s->ele = (int *)p; bytes += (long long)s->rpad * 4;
-    if ((rc = gpr_dev_alloc(&p, (size_t)s->rpad * sizeof(double), st))) return fail(rc);
-    s->norms = (double *)p; bytes += (long long)s->rpad * 8;
-    s->bytes = bytes;
-
+    if ((rc = gpr_dev_alloc(&p, total, st))) return fail(rc);
+    s->blob = p;
+    char *base = (char *)p;
+    if (up_bytes) {
+        const hipError_t ce = hipMemcpyAsync(base, hb.data(), up_bytes, hipMemcpyHostToDevice, st);
+        if (ce != hipSuccess) { gpr_set_error("gpr_set_create: upload failed: %s", hipGetErrorString(ce)); return fail(GPR_ERR_HIP); }
+    }
+    int *d_src = (int *)(base + o_src);
+    s->perm = (int *)(base + o_perm); s->inv_cnt = (double *)(base + o_inv);
+    if (role == GPR_ROLE_STREAM) {
+        s->chunks = (gpr_chunk *)(base + o_a); s->pt_chunk0 = (int *)(base + o_b);
+        s->ir_chunk0 = (int *)(base + o_c); s->ir_pt0 = (int *)(base + o_d);
+    } else {
+        s->rpts = (gpr_rpoint *)(base + o_a); s->wu_pt0 = (int *)(base + o_b); s->rowpt = (int *)(base + o_c);
+    }
+    s->ele = (int *)(base + o_ele); s->norms = (double *)(base + o_norms); s->ops = (double *)(base + o_ops);
+    s->bytes = (long long)(total - (o_perm - o_src));           // (the source-row map is only read by the pack kernel)
     if (s->rpad > 0) {
         pack_args a;
         a.x = x_dev; a.dxdr = dxdr_dev; a.ele = ele_dev; a.src_row = d_src;
@@ -417,7 +440,6 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
             return fail(GPR_ERR_HIP);
         }
     }
-    gpr_dev_free(d_src, st);          // stream-ordered: released after the pack kernel has read it
     *out = s;
     return GPR_OK;
 }
@@ -446,11 +468,8 @@ extern "C" int gpr_set_destroy(gpr_set *s, void *stream) {
     if (!s) return GPR_OK;
     hipStream_t st = (hipStream_t)stream;
     // stream-ordered frees: kernels already queued on `st` still see the arrays
-    gpr_dev_free(s->ops, st); gpr_dev_free(s->ele, st); gpr_dev_free(s->norms, st);
-    gpr_dev_free(s->perm, st); gpr_dev_free(s->inv_cnt, st); gpr_dev_free(s->chunks, st);
-    gpr_dev_free(s->pt_chunk0, st); gpr_dev_free(s->rpts, st); gpr_dev_free(s->wu_pt0, st); gpr_dev_free(s->rowpt, st);
-    gpr_dev_free(s->ir_chunk0, st); gpr_dev_free(s->ir_pt0, st);
-    s->ops = nullptr;
+    gpr_dev_free(s->blob, st);                                  // every device array of the set is a piece of it
+    s->blob = nullptr; s->ops = nullptr;
     hipEvent_t ev;
     if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, st) == hipSuccess) {
         std::lock_guard<std::mutex> lk(g_dead_mu);
