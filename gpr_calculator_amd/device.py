@@ -25,7 +25,15 @@ def device():
     return d
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """torch's current stream of the current device as a raw handle.  Asked some twenty times per prediction of the
+    pair-kernel route: the two C entry points cost 0.3 us where building a torch.cuda.Stream object cost 8."""
+    if _raw_stream is not None and _cur_device is not None:
+        return C.c_void_p(_raw_stream(_cur_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
