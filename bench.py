@@ -195,7 +195,7 @@ def dry_run(args):
     seen = comm.allreduce(np.eye(comm.size)[comm.rank])          # one tensor all-reduce: 1 at every rank that took part
     comm.barrier()
     if comm.rank == 0:
-        print(json.dumps({"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": None, "dry_run": True,
+        print(json.dumps({"metric": "GPR predict E+F+sigma structures/sec at N_train=%d" % args.n_train, "value": None, "dry_run": True,
                           "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup,
                           "config": {"ranks": comm.size, "ranks_seen": [int(v) for v in np.atleast_1d(seen)],
                                      "backend": torch.distributed.get_backend() if comm.size > 1 else None}}))
@@ -285,7 +285,8 @@ def main():
 
     # untimed: a few priming steps before the W warm-up steps the caller asked for (first call sizes the neighbour
     # tables exactly and records the capacities later calls guess from; clocks and the stream-ordered pool settle)
-    for _ in range(max(0, 30 - args.warmup) if args.kernel == "Dot" else 0):
+    n_prime = max(0, 30 - args.warmup) if args.kernel == "Dot" else 0
+    for _ in range(n_prime):
         step()
     run(args.warmup)
     comm.barrier()
@@ -467,11 +468,20 @@ def main():
                                           "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_MFMA_PEAK_TFLOPS,
                                           "ms_per_step": pr_ms, "structures_per_s": args.batch / (pr_ms * 1e-3),
                                           "work_unit": "1.10 kflop per same-species row pair (SURVEY.md section 8d)"}
-        line = {"metric": "GPR predict E+F+sigma structures/sec at N_train=2000", "value": value,
+        shape = {500: "cfg2", 2000: "cfg3", 8000: "cfg4"}.get(args.n_train, "cfg3-shaped")
+        line = {"metric": "GPR predict E+F+sigma structures/sec at N_train=%d" % args.n_train, "value": value,
                 "unit": "structures/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                # untimed steps actually run before the timed region: the caller's W plus the priming steps above
+                "untimed_steps_before_timing": args.warmup + n_prime,
+                # the same batch through the synchronous call (one batch at a time: what rounds 1-2 reported as `value` and
+                # what an optimiser step sees); `value` is the throughput form with `batches_in_flight` batches queued
+                "value_sync": world * args.batch / (sync_ms * 1e-3), "sync_ms_per_step": sync_ms,
+                # N > 1: `value` is N replicas by construction; the informative figures are ONE batch over N ranks and the
+                # N-rank fit
+                "strong_predict": strong, "fit_ms_all_ranks": {"weight_space": fit_ms, "dense": fit_dense_ms},
                 "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f64", "data": "synthetic",
-                "config": {"workload": f"cfg3: N_train={args.n_train} force environments + {len(gp.train_x['energy'][-1])} "
+                "config": {"workload": f"{shape}: N_train={args.n_train} force environments + {len(gp.train_x['energy'][-1])} "
                                        f"energy points (N={N}), {args.kernel} kernel zeta=2, SO3(3,4,5.0), predict "
                                        f"E/F/sigma batch of {args.batch} 32-atom structures per GPU",
                            "kernel": args.kernel, "n_train": args.n_train, "batch_per_gpu": args.batch, "N": int(N),

@@ -56,6 +56,10 @@ _L1_SIGNATURES = {
     "gpr_dot2_session_wait": ([_vp, _i, _vp, _vp, _vp, _vp, _vp], _i),
     "gpr_dot2_session_set_depth": ([_vp, _i], _i),
     "gpr_dot2_session_destroy": ([_vp], _i),
+    "gpr_dot2_session_slot_stream": ([_vp, _i], _vp),
+    "gpr_dev_cache_count": ([_vp, _i], _i),
+    "gpr_trsv_chain_fallbacks": ([], _i),
+    "gpr_trsv_debug_max_polls": ([_i], _i),
     "gpr_potrf_set_polling": ([_i], _i),
     "gpr_potrf_polling": ([], _i),
     "gpr_potrf_debug_max_polls": ([_i], _i),
@@ -88,6 +92,8 @@ _L1_SIGNATURES = {
     "gpr_nbr_destroy": ([_vp], _i),
     "gpr_nbr_build_device_rows": ([C.POINTER(_vp), _vp, _i, _vp, _vp, _vp, _vp, _vp, _d, _i, _i, _i, _vp, _vp, C.POINTER(_i)], _i),
     "gpr_nbr_set_fused": ([_i], _i),
+    "gpr_nbr_fused_state": ([c_int_p, c_int_p], _i),
+    "gpr_nbr_debug_fused_capacity": ([_i], _i),
     "gpr_dot2_features": ([_vp, _vp, _i, c_int_p, _d, _vp, _ll], _i),
     "gpr_set_shard": ([_i, _i], _i),
     "gpr_profile_enable": ([_i], _i),

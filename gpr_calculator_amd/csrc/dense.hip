@@ -1337,11 +1337,7 @@ int gpr_syrk_bulk_internal(hipStream_t st, int m, int k, const double *P, long l
     GPR_REQUIRE(k % SB_K == 0 && nwg >= 1, "gpr_syrk_bulk: k must be a multiple of %d", SB_K);
     const int nbt = (m + SB_T - 1) / SB_T, ntile = nbt * (nbt + 1) / 2;
     constexpr int pad_bytes = 16 * 1024;                      // static 69.6 KB + 16 KB: two of these do not fit 160 KB
-    static bool attr = false;
-    if (!attr) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)syrk_bulk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, pad_bytes));
-        attr = true;
-    }
+    { const int rc_ = gpr_func_lds_once((const void *)syrk_bulk_kernel, pad_bytes); if (rc_) return rc_; }
     hipLaunchKernelGGL(syrk_bulk_kernel, dim3(std::min(ntile, nwg)), dim3(512), pad_bytes, st, m, k, P, ldp, C, ldc);
     LAUNCH_CHECK("syrk_bulk");
     return GPR_OK;
@@ -1413,11 +1409,14 @@ __global__ void __launch_bounds__(256) trsv_step_kernel(const double *__restrict
 // numbers.  The L tile of the next step and the inverse of the own diagonal block depend on no solution and are requested ahead;
 // between two publications sit one poll, the last 64 x 64 update and the diagonal product.  A step of the launch-per-block form
 // costs a launch (15 us, 95 of them at N = 6063).  Workgroups only wait for lower ids, which the dispatcher starts first; a wait
-// that outlasts TRSV_CHAIN_POLLS or finds the abort word set gives up, raises it, and its rows end as NaNs (as do all later ones).
+// that outlasts the poll budget or finds the abort word set gives up and raises it; its rows of b stay what they were (so do
+// those of every later block, which all wait for it) and trsv_fixup_kernel, queued right behind, finishes the solve from there.
 constexpr int TRSV_CHAIN_POLLS = 1 << 22;
+static int g_trsv_max_polls = TRSV_CHAIN_POLLS;
 template <bool TRANS>
 __global__ void __launch_bounds__(256) trsv_chain_kernel(const double *__restrict__ dinv, const double *__restrict__ l, long long ldl,
-                                                          double *b, long long ldb, int nrhs, int n, double *xs, int *abort_word) {
+                                                          double *b, long long ldb, int nrhs, int n, double *xs, int *abort_word,
+                                                          int max_polls) {
     __shared__ double T[NB][NB + 1];
     __shared__ double X[NB][TRSV_MAX_RHS + 1];
     __shared__ int s_bad;
@@ -1451,7 +1450,7 @@ __global__ void __launch_bounds__(256) trsv_chain_kernel(const double *__restric
                 int polls = 0;
                 v = __hip_atomic_load(&xs[(size_t)row * nrhs + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 while (v != v) {
-                    if (++polls > TRSV_CHAIN_POLLS || ((polls & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+                    if (++polls > max_polls || ((polls & 63) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
                         s_bad = 1;
                         break;
                     }
@@ -1492,18 +1491,81 @@ __global__ void __launch_bounds__(256) trsv_chain_kernel(const double *__restric
         }
         // a NaN of the data itself (a factor that is not one) is published as an infinity: "not there yet" stays unambiguous
         // and the consumers end with non-finite numbers instead of waiting
-        const double bad = __builtin_nan(""), inf = __builtin_inf();
-        if (j0 < nrhs) {
-            b[(long long)(k0 + c) * ldb + j0] = ok ? x0 : bad;
-            if (ok) __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j0], x0 == x0 ? x0 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double inf = __builtin_inf();
+        if (j0 < nrhs && ok) {
+            b[(long long)(k0 + c) * ldb + j0] = x0;
+            __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j0], x0 == x0 ? x0 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (j1 < nrhs) {
-            b[(long long)(k0 + c) * ldb + j1] = ok ? x1 : bad;
-            if (ok) __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j1], x1 == x1 ? x1 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j1 < nrhs && ok) {
+            b[(long long)(k0 + c) * ldb + j1] = x1;
+            __hip_atomic_store(&xs[(size_t)(k0 + c) * nrhs + j1], x1 == x1 ? x1 : inf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     if (!ok && tid == 0) __hip_atomic_store(abort_word, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// Queued behind every trsv_chain_kernel: one workgroup that returns at once unless the abort word is up.  If it is, some block
+// of the chain gave up waiting; that block and all later ones have left their rows of b as they were and their part of xs
+// as NaNs, the earlier ones are solved and published.  The substitution is finished here block by block, in order, from
+// exactly that state -- slower than the chain (one workgroup), but the caller gets the solution, never NaNs, and the count of
+// such rescues (`fallbacks`, page-locked host memory) is there for anyone who wants to know (gpr_trsv_chain_fallbacks).
+template <bool TRANS>
+__global__ void __launch_bounds__(256) trsv_fixup_kernel(const double *__restrict__ dinv, const double *__restrict__ l, long long ldl,
+                                                          double *b, long long ldb, int nrhs, int n, double *xs, const int *abort_word,
+                                                          int *fallbacks) {
+    if (*abort_word == 0) return;
+    __shared__ double A[NB][TRSV_MAX_RHS + 1];
+    const int tid = threadIdx.x, nblk = (n + NB - 1) / NB;
+    for (int id = 0; id < nblk; id++) {
+        const int blk = TRANS ? nblk - 1 - id : id, k0 = blk * NB, kb = min(NB, n - k0);
+        const double first = __hip_atomic_load(&xs[(size_t)k0 * nrhs], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (first == first) continue;                            // solved and published by the chain
+        for (int e = tid; e < NB * nrhs; e += 256) {
+            const int r = e / nrhs, j = e - r * nrhs;
+            double acc = 0.0;
+            if (r < kb) {
+                acc = b[(long long)(k0 + r) * ldb + j];
+                const int q0 = TRANS ? k0 + kb : 0, q1 = TRANS ? n : k0;    // rows solved before this block
+                for (int q = q0; q < q1; q++) {
+                    const double lv = TRANS ? l[(long long)q * ldl + k0 + r] : l[(long long)(k0 + r) * ldl + q];
+                    acc = fma(-lv, __hip_atomic_load(&xs[(size_t)q * nrhs + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), acc);
+                }
+            }
+            A[r][j] = acc;
+        }
+        __syncthreads();
+        const double *W = dinv + (size_t)blk * NB * NB;
+        for (int e = tid; e < NB * nrhs; e += 256) {
+            const int r = e / nrhs, j = e - r * nrhs;
+            if (r < kb) {
+                double x = 0.0;
+                for (int q = 0; q < NB; q++) x = fma(TRANS ? W[q * NB + r] : W[r * NB + q], A[q][j], x);
+                b[(long long)(k0 + r) * ldb + j] = x;
+                __hip_atomic_store(&xs[(size_t)(k0 + r) * nrhs + j], x == x ? x : __builtin_inf(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+    if (tid == 0) __hip_atomic_fetch_add(fallbacks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// how often trsv_fixup_kernel had to finish a solve (process-wide; page-locked, read by the host without a device call)
+static int *g_trsv_fallbacks = nullptr, *g_trsv_fallbacks_dev = nullptr;
+static std::mutex g_trsv_mu;
+static int trsv_fallback_word(int **dev_ptr) {
+    std::lock_guard<std::mutex> lk(g_trsv_mu);
+    if (!g_trsv_fallbacks) {
+        GPR_HIP_TRY(hipHostMalloc((void **)&g_trsv_fallbacks, sizeof(int), hipHostMallocDefault));
+        *g_trsv_fallbacks = 0;
+        GPR_HIP_TRY(hipHostGetDevicePointer((void **)&g_trsv_fallbacks_dev, g_trsv_fallbacks, 0));
+    }
+    *dev_ptr = g_trsv_fallbacks_dev;
+    return GPR_OK;
+}
+extern "C" int gpr_trsv_chain_fallbacks(void) { return g_trsv_fallbacks ? __atomic_load_n(g_trsv_fallbacks, __ATOMIC_ACQUIRE) : 0; }
+// tests: polls a block of the one-launch solve may spend on a predecessor before it gives up (<= 0: the default)
+extern "C" int gpr_trsv_debug_max_polls(int polls) { g_trsv_max_polls = polls > 0 ? polls : TRSV_CHAIN_POLLS; return GPR_OK; }
 
 __global__ void trsv_copy_kernel(int n, int nrhs, const double *xs, double *b, long long ldb) {
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1525,11 +1587,21 @@ extern "C" int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, con
         if (rc) return rc;
         double *xs = (double *)p;
         int *abort_word = (int *)((char *)p + xs_bytes);
-        hipError_t me = hipMemsetAsync(xs, 0xFF, xs_bytes, st);  // NaNs: "not published yet"
+        int *fb = nullptr;
+        if ((rc = trsv_fallback_word(&fb))) { gpr_dev_free(p, st); return rc; }
+        // NaNs in xs: "not published yet"; the 16 bytes behind it hold the abort word and must start as zero -- one fill for
+        // both would need two patterns, so the abort word gets its own
+        hipError_t me = hipMemsetAsync(xs, 0xFF, xs_bytes, st);
         if (me == hipSuccess) me = hipMemsetAsync(abort_word, 0, sizeof(int), st);
         if (me == hipSuccess) {
-            if (trans) hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word);
-            else hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word);
+            const int polls = g_trsv_max_polls;
+            if (trans) {
+                hipLaunchKernelGGL(trsv_chain_kernel<true>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word, polls);
+                hipLaunchKernelGGL(trsv_fixup_kernel<true>, dim3(1), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word, fb);
+            } else {
+                hipLaunchKernelGGL(trsv_chain_kernel<false>, dim3(nblk), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word, polls);
+                hipLaunchKernelGGL(trsv_fixup_kernel<false>, dim3(1), dim3(256), 0, st, dinv, l, ldl, b, ldb, nrhs, n, xs, abort_word, fb);
+            }
         }
         const hipError_t e = me != hipSuccess ? me : hipGetLastError();
         gpr_dev_free(p, st);
@@ -1709,12 +1781,9 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
     if (m <= 0) return status_only();
     GPR_REQUIRE(n > 0 && out && P && Cinv && w && diag && ldp >= n && ldc >= n && vsq > 0.0, "gpr_ws_tail: bad arguments");
     constexpr int R = WT_ROWS;
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)wt_lds_bytes<R>()));
-        attr_set = true;
-    }
+    { int rc_ = gpr_func_lds_once((const void *)ws_tail_kernel<R, 0>, (int)wt_lds_bytes<R>());
+      if (!rc_) rc_ = gpr_func_lds_once((const void *)ws_tail_kernel<R, 1>, (int)wt_lds_bytes<R>());
+      if (rc_) return rc_; }
     const int nrb = (m + R - 1) / R, ncb = (n + WT_C - 1) / WT_C;
     // The row-resident kernel needs no exchange between workgroups, so it also serves a handful of rows (one structure:
     // four workgroups) whenever the shape allows it; the split form below stays for the other shapes.
@@ -1738,12 +1807,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         int rc = gpr_dev_alloc(&wsp, ws_bytes, st);
         if (rc) return rc;
         double *part = (double *)wsp, *mn = part + (size_t)nparts * m;
-        static bool attrf = false;
-        if (!attrf) {
-            const hipError_t ae = hipFuncSetAttribute((const void *)ws_tail_few_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tf_lds_bytes());
-            if (ae != hipSuccess) { gpr_dev_free(wsp, st); gpr_set_error("gpr_ws_tail: %s", hipGetErrorString(ae)); return GPR_ERR_HIP; }
-            attrf = true;
-        }
+        if ((rc = gpr_func_lds_once((const void *)ws_tail_few_kernel, (int)tf_lds_bytes()))) { gpr_dev_free(wsp, st); return rc; }
         const int pid = gpr_prof_begin(st, GPR_PROF_GEMM);
         if (staged)
             hipLaunchKernelGGL((ws_tail_kernel<R, 1>), dim3(ncb, nrb), dim3(256), wt_lds_bytes<R>(), st, m, n, P, ldp, Cinv, ldc, w, diag,
@@ -1761,12 +1825,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
     if (rows_ok && tail_form == 0) {
         // many rows, row-resident form: one launch, P read once, no barrier in the product loop
         const size_t lds = trw_lds_doubles(n) * sizeof(double);
-        static bool attr3 = false;
-        if (!attr3) {
-            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)(trw_lds_doubles(TRW_NMAX) * sizeof(double))));
-            attr3 = true;
-        }
+        { const int rc_ = gpr_func_lds_once((const void *)ws_tail_rows_kernel, (int)(trw_lds_doubles(TRW_NMAX) * sizeof(double))); if (rc_) return rc_; }
         int *done = nullptr;
         if (status_dst) {
             done = tail_stream_counters(st);
@@ -1785,12 +1844,9 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         // C^-1 bytes per flop of the 32-row form), their sums are combined by a second small launch
         constexpr int R2 = 64, NW2 = 8;
         constexpr size_t lds2 = wt_lds_bytes<R2, NW2>();
-        static bool attr2 = false;
-        if (!attr2) {
-            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_kernel<R2, 2, NW2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-            GPR_HIP_TRY(hipFuncSetAttribute((const void *)ws_tail_glds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)tg_lds_bytes()));
-            attr2 = true;
-        }
+        { int rc_ = gpr_func_lds_once((const void *)ws_tail_kernel<R2, 2, NW2>, (int)lds2);
+          if (!rc_) rc_ = gpr_func_lds_once((const void *)ws_tail_glds_kernel, (int)tg_lds_bytes());
+          if (rc_) return rc_; }
         // tiles by LDS DMA where the shape allows 16-byte pieces (always, for the degree-2 feature rows: F is even)
         static const bool no_glds = getenv("GPR_TAIL_NO_GLDS") != nullptr;
         const bool glds = !no_glds && n <= 512 && n % 2 == 0 && ldp % 2 == 0 && ldc % 2 == 0 &&
@@ -1803,7 +1859,7 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
         // arrival counter of the combine launch: in this call's workspace, zeroed by the tail kernel
         int *done = (int *)(mn + 2 * (size_t)m);
         const int pid2 = gpr_prof_begin(st, GPR_PROF_GEMM);
-        static const int tail_dbg = getenv("GPR_TAIL_DBG") ? atoi(getenv("GPR_TAIL_DBG")) : 0;
+        static const int tail_dbg = GPR_PHASE_ENV("GPR_TAIL_DBG");     // tools build only (gpr_internal.h); 0 otherwise
         if (glds)
             hipLaunchKernelGGL(ws_tail_glds_kernel, dim3(npart, nrb2), dim3(64 * TG_NW), tg_lds_bytes(), st, m, n, P, ldp, Cinv, ldc, w,
                                part, mn, done, tail_dbg);

@@ -106,6 +106,17 @@ struct gpr_block_call {
 // zero-fills nothing: the caller has already zeroed the output; bins are accumulated with RMW adds
 int gpr_launch_block(hipStream_t st, const gpr_block_call &c);
 
+// Phase-ablation exits of the large kernels (profiling: "how long does the kernel take up to here").  They exist only in a
+// tools build (make ABLATION=1 -> -DGPR_PHASE_ABLATION, then GPR_SO3_DBG / GPR_NBR_DBG / GPR_TAIL_DBG select the phase); the
+// production library has no such branch and does not read those variables -- a stray one cannot change a result.
+#ifdef GPR_PHASE_ABLATION
+#define GPR_PHASE_EXIT(dbg_, k_) if ((dbg_) == (k_)) return;
+#define GPR_PHASE_ENV(name_) (getenv(name_) ? atoi(getenv(name_)) : 0)
+#else
+#define GPR_PHASE_EXIT(dbg_, k_)
+#define GPR_PHASE_ENV(name_) 0
+#endif
+
 // profiling kinds of gpr_profile_fetch (kernel-only HIP-event timing, see include/gpr_hip.h)
 enum gpr_prof_kind { GPR_PROF_FF = 0, GPR_PROF_EF = 1, GPR_PROF_EE = 2, GPR_PROF_DIAG = 3, GPR_PROF_TRMM = 4,
                      GPR_PROF_GEMM = 5, GPR_PROF_SO3 = 6, GPR_PROF_FEATURES = 7, GPR_PROF_PACK = 8, GPR_PROF_GEMV = 9,
@@ -125,6 +136,10 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
                          double *status_dst, int std_out);
 
 // small helpers
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device): code objects are loaded per device, so a
+// process-wide "done" flag would leave the second device of a process at the 64 KB default
+int gpr_func_lds_once(const void *fn, int bytes);
+int gpr_cu_count();                                 // compute units of the current device (cached per device)
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
 int gpr_dev_free(void *p, hipStream_t st);
 int gpr_dev_cache_drop_stream(hipStream_t st);      // before hipStreamDestroy: cached temporaries of that stream go back to the driver

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
         if (tid < 8) misc[tid] = 0;
     }
     __syncthreads();
-    if (a.dbg == 1) return;
+    GPR_PHASE_EXIT(a.dbg, 1)
     // ---- count: one wavefront per centre, a lane per neighbour j walking its images; which images are inside the cutoff is
     // kept as a bit mask per (centre, neighbour) where it fits (<= 64 images, <= 64 atoms): the fill then tests nothing twice
     for (int il = wave; il < n; il += NBRF_WAVES) {
@@ -513,7 +514,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
         if (lane == 0) { cntP[il] = pair_run; cntR[il] = row_run; }
     }
     __syncthreads();
-    if (a.dbg == 2) return;
+    GPR_PHASE_EXIT(a.dbg, 2)
     // ---- offsets inside the structure, totals out, predecessors' totals in
     if (wave == 0) {
         int runR = 0, runP = 0;
@@ -547,7 +548,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
         if (lane == 0) { misc[0] = runR; misc[1] = runP; misc[2] = baseR; misc[3] = baseP; misc[4] = ok; misc[6] = allR; misc[7] = allP; }
     }
     __syncthreads();
-    if (a.dbg == 3) return;
+    GPR_PHASE_EXIT(a.dbg, 3)
     const int TR = misc[0], TP = misc[1], baseR = misc[2], baseP = misc[3];
     // too small a guess (or a wait that gave up): every offset of every structure is zero -- each centre then has no
     // pairs and no rows, and whatever is queued behind this kernel runs over empty ranges -- and the flag goes up
@@ -651,7 +652,7 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
                 }
             }
         }
-        if (a.dbg == 4) return;
+        GPR_PHASE_EXIT(a.dbg, 4)
         // ---- force points: row k of point a (atom a) is the seq row (i, a) of a's k-th neighbour i
         if (a.row_index) {
             for (int e = tid; e < n * n; e += blockDim.x) {
@@ -694,6 +695,89 @@ struct stage_buf { void *p = nullptr, *dev = nullptr; size_t cap = 0; hipEvent_t
 constexpr int NSTAGE = 8;
 thread_local stage_buf g_stage[NSTAGE];
 thread_local int g_stage_next = 0;
+}
+
+// ---- when may a build take the one-launch kernel?  Its workgroups wait for each other (every structure needs the totals
+// of all), so every workgroup of a launch -- and of every other such launch that may be running -- has to be resident at the
+// same time: two partly resident launches would otherwise hold each other's CUs until the polls run out.  The host therefore
+//   * asks the runtime how many of these workgroups (1024 threads, `lds` bytes of dynamic LDS) a CU takes and multiplies by
+//     the device's CU count (cached per device and LDS size);
+//   * raises the kernel's dynamic-LDS limit when a build needs more than the 64 KB default and the device has it, and
+//     declines the build when it does not;
+//   * keeps count of the workgroups of fused launches that have not finished yet (an event behind each launch), on every
+//     stream of the process, and admits a build only while all of them together fill at most half of that capacity.
+// A declined build takes the five-launch path: same tables, bit for bit.
+namespace {
+struct fused_flight { hipEvent_t ev = nullptr; int wgs = 0; bool busy = false; };
+std::mutex g_fused_mu;
+fused_flight g_fused_flight[32];
+std::map<std::pair<int, size_t>, int> g_fused_capacity;       // (device, lds) -> resident workgroups
+std::map<int, size_t> g_fused_lds_attr;                      // device -> dynamic-LDS limit set on the kernel so far
+std::atomic<int> g_fused_forced_capacity{-1};
+}
+// tests: pretend the device holds `workgroups` of the one-launch kernel at a time (< 0: ask the runtime, the default)
+extern "C" int gpr_nbr_debug_fused_capacity(int workgroups) { g_fused_forced_capacity.store(workgroups); return GPR_OK; }
+
+// admits `nstruct` workgroups with `lds` bytes each or says no (0); on yes *slot names the record to arm after the launch
+static int fused_admit(int nstruct, size_t lds, int *slot) {
+    int devid = 0;
+    if (hipGetDevice(&devid) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lk(g_fused_mu);
+    if (lds > (size_t)64 * 1024) {
+        size_t &have = g_fused_lds_attr[devid];
+        if (have < lds) {
+            int limit = 0;
+            if (hipDeviceGetAttribute(&limit, hipDeviceAttributeMaxSharedMemoryPerBlock, devid) != hipSuccess || (size_t)limit < lds ||
+                hipFuncSetAttribute((const void *)nbr_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+            have = lds;
+        }
+    }
+    const size_t lds_key = (lds + 4095) / 4096 * 4096;
+    auto it = g_fused_capacity.find({devid, lds_key});
+    if (it == g_fused_capacity.end()) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, nbr_fused_kernel, 64 * NBRF_WAVES, lds_key) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        it = g_fused_capacity.emplace(std::make_pair(devid, lds_key), per_cu * cus).first;
+    }
+    int flying = 0, free_slot = -1;
+    for (int k = 0; k < 32; k++) {
+        fused_flight &f = g_fused_flight[k];
+        if (f.busy && hipEventQuery(f.ev) != hipErrorNotReady) f.busy = false;      // finished (or failed: the stream will say)
+        if (f.busy) flying += f.wgs; else if (free_slot < 0) free_slot = k;
+    }
+    (void)hipGetLastError();
+    const int forced_cap = g_fused_forced_capacity.load();          // tests (gpr_nbr_debug_fused_capacity)
+    const int capacity = forced_cap >= 0 ? forced_cap : it->second;
+    if (free_slot < 0 || 2 * (flying + nstruct) > capacity) return 0;
+    fused_flight &f = g_fused_flight[free_slot];
+    if (!f.ev && hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f.ev = nullptr; return 0; }
+    *slot = free_slot;
+    return 1;
+}
+static void fused_arm(int slot, int nstruct, hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_fused_mu);
+    fused_flight &f = g_fused_flight[slot];
+    if (hipEventRecord(f.ev, st) == hipSuccess) { f.wgs = nstruct; f.busy = true; } else (void)hipGetLastError();
+}
+// resident workgroups the runtime reported for the last admitted shape on this device, launches counted as in flight (tests)
+extern "C" int gpr_nbr_fused_state(int *capacity, int *in_flight) {
+    int devid = 0;
+    (void)hipGetDevice(&devid);
+    std::lock_guard<std::mutex> lk(g_fused_mu);
+    int cap = 0, fly = 0;
+    for (auto &kv : g_fused_capacity) if (kv.first.first == devid) cap = std::max(cap, kv.second);
+    for (fused_flight &f : g_fused_flight) {
+        if (f.busy && hipEventQuery(f.ev) != hipErrorNotReady) f.busy = false;
+        if (f.busy) fly += f.wgs;
+    }
+    (void)hipGetLastError();
+    if (capacity) *capacity = cap;
+    if (in_flight) *in_flight = fly;
+    return GPR_OK;
 }
 
 static std::atomic<unsigned> g_nbr_epoch{1};
@@ -777,8 +861,20 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
     int nmax_atoms = 0, nimg_max = 1;
     for (int s = 0; s < nstruct; s++) { nmax_atoms = std::max(nmax_atoms, sinfo[s].n); nimg_max = std::max(nimg_max, sinfo[s].nimg); }
     static const bool no_fused = getenv("GPR_NBR_NO_FUSED") != nullptr;
-    if (!no_fused && g_nbr_fused.load() && cap_pairs > 0 && cap_rows > 0 && natoms > 0 && n_extra == 0 && nstruct <= NBRF_MAX_STRUCT && nmax_atoms <= NBRF_MAX_N &&
-        nimg_max <= 512) {
+    size_t lds = 0;
+    int use_mask = 0, mask_off = 0, flight_slot = -1;
+    bool fused = !no_fused && g_nbr_fused.load() && cap_pairs > 0 && cap_rows > 0 && natoms > 0 && n_extra == 0 && nstruct <= NBRF_MAX_STRUCT &&
+                 nmax_atoms <= NBRF_MAX_N && nimg_max <= 512;
+    if (fused) {
+        lds = (size_t)(3 * nmax_atoms + 3 * nimg_max) * sizeof(double) + (size_t)(5 * nmax_atoms + 8) * sizeof(int) +
+              (size_t)nmax_atoms * nmax_atoms * 3 + 16;
+        use_mask = (nmax_atoms <= 64 && nimg_max <= 64) ? 1 : 0;
+        lds = (lds + 7) / 8 * 8;
+        mask_off = (int)(lds / 8);                           // in doubles from the start of the dynamic LDS
+        if (use_mask) lds += (size_t)nmax_atoms * nmax_atoms * 8;
+        fused = fused_admit(nstruct, lds, &flight_slot) != 0;      // residency and LDS: see above; no -> the five launches below
+    }
+    if (fused) {
         if (!sb.dev && hipHostGetDevicePointer(&sb.dev, sb.p, 0) != hipSuccess) { gpr_set_error("gpr_nbr_build_device: no device alias of the staging buffer"); return fail(GPR_ERR_HIP); }
         nb->capped = true; nb->P = cap_pairs; nb->S = cap_rows;
         if ((rc = gpr_dev_alloc(&p, (size_t)cap_pairs * 4 * sizeof(double) + ((size_t)3 * cap_rows + 4) * sizeof(int), st))) return fail(rc);
@@ -797,7 +893,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.off_sid = fa.off_num + (long long)b_num; fa.off_a0 = fa.off_sid + (long long)b_num; fa.bytes = (long long)b_total;
         fa.nstruct = nstruct; fa.natoms = natoms; fa.weight_on = weight_on; fa.cap_pairs = cap_pairs; fa.cap_rows = cap_rows;
         fa.nmax = nmax_atoms; fa.nimg_max = nimg_max; fa.rc2 = rcut * rcut;
-        static const int nbr_dbg = getenv("GPR_NBR_DBG") ? atoi(getenv("GPR_NBR_DBG")) : 0;
+        static const int nbr_dbg = GPR_PHASE_ENV("GPR_NBR_DBG");      // tools build only (gpr_internal.h); 0 otherwise
         fa.dbg = nbr_dbg;
         unsigned ep = g_nbr_epoch.fetch_add(1);
         if (ep == 0) ep = g_nbr_epoch.fetch_add(1);
@@ -825,14 +921,11 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.vec = nb->d_vec; fa.w = nb->d_w; fa.rp0 = nb->d_rp0; fa.self_row = nb->d_self; fa.seq = nb->d_seq;
         fa.row_index = row_index_dev; fa.x_index = row_index_dev ? x_index_dev : nullptr;
         for (int s = 0; s < nstruct; s++) fa.si[s] = sinfo[s];
-        size_t lds = (size_t)(3 * nmax_atoms + 3 * nimg_max) * sizeof(double) + (size_t)(5 * nmax_atoms + 8) * sizeof(int) +
-                     (size_t)nmax_atoms * nmax_atoms * 3 + 16;
-        fa.use_mask = (nmax_atoms <= 64 && nimg_max <= 64) ? 1 : 0;
-        lds = (lds + 7) / 8 * 8;
-        fa.mask_off = (int)(lds / 8);                        // in doubles from the start of the dynamic LDS
-        if (fa.use_mask) lds += (size_t)nmax_atoms * nmax_atoms * 8;
+        fa.use_mask = use_mask;
+        fa.mask_off = mask_off;
         hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess) fused_arm(flight_slot, nstruct, st);
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fused launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
         nb->fused_rows = row_index_dev != nullptr;

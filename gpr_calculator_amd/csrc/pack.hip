@@ -12,6 +12,7 @@
 #include <cstring>
 #include <cstdarg>
 #include <numeric>
+#include <map>
 #include <mutex>
 #include <unordered_map>
 #include <vector>
@@ -76,6 +77,31 @@ void release_to_driver(void *p, hipStream_t st) {
     if (hipFreeAsync(p, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(p); }
 }
 int current_device() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = -1; } return d; }
+}
+
+int gpr_func_lds_once(const void *fn, int bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> done;       // (kernel, device) -> limit set so far
+    const int devid = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    int &have = done[{fn, devid}];
+    if (have >= bytes) return GPR_OK;
+    GPR_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    have = bytes;
+    return GPR_OK;
+}
+
+int gpr_cu_count() {
+    static std::mutex mu;
+    static std::map<int, int> cus;
+    const int devid = current_device();
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cus.find(devid);
+    if (it != cus.end()) return it->second;
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, devid < 0 ? 0 : devid) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+    cus[devid] = n;
+    return n;
 }
 
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st) {
@@ -144,6 +170,16 @@ int gpr_dev_cache_drop_stream(hipStream_t st) {
     }
     for (const cached_block &c : out) release_to_driver(c.p, c.st);
     return GPR_OK;
+}
+
+// how many cached temporaries remember `stream` as the stream they were freed on (all streams with any != 0): after a
+// stream's owner has called gpr_dev_cache_drop_stream this must be zero, or a later eviction would hand a block to the
+// driver on a destroyed handle (tests/test_gpu_session_teardown.py)
+extern "C" int gpr_dev_cache_count(void *stream, int any) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    int n = 0;
+    for (const cached_block &c : g_cache) n += (any || c.st == (hipStream_t)stream) ? 1 : 0;
+    return n;
 }
 
 extern "C" int gpr_memcpy_dtod(void *stream, void *dst, const void *src, long long bytes) {

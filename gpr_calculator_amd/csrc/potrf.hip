@@ -738,7 +738,7 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
                 // where the chain of diagonal blocks decides the time (not pair_bulk) the bulk runs as a persistent kernel
                 // on all but a few CUs, which stay free for the chain; elsewhere the plain tiled GEMM on every CU
                 if (reserve_cus > 0 && !pair_bulk && kk % 16 == 0 && n - c3 >= 1024)
-                    rc = gpr_syrk_bulk_internal(g_la.side, n - c3, kk, at(c3, k0), lda, at(c3, c3), lda, 256 - reserve_cus);
+                    rc = gpr_syrk_bulk_internal(g_la.side, n - c3, kk, at(c3, k0), lda, at(c3, c3), lda, std::max(gpr_cu_count() - reserve_cus, 1));
                 else
                     rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, kk, -1.0, at(c3, k0), lda, at(c3, k0), lda, 1.0, at(c3, c3), lda, 1);
                 bulk_last = mark(g_la.side);

@@ -221,6 +221,12 @@ extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
     return GPR_OK;
 }
 
+// the stream slot k works on (NULL: the slot has not been used yet, or k is out of range) -- for tests of the teardown path
+extern "C" void *gpr_dot2_session_slot_stream(gpr_dot2_session *s, int k) {
+    if (!s || k < 0 || k >= SESSION_SLOTS || !s->slot[k].has_stream) return nullptr;
+    return (void *)s->slot[k].st;
+}
+
 // a private stream for slot k >= 1: behind everything queued on the session's stream so far (the model arrays)
 static int session_slot_stream(gpr_dot2_session *s, session_slot &sl) {
     if (sl.has_stream) return GPR_OK;
@@ -247,6 +253,9 @@ static int session_enqueue(gpr_dot2_session *s, session_slot &sl, int cap_pairs,
 // fixed[natoms] (may be NULL): non-zero marks atoms held by FixAtoms -- F = F_std = 0 there, no force rows.
 // Queues the whole prediction of the batch and returns; *ticket names the submission for _wait.  The input arrays must
 // stay valid and unchanged until _wait has returned.  At most `depth` submissions may be waiting.
+static int session_submit_on(gpr_dot2_session *s, int k, int nstruct, const int *atom0, const double *positions,
+                             const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed, int *ticket);
+
 extern "C" int gpr_dot2_session_submit(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
                                        const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
                                        int *ticket) {
@@ -258,6 +267,11 @@ extern "C" int gpr_dot2_session_submit(gpr_dot2_session *s, int nstruct, const i
     }
     GPR_REQUIRE(k >= 0, "gpr_dot2_session_submit: %d submissions are waiting already (gpr_dot2_session_wait first, or raise the depth)", s->depth);
     s->next = (k + 1) % s->depth;
+    return session_submit_on(s, k, nstruct, atom0, positions, cells, pbc, numbers, fixed, ticket);
+}
+
+static int session_submit_on(gpr_dot2_session *s, int k, int nstruct, const int *atom0, const double *positions,
+                             const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed, int *ticket) {
     session_slot &sl = s->slot[k];
     int rc = session_slot_stream(s, sl);
     if (rc) return rc;
@@ -325,8 +339,7 @@ extern "C" int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E,
             // different paths: a late result row behind the status words was seen once in a few hundred calls).  The words
             // end the long wait cheaply; the short rest is a busy query of the slot's stream -- no sleep, unlike a blocking
             // synchronisation.
-            static const bool trust_words = getenv("GPR_SESSION_TRUST_WORDS") != nullptr;
-            if (seen && !trust_words) {
+            if (seen) {
                 hipError_t q;
                 while ((q = hipStreamQuery(sl.st)) == hipErrorNotReady) {}
                 if (q != hipSuccess) { gpr_set_error("gpr_dot2_session_wait: %s", hipGetErrorString(q)); return GPR_ERR_HIP; }
@@ -374,18 +387,20 @@ extern "C" int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E,
     return GPR_OK;
 }
 
-// one batch, synchronous: submit on slot 0 (the caller's stream) and wait
+// one batch, synchronous: submit on a free slot (slot 0, the caller's stream, unless a ticket holds it) and wait
 extern "C" int gpr_dot2_session_predict(gpr_dot2_session *s, int nstruct, const int *atom0, const double *positions,
                                         const double *cells, const int *pbc, const int *numbers, const unsigned char *fixed,
                                         double *E, double *F, double *E_std, double *F_std, double *info) {
     GPR_REQUIRE(s && nstruct >= 0 && atom0 && E && F && (!s->want_std || (E_std && F_std)), "gpr_dot2_session_predict: null pointer");
     if (nstruct == 0) return GPR_OK;
-    GPR_REQUIRE(!s->slot[0].busy, "gpr_dot2_session_predict: slot 0 holds a submission that has not been waited for");
-    const int depth = s->depth, next = s->next;
-    s->depth = 1; s->next = 0;                            // slot 0
+    // slot 0 -- the caller's stream -- when it is free; with submissions in flight any free slot serves (its own stream,
+    // behind the model arrays): a synchronous call never has to wait for tickets somebody else holds
+    int k = -1;
+    for (int c = 0; c < SESSION_SLOTS && k < 0; c++)
+        if (!s->slot[c].busy) k = c;
+    GPR_REQUIRE(k >= 0, "gpr_dot2_session_predict: all %d slots hold submissions that have not been waited for", SESSION_SLOTS);
     int ticket = -1;
-    int rc = gpr_dot2_session_submit(s, nstruct, atom0, positions, cells, pbc, numbers, fixed, &ticket);
-    s->depth = depth; s->next = next;
+    int rc = session_submit_on(s, k, nstruct, atom0, positions, cells, pbc, numbers, fixed, &ticket);
     if (rc) return rc;
     return gpr_dot2_session_wait(s, ticket, E, F, E_std, F_std, info);
 }

@@ -480,7 +480,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
         for (int c0 = p0; c0 < p1; c0 += PC) {
             const int npc = min(PC, p1 - c0);
             build_records(c0, npc);
-            if (P.dbg == 1) return;
+            GPR_PHASE_EXIT(P.dbg, 1)
             if (mine)
                 for (int q = grp; q < npc; q += G) {
                     const double *rec = recs + q * REC;
@@ -525,7 +525,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
     // ---- gradient coefficients contracted with c_tot (SO3.py:682-707 folded into per-centre tables):
     //      S_nlk(pair) = (1/r) sum_{side} sum_{m' >= 0} Re[Y_{l', m'} conj(Tf[nl][k][side][m'])], l' = l -/+ 1
     {
+#ifdef GPR_PHASE_ABLATION
         const int NB = (L * L + L) * 3, ntf = (P.dbg == 5) ? 0 : P.nmax * NB;      // dbg 5: timing without the tables (wrong numbers)
+#else
+        const int NB = (L * L + L) * 3, ntf = P.nmax * NB;
+#endif
         const double *GT = P.table + tab.oGT;
         for (int e = tid; e < ntf; e += 256) {
             const int n = e / NB, idx = e - n * NB;
@@ -555,7 +559,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
     }
     __syncthreads();
 
-    if (P.dbg == 2) return;
+    GPR_PHASE_EXIT(P.dbg, 2)
     // ---- pass 2 (stress variant below): dP rows, one row per wavefront at a time.  Lane t < NL owns R_nl, lanes NL .. 4 NL - 1 own S_nlk;
     //      lanes e < 3 d then combine into the row's outputs.
     const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1];
@@ -657,7 +661,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                     }
             }
             __syncthreads();                                  // records read, pair -> row map complete
+#ifdef GPR_PHASE_ABLATION
             if (P.dbg == 3) { if (active && outv[0] == 1.234567e300) P.x[0] = 0.0; return; }   // ablation: keep outv alive
+#endif
             const int myrow = active ? sMap[q] : 0, myj = active ? sMap[PC + q] : -1;
             const int rowb = sMap[0], nrows_c = sMap[npc - 1] - rowb + 1, maxj = sMap[2 * PC];
             const bool cont = P.row_pair0[r0 + rowb] < c0;    // the chunk's first row began in the previous chunk
@@ -677,7 +683,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
                 }
                 __syncthreads();
             }
-            if (P.dbg == 4) return;
+            GPR_PHASE_EXIT(P.dbg, 4)
             for (int f = tid; f < nrows_c * ne; f += 256) {
                 const int rl = f / ne, row = r0 + rowb + rl;
                 if (row == rself) continue;
@@ -923,7 +929,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     (void)nrows;
     so3_args A;
     A.nmax = nmax; A.lmax = lmax; A.d = d; A.nseg = nseg; A.ncheb = ncheb; A.rcut = rcut; A.alpha = alpha;
-    { const char *dbg = getenv("GPR_SO3_DBG"); A.dbg = dbg ? atoi(dbg) : 0; }   // phase ablation for profiling only
+    A.dbg = GPR_PHASE_ENV("GPR_SO3_DBG");          // phase ablation: tools build only (gpr_internal.h); 0 otherwise
     A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
     A.positions = positions; A.inv_vol = inv_vol; A.rdxdr = rdxdr;
@@ -933,14 +939,13 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         gpr_set_error("gpr_so3_power_spectrum: (nmax=%d, lmax=%d) needs %zu bytes of LDS", nmax, lmax, lds_bytes);
         return GPR_ERR_UNSUPPORTED;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<5, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<SO3_LCAP, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        GPR_HIP_TRY(hipFuncSetAttribute((const void *)so3_centre_kernel<4, SO3_NCAP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
-        attr_set = true;
+    {
+        int rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<5, 3, false>, 96 * 1024);
+        if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<SO3_LCAP, 4, false>, 96 * 1024);
+        if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<5, 3, true>, 96 * 1024);
+        if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<SO3_LCAP, 4, true>, 96 * 1024);
+        if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<4, SO3_NCAP, false>, 96 * 1024);
+        if (rc_) return rc_;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
     const bool small_l = lmax + 1 <= 5 && nmax <= 3;

@@ -210,6 +210,13 @@ int gpr_dot2_session_submit(gpr_dot2_session *s, int nstruct, const int *atom0, 
                             const int *pbc, const int *numbers, const unsigned char *fixed, int *ticket);
 int gpr_dot2_session_wait(gpr_dot2_session *s, int ticket, double *E, double *F, double *E_std, double *F_std, double *info);
 int gpr_dot2_session_set_depth(gpr_dot2_session *s, int depth);
+/* gpr_dot2_session_predict takes slot 0 (the stream the session was created on) when no ticket holds it, otherwise any
+ * free slot: synchronous calls and submissions may be mixed freely on one session.
+ * Teardown checks (tests): the stream slot k works on (NULL before its first use), and the number of cached
+ * stream-ordered temporaries that still remember `stream` (any != 0: all streams) -- zero for every slot stream once
+ * gpr_dot2_session_destroy has returned. */
+void *gpr_dot2_session_slot_stream(gpr_dot2_session *s, int k);
+int gpr_dev_cache_count(void *stream, int any);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
@@ -300,6 +307,14 @@ int gpr_nbr_build_device_rows(gpr_nbr **out, void *stream, int nstruct, const in
                               const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
                               int cap_pairs, int cap_rows, int *row_index_dev, int *x_index_dev, int *rows_done);
 int gpr_nbr_set_fused(int on);      /* tests / A-B timing: 0 keeps every capped build on the five-launch path */
+/* The one-launch builder's workgroups wait for each other, so it is only taken while every such workgroup in flight in
+ * the process (all streams) plus the new ones fill at most half of what the device keeps resident at once
+ * (hipOccupancyMaxActiveBlocksPerMultiprocessor x CU count for the build's LDS need; more than the 64 KB default of
+ * dynamic LDS is requested from the runtime, and a build the device cannot hold takes the five-launch path).
+ * gpr_nbr_fused_state: that capacity (largest shape admitted so far on this device) and the workgroups counted as in
+ * flight right now.  gpr_nbr_debug_fused_capacity: tests pretend a capacity (< 0: back to the runtime's answer). */
+int gpr_nbr_fused_state(int *capacity, int *in_flight);
+int gpr_nbr_debug_fused_capacity(int workgroups);
 /* dst_dev[0..3] = [missing force rows, overflow (capped builds), true pair count, true seq-row count] in stream order */
 int gpr_nbr_info_to(const gpr_nbr *nb, double *dst_dev);
 /* the four device ints gpr_nbr_info_to converts (for kernels that deliver them themselves, gpr_ws_tail_status) */
@@ -394,6 +409,14 @@ int gpr_trsm_lower(void *stream, int trans, int n, int nrhs, const double *l, lo
 /* same with the diagonal-block inverses of gpr_potrf_lower_dinv: every block solve is a small product */
 int gpr_trsm_lower_dinv(void *stream, int trans, int n, int nrhs, const double *l, long long ldl,
                         const double *dinv, double *b, long long ldb);
+/* With up to 8 right-hand sides and 2 .. 1024 blocks of 64 rows the solve is ONE launch whose workgroups hand their
+ * solutions on by polling (csrc/dense.hip, trsv_chain_kernel).  A workgroup whose wait outlasts the poll budget gives up;
+ * a one-workgroup kernel queued behind the launch then finishes the substitution from where the chain stopped, so the
+ * caller always receives the solution (never NaNs for a time-out).  gpr_trsv_chain_fallbacks: how often that has happened
+ * in this process (0 in a healthy run; readable at any time, meaningful once the stream has been synchronised).
+ * gpr_trsv_debug_max_polls: the poll budget (tests force the fallback with 1; <= 0 restores the default). */
+int gpr_trsv_chain_fallbacks(void);
+int gpr_trsv_debug_max_polls(int polls);
 /* C[n,nrhs] = T B with T lower triangular n x n: the strict upper triangle of T must hold zeros; whole
  * 128-column blocks to the right of a row block's diagonal block are skipped (never read) */
 int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,

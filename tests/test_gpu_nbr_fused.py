@@ -99,3 +99,101 @@ def test_overflow_is_all_or_nothing():
         assert not o["cr0"].any() and not o["cp0"].any()                                      # every range empty
     exact = _build(strucs, P, S, True)                                                         # capacities that just fit
     assert exact["info"][1] == 0 and np.array_equal(exact["seq"], full["seq"])
+
+
+def _rows_done(strucs, capP, capR):
+    """does a capped build with regrouping take the one-launch kernel right now?"""
+    import torch
+    from gpr_calculator_amd import _lib, device as dev
+    L = _lib.lib()
+    atom0, pos, cells, pbc, num = _arrays(strucs)
+    ri = torch.full((2 * capR,), -7, dtype=torch.int32, device=dev.device())
+    h, done = C.c_void_p(), C.c_int(0)
+    dev.check(L.gpr_nbr_build_device_rows(C.byref(h), dev.stream_ptr(), len(strucs), atom0.ctypes.data, pos.ctypes.data, cells.ctypes.data,
+                                          pbc.ctypes.data, num.ctypes.data, 5.0, 0, capP, capR, ri.data_ptr(), ri.data_ptr() + 4 * capR,
+                                          C.byref(done)), "gpr_nbr_build_device_rows")
+    torch.cuda.synchronize()
+    L.gpr_nbr_destroy(h)
+    return done.value
+
+
+def test_the_one_launch_build_is_declined_when_its_workgroups_could_not_all_be_resident():
+    """The kernel's workgroups wait for each other: the host admits a build only while all such workgroups in flight fill
+    at most half of what the device keeps resident (occupancy x CU count).  A build that does not fit takes the five-launch
+    path -- same tables -- instead of spinning until the polls run out."""
+    import torch
+    from gpr_calculator_amd import _lib
+    from gpr_calculator_amd.synthetic import neb_images
+    L = _lib.lib()
+    strucs = neb_images(40, seed=310)
+    natoms = sum(len(s) for s in strucs)
+    capP, capR = natoms * 140, natoms * 40
+    assert _rows_done(strucs, capP, capR) == 1
+    cap, fly = C.c_int(-1), C.c_int(-1)
+    L.gpr_nbr_fused_state(C.byref(cap), C.byref(fly))
+    assert cap.value >= 256 and fly.value == 0, (cap.value, fly.value)        # >= one 1024-thread workgroup per CU; nothing left flying
+    want = _build(strucs, capP, capR, False)
+    try:
+        L.gpr_nbr_debug_fused_capacity(2 * len(strucs) - 1)                   # one workgroup short of "half the device"
+        assert _rows_done(strucs, capP, capR) == 0
+        L.gpr_nbr_debug_fused_capacity(2 * len(strucs))
+        assert _rows_done(strucs, capP, capR) == 1
+        # two streams: the first launch is still flying (the stream is held back by a long kernel in front of it) when the
+        # second asks -- together they exceed the pretended capacity, so the second build is declined
+        L.gpr_nbr_debug_fused_capacity(3 * len(strucs))
+        s1 = torch.cuda.Stream()
+        big = torch.empty((8192, 8192), dtype=torch.float64, device="cuda").normal_()
+        with torch.cuda.stream(s1):
+            for _ in range(4):
+                big = big @ big * 1e-4                                          # tens of milliseconds ahead of the build
+            first = _rows_done_async(strucs, capP, capR)
+        second = _rows_done(strucs, capP, capR)
+        s1.synchronize()
+        first[1]()
+        assert first[0] == 1 and second == 0
+    finally:
+        L.gpr_nbr_debug_fused_capacity(-1)
+    got = _build(strucs, capP, capR, True)                                    # admitted again, and the same tables either way
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
+def _rows_done_async(strucs, capP, capR):
+    """(rows_done, release) of a capped build queued on the current stream without waiting for it"""
+    import torch
+    from gpr_calculator_amd import _lib, device as dev
+    L = _lib.lib()
+    atom0, pos, cells, pbc, num = _arrays(strucs)
+    ri = torch.full((2 * capR,), -7, dtype=torch.int32, device=dev.device())
+    h, done = C.c_void_p(), C.c_int(0)
+    dev.check(L.gpr_nbr_build_device_rows(C.byref(h), dev.stream_ptr(), len(strucs), atom0.ctypes.data, pos.ctypes.data, cells.ctypes.data,
+                                          pbc.ctypes.data, num.ctypes.data, 5.0, 0, capP, capR, ri.data_ptr(), ri.data_ptr() + 4 * capR,
+                                          C.byref(done)), "gpr_nbr_build_device_rows")
+    keep = (atom0, pos, cells, pbc, num, ri)
+    return done.value, (lambda: (L.gpr_nbr_destroy(h), keep)[0])
+
+
+def test_a_build_that_needs_more_than_64_kb_of_lds_still_runs():
+    """128 atoms in a cell small enough for hundreds of periodic images: the tables of the one-launch kernel pass the
+    64 KB default of dynamic LDS.  The limit is raised (or the build declined) -- never a failed launch."""
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    rng = np.random.default_rng(11)
+    n = 128
+    cell = np.diag([2.6, 2.6, 40.0])
+    pos = rng.uniform(0.0, 1.0, (n, 3)) @ cell
+    s = SimpleAtoms(np.full(n, 46), pos, cell, [True, True, False])            # 5 x 5 x 1 images and more
+    natoms = n
+    a, b = _build_any([s], natoms * 600, natoms * 130), _build([s], natoms * 600, natoms * 130, False)
+    assert a["info"][1] == 0 and b["info"][1] == 0
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def _build_any(strucs, capP, capR):
+    """_build without insisting on which path served it"""
+    import gpr_calculator_amd._lib as _lib
+    L = _lib.lib()
+    try:
+        return _build(strucs, capP, capR, True)
+    except AssertionError:
+        return _build(strucs, capP, capR, False)

@@ -118,6 +118,42 @@ def test_poll_timeout_is_a_schedule_event_not_a_verdict_on_the_matrix(gpu):
     assert np.abs(t.cpu().numpy() - L).max() / np.abs(L).max() < 1e-13
 
 
+@pytest.mark.parametrize("n,nrhs", [(1516, 1), (6063, 1), (2049, 5)])
+def test_one_launch_solve_that_gives_up_waiting_is_finished_not_poisoned(gpu, n, nrhs):
+    """The one-launch triangular solve (trsv_chain_kernel) with a poll budget of one: some workgroup gives up on its
+    predecessor almost surely.  The caller must still get the solution (trsv_fixup_kernel finishes the substitution),
+    the status must be GPR_OK, and the rescue must be counted -- round 3 returned GPR_OK with NaNs."""
+    import torch
+    from scipy.linalg import cholesky, solve_triangular
+    from gpr_calculator_amd import device as dev
+    rng = np.random.default_rng(n)
+    L = cholesky(_spd(n, 3), lower=True)
+    B = rng.standard_normal((n, nrhs))
+    Ld = torch.tensor(L, device="cuda")
+    dinv = dev.tri_inv64(Ld)
+    want = {False: solve_triangular(L, B, lower=True), True: solve_triangular(L.T, B, lower=False)}
+    for trans in (False, True):                                   # healthy run first: nothing to rescue
+        before = gpu.gpr_trsv_chain_fallbacks()
+        x = dev.trsm_lower_(Ld, torch.tensor(B, device="cuda"), trans=trans, dinv=dinv)
+        torch.cuda.synchronize()
+        assert np.abs(x.cpu().numpy() - want[trans]).max() / np.abs(want[trans]).max() < 1e-12
+        assert gpu.gpr_trsv_chain_fallbacks() == before
+    try:
+        assert gpu.gpr_trsv_debug_max_polls(1) == 0
+        rescued = 0
+        for trans in (False, True):
+            before = gpu.gpr_trsv_chain_fallbacks()
+            x = dev.trsm_lower_(Ld, torch.tensor(B, device="cuda"), trans=trans, dinv=dinv)
+            torch.cuda.synchronize()
+            got = x.cpu().numpy()
+            assert np.isfinite(got).all()
+            assert np.abs(got - want[trans]).max() / np.abs(want[trans]).max() < 1e-12
+            rescued += gpu.gpr_trsv_chain_fallbacks() - before
+        assert rescued >= 1, "a poll budget of one did not make any workgroup give up: the path under test did not run"
+    finally:
+        gpu.gpr_trsv_debug_max_polls(0)
+
+
 def test_two_host_threads_factor_at_once(gpu):
     """two factorisations with look-ahead enqueued from two host threads on two streams: they share the look-ahead
     context of the device (flag words, private streams) and are serialised by it -- both factors are right"""
