@@ -13,7 +13,8 @@ What is sharded, and what moves:
     block-cyclic rows (256-row blocks, block b on rank b % G), right-looking.  Per block step: the owner factors the
     diagonal block and BROADCASTS its operand tiles (311 KB); every rank solves its own rows of the panel; the panel
     rows are ALL-GATHERED (N x 256 doubles at most); every rank updates its own rows of the trailing matrix on the matrix
-    cores.  The factor is gathered at the end (predictions keep using a replicated L).
+    cores -- with one step of look-ahead: the broadcast and the all-gather of step k + 1 run on a second stream beside
+    the bulk of step k's update.  The factor is gathered at the end (predictions keep using a replicated L).
 
 Both routines take the local arithmetic as an `ops` object: `DeviceOps` (libgprhip.so) in production, a numpy / scipy
 implementation in tests/test_distributed_gloo.py, which runs the very same schedule over gloo with world size 2.
@@ -129,30 +130,64 @@ def cholesky_block_cyclic(Aloc, dist, comm, ops):
     """In-place lower Cholesky of a symmetric matrix held as block-cyclic row blocks: Aloc [local rows, n] holds, on
     return, this rank's rows of L (entries above the diagonal are unspecified).  Only the lower triangle is read.
     A diagonal block that is not positive definite sets the owner's info word and the loop carries on (on NaNs) through
-    the same collectives on every rank; potrf_distributed makes the ranks agree on info afterwards."""
+    the same collectives on every rank; potrf_distributed makes the ranks agree on info afterwards.
+
+    Schedule (one step of look-ahead).  The work of step k falls into a *chain* -- factor the diagonal block (owner),
+    broadcast its tiles, solve the own panel rows, all-gather the panel -- and the trailing update A22 -= P P^T of the
+    rank's own rows.  The chain of step k + 1 needs only column block k + 1 of that update, so the update is cut in two:
+
+        side lane:  U_k[column block k + 1]  ->  chain(k + 1): diag, broadcast, panel rows, all-gather
+        main lane:  U_k[column blocks k + 2 ...]                      (the bulk of the flops)
+
+    Both lanes run at the same time: the collectives of step k + 1 (311 KB of tiles, then up to n x 256 doubles of panel)
+    cross the links while the matrix cores work on the rest of step k.  `ops.side()` is the lane switch (a second stream
+    on the device, on which torch.distributed also orders its collectives; nothing at all in the numpy test double, where
+    the same calls simply run in this order), `ops.fork_side()` makes the side lane wait for what the main lane has queued,
+    `ops.join_side()` the reverse.  Panels land in two buffers used in turn: the all-gather of step k + 1 must not write
+    what the update of step k still reads."""
     rank, size, nb, n = comm.rank, comm.size, dist.nb, dist.n
     # row orders of every step, on the device, built once: the gathered panel is rank-major, the update wants global order
     perms = ops.index_tables([dist.perm_after(k) for k in range(dist.nblk - 1)])
     buf = ops.new_tiles()
-    panel_rm = ops.zeros((max(n - nb, 0), nb)) if dist.nblk > 1 else None          # rank-major landing zone, reused
-    for k in range(dist.nblk):
+    lands = [ops.zeros((max(n - nb, 0), nb)) for _ in range(2)] if dist.nblk > 1 else None      # rank-major landing zones
+
+    def chain(k):
+        """diag(k) .. all-gather(k) on the current lane; (panel in global row order, r0, m, k0, kb, c1) or None (last block)"""
         k0, kb, owner = k * nb, dist.block_rows(k), k % size
         if rank == owner:
             ops.diag_(Aloc, dist.local_row0(rank, k), k0, kb, buf)
         comm.broadcast_(buf, root=owner)
         c1 = k0 + kb
         if c1 >= n:
-            return k + 1
+            return None
         r0, m = dist.rows_after(rank, k)
         if m > 0:
             ops.panel_(buf, Aloc, r0, k0, kb, m)
         counts = [dist.rows_after(q, k)[1] for q in range(size)]
         mine = Aloc[r0:r0 + m, k0:c1].contiguous()
-        land = panel_rm[:n - c1] if kb == nb else ops.zeros((n - c1, kb))
+        land = lands[k % 2][:n - c1] if kb == nb else ops.zeros((n - c1, kb))
         panel = comm.all_gather_rows(mine, counts, out=land)         # rank-major
         panel = ops.take_rows(panel, perms[k])                      # global order: rows c1 .. n - 1
-        if m > 0:
-            ops.update_(Aloc, r0, m, k0, kb, panel, c1, n - c1, dist, rank)
+        return panel, r0, m, k0, kb, c1
+
+    with ops.side():
+        ops.fork_side()
+        state = chain(0)
+    for k in range(dist.nblk):
+        if state is None:
+            break
+        panel, r0, m, k0, kb, c1 = state
+        ops.join_side(panel)                                         # main lane: panel k and the own panel rows are there
+        nxt = dist.block_rows(k + 1)                                 # width of column block k + 1
+        with ops.side():
+            ops.fork_side()                                          # column block k + 1 was last written by U_{k-1} on the main lane
+            if m > 0:
+                ops.update_(Aloc, r0, m, k0, kb, panel[:nxt], c1, nxt, dist, rank)
+            state = chain(k + 1)
+        rest = n - c1 - nxt
+        if m > 0 and rest > 0:
+            ops.update_(Aloc, r0, m, k0, kb, panel[nxt:], c1 + nxt, rest, dist, rank)
+    ops.join_side()
     return dist.nblk
 
 
@@ -180,6 +215,17 @@ def potrf_distributed(K, comm, ops, nb=NB):
 # ------------------------------------------------------------------------------------------------ device arithmetic
 class OpsBase:
     """what the schedule needs besides arithmetic, the same for every implementation of the local arithmetic"""
+
+    # lanes of cholesky_block_cyclic: one lane here (calls run in program order); DeviceOps overrides with two streams
+    def side(self):
+        import contextlib
+        return contextlib.nullcontext()
+
+    def fork_side(self):
+        pass
+
+    def join_side(self, *tensors):
+        pass
 
     def index_tables(self, tables):
         """several host index arrays -> index tensors where the matrices live, one upload for all of them"""
@@ -217,6 +263,31 @@ class DeviceOps(OpsBase):
 
     def zeros(self, shape):
         return torch.zeros(shape, dtype=self.dev.F64, device=self.dev.device())
+
+    # ---- the two lanes of cholesky_block_cyclic.  The main lane is the stream that is current when the factorisation
+    # starts; the side lane is a stream of this object.  Kernels go where torch's current stream points
+    # (device.stream_ptr), and torch.distributed orders a collective behind the current stream and lets the current
+    # stream wait for it -- so `with ops.side():` moves the chain of a step, collectives included, off the main lane.
+    _side = _main = None
+
+    def side(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev.device())
+        self._main = torch.cuda.current_stream(self.dev.device())
+        return torch.cuda.stream(self._side)
+
+    def fork_side(self):
+        """(called on the side lane) wait for everything the main lane has queued so far"""
+        self._side.wait_stream(self._main)
+
+    def join_side(self, *tensors):
+        """(called on the main lane) wait for everything the side lane has queued so far; tensors made there are about
+        to be read here"""
+        if self._side is None:
+            return
+        torch.cuda.current_stream(self.dev.device()).wait_stream(self._side)
+        for t in tensors:
+            t.record_stream(torch.cuda.current_stream(self.dev.device()))
 
     def mirror_lower_(self, M):
         self.dev.check(self.lib.gpr_mirror_lower(self.dev.stream_ptr(), M.shape[0], self.dev.ptr(M), int(M.stride(0))), "gpr_mirror_lower")

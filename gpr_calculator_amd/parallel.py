@@ -100,14 +100,38 @@ class Comm:
 
     def gather_slabs_inplace(self, full, row0, counts, owners):
         """`full` [n, ncols] already holds this rank's row slabs (slab i = rows row0[i] : row0[i] + counts[i], computed by
-        rank owners[i]); on return it holds everyone's.  One broadcast per slab, in place: each element crosses a link
-        once and lands where it stays."""
+        rank owners[i]); on return it holds everyone's.  Each element crosses a link once and lands where it stays.
+        The slabs come in rounds of one slab per rank, in rank order (the energy rows of every rank, then the force
+        rows).  A round is ONE collective where the backend has one for it:
+          * equal, adjacent slabs: all_gather_into_tensor straight into their rows of `full`;
+          * unequal slabs on RCCL: all_gather with a list of views -- torch issues the G broadcasts of such a call as one
+            grouped launch (ncclGroupStart / End), every broadcast writing its rows of `full` directly;
+          * otherwise (gloo wants equal sizes; empty slabs): one asynchronous broadcast per slab, waited for together."""
         if not self.active or self.size == 1:
             return full
+        G = self.size
+        slabs = [(int(o), int(c), int(r)) for o, c, r in zip(row0, counts, owners)]
+        rounds, loose = [], []
+        for i in range(0, len(slabs), G):
+            rnd = slabs[i:i + G]
+            (rounds if len(rnd) == G and [r for _, _, r in rnd] == list(range(G)) else loose).append(rnd)
+        nccl = dist.get_backend(self.group) == "nccl"
         works = []
-        for o, c, r in zip(row0, counts, owners):
-            if int(c):
-                works.append(dist.broadcast(full[int(o):int(o) + int(c)], src=self._global_rank(int(r)), group=self.group, async_op=True))
+        for rnd in rounds:
+            cs = [c for _, c, _ in rnd]
+            views = [full[o:o + c] for o, c, _ in rnd]
+            adjacent = all(rnd[q][0] + rnd[q][1] == rnd[q + 1][0] for q in range(G - 1))
+            if min(cs) > 0 and min(cs) == max(cs) and adjacent and full.is_contiguous():
+                mine = views[self.rank].clone()                      # (not the in-place form: one copy of 1 / G of the rows)
+                works.append(dist.all_gather_into_tensor(full[rnd[0][0]:rnd[0][0] + G * cs[0]], mine, group=self.group, async_op=True))
+            elif nccl and min(cs) > 0:
+                works.append(dist.all_gather(views, views[self.rank].clone(), group=self.group, async_op=True))
+            else:
+                loose.append(rnd)
+        for rnd in loose:
+            for o, c, r in rnd:
+                if c:
+                    works.append(dist.broadcast(full[o:o + c], src=self._global_rank(r), group=self.group, async_op=True))
         for w in works:
             w.wait()
         return full

@@ -127,7 +127,7 @@ def test_one_launch_solve_that_gives_up_waiting_is_finished_not_poisoned(gpu, n,
     from scipy.linalg import cholesky, solve_triangular
     from gpr_calculator_amd import device as dev
     rng = np.random.default_rng(n)
-    L = cholesky(_spd(n, 3), lower=True)
+    L = np.ascontiguousarray(cholesky(_spd(n, 3), lower=True))       # scipy hands back column-major storage
     B = rng.standard_normal((n, nrhs))
     Ld = torch.tensor(L, device="cuda")
     dinv = dev.tri_inv64(Ld)

@@ -51,6 +51,13 @@ def _worker_body(rank, world, port, q):
         if r == rank:
             full[o:o + c] = 10.0 * (r + 1) + torch.arange(o, o + c, dtype=torch.float64)[:, None]
     out["slabs"] = comm.gather_slabs_inplace(full, row0, cnt, owners).numpy().copy()
+    # rounds of equal, adjacent slabs take ONE all_gather_into_tensor each, straight into their rows
+    full = torch.zeros((10, 3), dtype=torch.float64)
+    row0, cnt, owners = [0, 2, 4, 7], [2, 2, 3, 3], [0, 1, 0, 1]
+    for o, c, r in zip(row0, cnt, owners):
+        if r == rank:
+            full[o:o + c] = 10.0 * (r + 1) + torch.arange(o, o + c, dtype=torch.float64)[:, None]
+    out["slabs_equal"] = comm.gather_slabs_inplace(full, row0, cnt, owners).numpy().copy()
     out["max"] = comm.all_reduce_max_(torch.tensor([float(rank), 5.0 - rank], dtype=torch.float64)).numpy().copy()
     # all-reduce of a sharded matrix: every element owned by exactly one rank -> exact sum
     full = torch.arange(24, dtype=torch.float64).reshape(4, 6) * 0.1
@@ -93,6 +100,8 @@ def test_comm_world2_gloo():
         assert o["gather_equal"][0] and (o["gather_equal"][1][:4] == 1).all() and (o["gather_equal"][1][4:] == 2).all()
         want = np.array([10.0, 11.0, 22.0, 13.0, 14.0, 25.0])[:, None] * np.ones((1, 3))
         assert np.array_equal(o["slabs"], want)
+        want = np.array([10.0, 11.0, 22.0, 23.0, 14.0, 15.0, 16.0, 27.0, 28.0, 29.0])[:, None] * np.ones((1, 3))
+        assert np.array_equal(o["slabs_equal"], want)
         assert np.array_equal(o["max"], [1.0, 5.0])
         assert o["reduce_exact"]
         assert o["structures"] == {k: k * k for k in range(7)}
