@@ -70,32 +70,20 @@ class GP():
         self.logging = logging
 
         self.comm = Comm()
-        self.rank = self.comm.rank
-        self.size = self.comm.size
-        if type(noise_e) is not list:
-            self.noise_e = noise_e
-            self.noise_f = noise_f
-            self.noise_bounds = None
-        else:
-            self.noise_e = noise_e[0]
-            self.noise_f = noise_f[0]
-            self.noise_bounds = noise_e[1:]
+        self.rank, self.size = self.comm.rank, self.comm.size
+        # model definition.  A list for noise_e means "optimise the noise too": [start, lower, upper] (its tail is the
+        # L-BFGS-B bound); the force noise then follows as f_coef x the energy noise (gaussianprocess.py:64-75, 268-283)
+        tunable = isinstance(noise_e, list)
+        self.noise_e, self.noise_f = (noise_e[0], noise_f[0]) if tunable else (noise_e, noise_f)
+        self.noise_bounds = noise_e[1:] if tunable else None
         self.f_coef = f_coef
-        self.error = None
-
-        self.descriptor = descriptor
-        self.kernel = kernel
-        self.base_potential = base_potential
-
-        self.x = None
-        self.train_x = None
-        self.train_y = None
-        self.train_db = None
-        self.N_energy = 0
-        self.N_forces = 0
-        self.N_energy_queue = 0
-        self.N_forces_queue = 0
-        self.N_queue = 0
+        self.kernel, self.descriptor, self.base_potential = kernel, descriptor, base_potential
+        # training set: nothing yet.  train_x / train_y / train_db are filled by set_train_pts; the *_queue counters count
+        # points added since the last fit (they are invisible to predictions until then, get_train_x)
+        self.x = self.train_x = self.train_y = self.train_db = None
+        for counter in ("N_energy", "N_forces", "N_energy_queue", "N_forces_queue", "N_queue"):
+            setattr(self, counter, 0)
+        self.error = None                # metrics of the last validate_data(show=True)
 
         # device-resident model state
         self._dense = {"L": None, "alpha": None, "dinv": None}   # Cholesky factor of K + noise [N, N], (K + noise)^-1 y
@@ -1446,65 +1434,70 @@ class GP():
         E.species_all = F.species_all = tuple(int(z) for z in np.unique(nbr.numbers))
         return {"energy": E, "force": F}, frees
 
+    # ---- add_structure: what the reference's routine (gaussianprocess.py:921-1002) amounts to
+    #   labels      the base potential's share is taken off the labels (on copies; upstream edits the caller's arrays);
+    #   judgement   a fitted model predicts the structure's energy per atom and every force component with their standard
+    #               deviations; a model that has never been fitted counts as "twice the tolerance uncertain" everywhere;
+    #   energy      always queued;
+    #   forces      atom a is a CANDIDATE when its largest force std exceeds tol_f or the flat force vector's entry number a
+    #               (sic -- upstream indexes the flattened [3n] arrays with the atom id; the trained sets depend on it) misses
+    #               its label by more than 1.5 tol_f; candidates are taken in atom order, each only if its descriptor is new
+    #               among those taken so far (utilities.new_pt), until N_max are in;
+    #   queue       one db record (atoms, E, F, True, atom ids) and the points go to set_train_pts("a+").
+    # tol_e = tol_e_var * noise_e, tol_f = tol_f_var * noise_f.
+    def _labels_without_base(self, atoms, energy, force):
+        if self.base_potential is None:
+            return energy, force, 0, np.zeros((len(atoms), 3))
+        e_off, f_off, _ = self.compute_base_potential(atoms)
+        return energy - e_off, force - f_off, e_off, f_off
+
+    def _judge_structure(self, my_data, natoms, energy, force, tol_e, tol_f):
+        """(E, E_pred, E_std, F, F_pred, F_std[n, 3]): labels per atom / flat, what the model says, how sure it is"""
+        if not self._fitted:
+            label_e, label_f = [energy / natoms], force.flatten()
+            return label_e, label_e, 2 * tol_e, label_f, label_f, np.full((natoms, 3), 2 * tol_f)
+        E, E_pred, E_std, F, F_pred, F_std = self.validate_data(my_data, return_std=True)
+        return E, E_pred, E_std[0], F, F_pred, F_std.reshape((natoms, 3))
+
+    @staticmethod
+    def _pick_force_points(x_rows, ele_rows, F, F_pred, F_std, tol_f, N_max):
+        """atom ids whose force environments are queued, in atom order"""
+        natoms = len(F_std)
+        flat_label, flat_pred = np.asarray(F, dtype=np.float64).reshape(-1), np.asarray(F_pred, dtype=np.float64).reshape(-1)
+        unsure = F_std.max(axis=1) > tol_f
+        off = np.abs(flat_label[:natoms] - flat_pred[:natoms]) > 1.5 * tol_f        # entry a of the FLAT vectors (see above)
+        candidates = np.flatnonzero(unsure | off)
+        if N_max == 0 and (len(candidates) == 0 or candidates[0] != 0):
+            return []                    # upstream tests "N_max points are in" at the END of every atom's turn, with ==:
+                                         # N_max = 0 stops after atom 0 unless atom 0 got in, and is never met again if it did
+        taken, seen = [], []
+        for a in candidates:
+            here = (x_rows[a], ele_rows[a])
+            if not seen or new_pt(here, seen):
+                taken.append(int(a))
+                seen.append(here)
+            if len(taken) == N_max:
+                break
+        return taken
+
     def add_structure(self, data, N_max=20, tol_e_var=1.2, tol_f_var=1.2, add_force=True):
-        """Queue training points from a labelled structure (gaussianprocess.py:921-1002): the energy
-        always, force points whose predicted std or error exceeds the tolerance, de-duplicated by
-        cosine similarity, at most N_max."""
-        tol_e_var *= self.noise_e
-        tol_f_var *= self.noise_f
-        pts_to_add = {"energy": [], "force": [], "db": []}
-        (atoms, energy, force) = data
-        if self.base_potential is not None:
-            energy_off, force_off, _ = self.compute_base_potential(atoms)
-        else:
-            energy_off, force_off = 0, np.zeros((len(atoms), 3))
-        energy = energy - energy_off
-        force = force - force_off
+        """Queue training points from a labelled structure `(atoms, energy, forces)`; returns (points, how many,
+        (E, E_pred, E_std, F, F_pred, F_std)) with the base potential's share added back to the energies and forces."""
+        atoms, energy, force = data
+        natoms = len(atoms)
+        tol_e, tol_f = tol_e_var * self.noise_e, tol_f_var * self.noise_f
+        energy, force, e_off, f_off = self._labels_without_base(atoms, energy, force)
         my_data = convert_train_data([(atoms, energy, force)], self.descriptor)
+        E, E_pred, E_std, F, F_pred, F_std = self._judge_structure(my_data, natoms, energy, force, tol_e, tol_f)
+        F, F_pred = np.asarray(F, dtype=np.float64).reshape(-1), np.asarray(F_pred, dtype=np.float64).reshape(-1)
 
-        if self._fitted:
-            E, E1, E_std, F, F1, F_std = self.validate_data(my_data, return_std=True)
-            E_std = E_std[0]
-            F_std = F_std.reshape((len(atoms), 3))
-        else:
-            E = E1 = [energy / len(atoms)]
-            F = F1 = force.flatten()
-            E_std = 2 * tol_e_var
-            F_std = 2 * tol_f_var * np.ones((len(atoms), 3))
-        # the reference keeps F / F1 flat ([3n]) and still indexes them with the atom id (gaussianprocess.py:978):
-        # the error test of atom f_id looks at flat component f_id.  Reproduced as is: it decides which points train.
-        F, F1 = np.asarray(F, dtype=np.float64).reshape(-1), np.asarray(F1, dtype=np.float64).reshape(-1)
-
-        pts_to_add["energy"] = my_data["energy"]
-        N_energy, energy_in = 1, True
-
-        force_in = []
-        if add_force:
-            xs_added = []
-            for f_id in range(len(atoms)):
-                include = False
-                if np.max(F_std[f_id]) > tol_f_var or np.max(abs(F[f_id] - F1[f_id])) > 1.5 * tol_f_var:
-                    X = my_data["energy"][0][0][f_id]
-                    _ele = my_data["energy"][0][2][f_id]
-                    if len(xs_added) == 0:
-                        include = True
-                    elif new_pt((X, _ele), xs_added):
-                        include = True
-                if include:
-                    force_in.append(f_id)
-                    xs_added.append((X, _ele))
-                    pts_to_add["force"].append(my_data["force"][f_id])
-                if len(force_in) == N_max:
-                    break
-
-        N_forces = len(force_in)
-        N_pts = N_energy + N_forces
-        if N_pts > 0:
-            pts_to_add["db"].append((atoms, energy, force, energy_in, force_in))
-            self.set_train_pts(pts_to_add, mode="a+")
-        errors = (E[0] + energy_off, E1[0] + energy_off, E_std,
-                  F + force_off.flatten(), F1 + force_off.flatten(), F_std)
-        return pts_to_add, N_pts, errors
+        x_rows, _, ele_rows = my_data["energy"][0]
+        atoms_in = self._pick_force_points(x_rows, ele_rows, F, F_pred, F_std, tol_f, N_max) if add_force else []
+        points = {"energy": my_data["energy"], "force": [my_data["force"][a] for a in atoms_in],
+                  "db": [(atoms, energy, force, True, atoms_in)]}
+        self.set_train_pts(points, mode="a+")
+        back = np.asarray(f_off).reshape(-1)
+        return points, 1 + len(atoms_in), (E[0] + e_off, E_pred[0] + e_off, E_std, F + back, F_pred + back, F_std)
 
     # ------------------------------------------------------------------ persistence (json + ASE db)
     def save(self, filename, db_filename, verbose=True):
@@ -1609,52 +1602,59 @@ class GP():
             self.remove_train_pts([int(p) for p in pts_e], pts_f)
         return list(pts_e), pts_f
 
+    # ---- bootstrap (gaussianprocess.py:1025-1116).  Two ways in:
+    #   a saved model (json_file exists): load it -- descriptors are recomputed from its db -- optionally replace noise levels
+    #   and kernel by the arguments (`overwrite`), fit with hyper-parameter optimisation, form K^-1;
+    #   from scratch: default kernel of the requested family, SO3(nmax, lmax, rcut), then train_images.
+    # Kernel families and their starting hyper-parameters as upstream: "Dot" -> Dot_mb([2, 2.0]), RBF_mb([1.0, 0.1]) otherwise;
+    # the overwrite branch decides the other way round ("RBF" -> RBF_mb, anything else Dot_mb) and only when the family changes.
+    @staticmethod
+    def _starting_kernel(family, zeta):
+        return Dot_mb(para=[2, 2.0], zeta=zeta) if family == "Dot" else RBF_mb(para=[1.0, 0.1], zeta=zeta)
+
     @classmethod
     def set_GPR(cls, images, base, kernel='RBF', zeta=2.0, noise_e=0.002, noise_f=0.1, lmax=4, nmax=3, rcut=5.0,
                 json_file=None, overwrite=False):
-        """Set up and train a model from images (gaussianprocess.py:1025-1072)."""
+        """Model for a set of images: restored from `json_file` when that exists, trained on the images otherwise."""
         from .SO3 import SO3
-        if json_file is not None and os.path.exists(json_file):
-            instance = cls.load(json_file)
-            if overwrite:
-                if instance.noise_e != noise_e:
-                    instance.noise_e = noise_e
-                if instance.noise_f != noise_f:
-                    instance.noise_f = noise_f
-                if instance.kernel.name != kernel:
-                    instance.kernel = RBF_mb(para=[1.0, 0.1], zeta=zeta) if kernel == "RBF" else \
-                        Dot_mb(para=[2, 2.0], zeta=zeta)
-            instance.fit()
-            instance.set_K_inv()
-        else:
-            instance = cls(kernel=None, descriptor=None, base_potential=None)
-            instance.kernel = Dot_mb(para=[2, 2.0], zeta=zeta) if kernel == 'Dot' else RBF_mb(para=[1.0, 0.1], zeta=zeta)
-            instance.descriptor = SO3(nmax=nmax, lmax=lmax, rcut=rcut)
-            instance.noise_e = noise_e
-            instance.noise_f = noise_f
-            instance.train_images(images, base)
-        return instance
+        restore = json_file is not None and os.path.exists(json_file)
+        if not restore:
+            gp = cls(kernel=cls._starting_kernel(kernel, zeta), descriptor=SO3(nmax=nmax, lmax=lmax, rcut=rcut),
+                     base_potential=None)
+            gp.noise_e, gp.noise_f = noise_e, noise_f
+            gp.train_images(images, base)
+            return gp
+        gp = cls.load(json_file)
+        if overwrite:
+            gp.noise_e, gp.noise_f = noise_e, noise_f
+            if gp.kernel.name != kernel:
+                gp.kernel = cls._starting_kernel("RBF" if kernel == "RBF" else "Dot", zeta)
+        gp.fit()
+        gp.set_K_inv()
+        return gp
+
+    def _label_image(self, image, base, tag):
+        """energy and forces of one image from the base calculator (rank 0 only; the others get them by broadcast).
+        Calculators that write files (ase's Vasp has `set`) get a directory of their own per image."""
+        eng, forces = 0.0, None
+        if self.rank == 0:
+            image.calc = base
+            if hasattr(base, 'set'):
+                try:
+                    base.set(directory=f"GP/calc_{tag}")
+                except Exception:
+                    pass
+            eng, forces = image.get_potential_energy(), image.get_forces()
+            print(f"Calculate E/F for image {tag}: {eng:.6f}")
+        image.calc = None
+        self.comm.barrier()
+        return self.comm.bcast(eng, root=0), self.comm.bcast(forces, root=0)
 
     def train_images(self, images, base):
-        """Label every image with the base calculator on rank 0, queue them, fit
-        (gaussianprocess.py:1074-1116)."""
-        for i, image in enumerate(images):
-            if self.rank == 0:
-                image.calc = base
-                if hasattr(image.calc, 'set'):
-                    try:
-                        image.calc.set(directory=f"GP/calc_{i}")
-                    except Exception:
-                        pass
-                eng = image.get_potential_energy()
-                forces = image.get_forces()
-                print(f"Calculate E/F for image {i}: {eng:.6f}")
-            else:
-                eng, forces = 0.0, None
-            image.calc = None
-            self.comm.barrier()
-            eng = self.comm.bcast(eng, root=0)
-            forces = self.comm.bcast(forces, root=0)
+        """Label every image with the base calculator, queue what add_structure selects, then fit (with optimisation),
+        validate on the training set and form K^-1."""
+        for tag, image in enumerate(images):
+            eng, forces = self._label_image(image, base, tag)
             self.add_structure((image.copy(), eng, forces))
         self.fit()
         self.validate_data()

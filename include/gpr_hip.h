@@ -10,8 +10,11 @@
  *       names, argument order and semantics: HOST pointers in and out, outputs ACCUMULATED
  *       (+= / -=) into caller-zeroed buffers, rows with |x| <= 1e-8 and species mismatches
  *       skipped, void return.  They upload, run the HIP kernels on the current device and
- *       download; a failure (no GPU, bad shapes) is reported through gpr_last_error() and
- *       aborts loudly on stderr -- there is NO CPU fallback.
+ *       download.  There is NO CPU fallback and nothing terminates the process: on a failure
+ *       (no GPU, a HIP error, an unsupported shape) the output buffers are left untouched, the
+ *       reason is printed once on stderr and kept for gpr_last_error(), and the status of the
+ *       most recent L0 call is what gpr_l0_last_status() returns (the void signature has no
+ *       other channel).
  *
  *  (L1) Device-resident API used by the Python host layer (gpr_calculator_amd/): descriptor
  *       rows are packed once into MFMA operand order (gpr_set), covariance blocks are written

@@ -87,12 +87,26 @@ class ThreadComm:
 
     Barrier = barrier
 
+    @staticmethod
+    def _sync():
+        """Thread ranks share one device but not one stream (the look-ahead schedule moves its chain to a side stream per
+        rank): what a rank hands to the others must be complete when they read it, and what it read must have been read
+        before the owner reuses the memory.  A real backend orders this with stream events; here the host waits."""
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            torch.cuda.current_stream().synchronize()
+
     def _exchange(self, value):
+        self._sync()
         self.w.slots[self._rank] = value
         self.w.barrier.wait()
         out = list(self.w.slots)
         self.w.barrier.wait()
         return out
+
+    def _done(self):
+        """every rank has finished reading what the others handed over"""
+        self._sync()
+        self.w.barrier.wait()
 
     def bcast(self, obj, root=0):
         return self._exchange(obj)[root]
@@ -108,8 +122,10 @@ class ThreadComm:
         parts = self._exchange(local)
         cat = torch.cat([p[:int(c)] for p, c in zip(parts, counts)], dim=0)
         if out is None:
-            return cat.clone()
-        out.copy_(cat)
+            out = cat.clone()
+        else:
+            out.copy_(cat)
+        self._done()
         return out
 
     def gather_slabs_inplace(self, full, row0, counts, owners):
@@ -117,6 +133,7 @@ class ThreadComm:
         for part in self._exchange(mine):
             for o, c, rows in part:
                 full[o:o + c].copy_(rows)
+        self._done()
         return full
 
     def all_reduce_max_(self, t):
@@ -125,6 +142,7 @@ class ThreadComm:
         for p in parts[1:]:
             total = torch.maximum(total, p)
         t.copy_(total)
+        self._done()
         return t
 
     def all_reduce_sum_(self, t):
@@ -133,13 +151,14 @@ class ThreadComm:
         for p in parts[1:]:
             total += p
         t.copy_(total)
+        self._done()
         return t
 
     def broadcast_(self, t, root=0):
         parts = self._exchange(t)
         if self._rank != root:
             t.copy_(parts[root])
-        self.w.barrier.wait()          # the root must not overwrite its tensor before everybody has copied it
+        self._done()                   # the root must not overwrite its tensor before everybody has copied it
         return t
 
 
