@@ -32,7 +32,7 @@ def timed(owner, name, label=None):
     setattr(owner, name, g)
 
 
-timed(loop, "lj_energy_forces", "base potential (numpy LJ, host)")
+timed(loop.Base, "_eval", "base calculator (numpy LJ on the host; not GPR)")
 timed(GP, "predict_structure", "predict_structure (surrogate)")
 timed(GP, "add_structure", "add_structure")
 timed(gpmod, "convert_train_data", "  add_structure: descriptor + packing")
@@ -60,5 +60,6 @@ for k, (n, s) in acc.items():
 print(f"loop total {sum(secs) * 1e3:.1f} ms; N at the end = {len(gp.y_train)} (energy {gp.N_energy}, force {gp.N_forces})")
 if pr:
     s = io.StringIO()
-    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(45)
+    pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(70)
+    pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(40)
     print(s.getvalue())
