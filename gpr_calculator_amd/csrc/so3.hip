@@ -27,6 +27,7 @@
 // lane per (pair, l) and adds them over the pairs of a seq row in an LDS row buffer that is written out as the
 // centre's slab of dxdr (the stress variant walks the seq rows instead, one row per wavefront).  No floating-point
 // atomics; the summation order is fixed.
+#include <atomic>
 #include "gpr_internal.h"
 
 namespace {
@@ -96,6 +97,7 @@ __host__ __device__ inline so3_tab so3_table_layout(int nmax, int lmax, int nseg
     t.oCG = off; off += L * M * 6;
     t.oNL = off; off += L;
     t.oRI = off; off += YW * YW;
+    off = (off + 1) & ~1;                                       // entries of GT are read 16 bytes at a time
     t.oGT = off; off += (L * L + L) * 3 * SO3_GT_W;
     t.total = off;
     return t;
@@ -822,6 +824,402 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
     }
 }
 
+// ---------------------------------------------------------------- the same kernel with (nmax, lmax) known at compile time
+// The generic kernel above carries nmax / lmax as run-time values, so every index -- record strides, table offsets, the LDS
+// layout, triangular decodes -- is integer arithmetic at run time (more than half of its vector instructions are not
+// floating point, and its scalar unit spills to vector lanes).  The reference uses ONE configuration everywhere
+// (SO3(nmax = 3, lmax = 4): gaussianprocess.py:1028, examples/database/pd4-RBF.json:24-31): this instance has every size as a
+// constant and its phases re-mapped so that nearly all 256 lanes work in each of them:
+//   radial part   lane = (pair, l): the three channels (n, l) of one l, as dot products of the Chebyshev coefficients with
+//                 T_k(t) formed once per lane (one multiply-add per coefficient instead of the two of the Clenshaw recurrence);
+//   angular part  lane = (pair, m): Y_l^m for l = m .. lmax + 1 as N_lm Q_l^m(cos theta) (u_x + i u_y)^m -- the azimuth and the
+//                 sin^m theta factor of the associated Legendre function are one complex power, no square root, no division
+//                 and no special case on the axis;
+//   c_tot         45 tasks (n, l, m >= 0) x 5 pair groups;
+//   gradient map  lane = table entry, the three n in a row (the map is the same for every n: one read of its coefficients);
+//   pass 2        lane = (pair, l) with the heavy l first (a wavefront pays for the largest l it holds).
+// Same arithmetic as the generic kernel up to the order of a few sums; tests/test_gpu_so3.py holds both to the goldens of the
+// reference's own SO3.calculate and to each other.
+template <int NMAX, int LMAX>
+struct so3_fx {
+    static constexpr int L = LMAX + 1, M = 2 * LMAX + 1, NL = NMAX * L, YW = LMAX + 3, LT = LMAX + 1;
+    static constexpr int NPI = NMAX * (NMAX + 1) / 2, D = NPI * L, NE = 3 * D;
+    static constexpr int TRI = (LT + 1) * (LT + 2) / 2;       // Y_l^m, 0 <= m <= l <= LT
+    static constexpr int TRIL = L * (L + 1) / 2;              // (l, m >= 0) with l <= LMAX
+    static constexpr int NLP = (NL + 1) & ~1;                 // channel tables padded to an even length (16-byte records)
+    static constexpr int REC = 8 + 2 * NLP + 2 * TRI;
+    static constexpr int PC = 256 / (LT + 1);                 // pairs per chunk: (pair, m) lanes for m = 0 .. LT
+    static constexpr int NB = (L * L + L) * 3;                // gradient-table entries per n
+    static constexpr int NLM = NL * M;
+    static constexpr int NTASK = NMAX * TRIL, NGRP = 256 / NTASK;          // c_tot tasks and pair groups
+    static constexpr int NF = 2 * NL;
+    // LDS (doubles)
+    static constexpr int oNY = 0, oRI = YW * YW, oQB = 2 * YW * YW, oNLc = 3 * YW * YW;
+    static constexpr int oCtot = (oNLc + L + 1) & ~1;
+    static constexpr int oRf = oCtot + 2 * NLM;
+    static constexpr int oTf = oRf + 2 * NL * L;
+    static constexpr int oPart = oTf;                           // the partial sums of c_tot are consumed before T is written
+    static constexpr int oRec = oTf + (2 * NMAX * NB > 2 * NTASK * NGRP ? 2 * NMAX * NB : 2 * NTASK * NGRP);
+    static constexpr int AREA_REC = PC * REC + PC + 2, AREA_ROWS = (PC + 1) * NE;
+    static constexpr int AREA = AREA_REC > AREA_ROWS ? AREA_REC : AREA_ROWS;
+    static constexpr int TOTAL = oRec + (AREA > 2 * SO3_SELFW ? AREA : 2 * SO3_SELFW);
+    static_assert(L * PC <= 256 && (LT + 1) * PC <= 256 && NE <= SO3_SELFW && NB <= 256 && D <= 64 && NGRP >= 1, "lane maps");
+};
+
+#ifndef GPR_SO3_FIXED_WAVES
+#define GPR_SO3_FIXED_WAVES 3
+#endif
+template <int NMAX, int LMAX>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO3_FIXED_WAVES, 4))) so3_fixed_kernel(so3_args P) {
+    using F = so3_fx<NMAX, LMAX>;
+    constexpr int L = F::L, M = F::M, YW = F::YW, LT = F::LT, NPI = F::NPI, NE = F::NE, NLP = F::NLP, REC = F::REC,
+                  PC = F::PC, NB = F::NB, NLM = F::NLM, NTASK = F::NTASK, NGRP = F::NGRP, NF = F::NF, TRIL = F::TRIL;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const double *sNY = smem + F::oNY, *sQA = smem + F::oRI, *sQB = smem + F::oQB, *sNL = smem + F::oNLc;
+    cplx *ctot = (cplx *)(smem + F::oCtot), *sRf = (cplx *)(smem + F::oRf), *sTf = (cplx *)(smem + F::oTf);
+    double *recs = smem + F::oRec, *sSelf = recs;
+    const int tid = threadIdx.x;
+    // Wavefront w of every workgroup runs on SIMD w, and the phases below give the wavefronts unequal work (the heavy l of pass 2,
+    // the long m chains, the table entries).  The roles are therefore rotated from workgroup to workgroup -- `vt` is the thread
+    // id all task maps use -- so that the workgroups resident on a CU (ids 256 apart) load its four SIMDs evenly.
+    const int wave = ((tid >> 6) + (blockIdx.x >> 8) + (blockIdx.x >> 3)) & 3, vt = (wave << 6) | (tid & 63);
+    const int ic = blockIdx.x;
+    const int p0 = P.centre_pair0[ic], p1 = P.centre_pair0[ic + 1];
+    const int r0 = P.centre_row0[ic], r1 = P.centre_row0[ic + 1];
+    const so3_tab tab = so3_table_layout(NMAX, LMAX, P.nseg, SO3_NCHEB);
+    // angular constants in the form the recurrence below wants them: N_lm (-1)^m (2m - 1)!!, (2l - 1) / (l - m), (l + m - 1) / (l - m)
+    for (int e = tid; e < YW * YW; e += 256) {
+        const int l = e / YW, m = e - l * YW;
+        double pref = 1.0;
+        for (int k = 1; k <= m; k++) pref *= -(double)(2 * k - 1);
+        const double ri = P.table[tab.oRI + e];                 // 1 / (l - m) for l > m, else 0
+        smem[F::oNY + e] = P.table[tab.oNY + e] * pref;
+        smem[F::oRI + e] = (2 * l - 1) * ri;
+        smem[F::oQB + e] = (l + m - 1) * ri;
+    }
+    if (tid < L) smem[F::oNLc + tid] = P.table[tab.oNL + tid];
+    __syncthreads();
+
+    // lane maps of the two halves of a chunk's tables: (l or m) = vt / PC, pair = vt % PC
+    const int hi = vt / PC, q_lane = vt - hi * PC;
+    const double seg_scale = (double)P.nseg / P.rcut, inv_rcut = 1.0 / P.rcut;
+    // (hi_ / q_: the lane's coordinates behind an empty asm, so that the addresses derived from them are formed where they are
+    //  used -- hoisted out of the chunk loops, which almost always run once, they only sit in registers and spill)
+    auto build_records = [&](int c0, int npc) {
+        int hi_ = hi, q_ = q_lane;
+        asm volatile("" : "+v"(hi_), "+v"(q_));
+        if (hi_ < L && q_ < npc) {                              // radial channels (n, l = hi) of pair q
+            const int l = hi_, p = c0 + q_;
+            double *rec = recs + q_ * REC;
+            const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+            const double r2 = vx * vx + vy * vy + vz * vz, w = P.wj[p];
+            // The segment of the Chebyshev table from a single-precision root: the coefficient loads -- the long latency of this
+            // phase -- then do not wait for the double-precision one.  A radius within 1e-7 of a segment boundary may land in
+            // the neighbouring segment, whose polynomial is just as good there (t a hair outside [-1, 1]).
+            int seg = (int)(__builtin_sqrtf((float)r2) * (float)seg_scale);
+            seg = seg < 0 ? 0 : (seg > P.nseg - 1 ? P.nseg - 1 : seg);
+            const double2 *cb = (const double2 *)(P.table + (size_t)seg * SO3_NCHEB * NF) + l;
+            // coefficients of F0 / F1 (one 16-byte load for both) in halves of eight: the halves of channel n + 1 are
+            // requested while those of channel n are multiplied, 16 loads in flight at any time
+            constexpr int H = SO3_NCHEB / 2;
+            double2 ca[H], cl[H];
+#pragma unroll
+            for (int k = 0; k < H; k++) ca[k] = cb[(H + k) * (NF / 2)];
+#pragma unroll
+            for (int k = 0; k < H; k++) cl[k] = cb[k * (NF / 2)];
+            const double r = sqrt(r2);
+            double sarg, carg;
+            sincospi(r * inv_rcut, &sarg, &carg);              // cutoff 0.5 (cos(pi r / rcut) + 1) and its derivative
+            const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI * inv_rcut * sarg;
+            const double t = (r * seg_scale - (seg + 0.5)) * 2.0, t2 = 2.0 * t;
+            const double nw = sNL[l] * w;                       // SO3.py:206, 221
+            // sum_k c_k T_k(t) with T_k formed on the way (T_{k+1} = 2 t T_k - T_{k-1}: two registers instead of a table of
+            // sixteen per lane); the upper half of the coefficients is multiplied first, so T_8, T_9 are carried over
+            double T8, T9;
+#pragma unroll
+            for (int n = 0; n < NMAX; n++) {
+                double f0 = 0.0, f1 = 0.0;
+                if (n == 0) {
+                    double ta = 1.0, tb = t;                    // T_0, T_1 -> T_8, T_9 once
+#pragma unroll
+                    for (int k = 2; k <= H + 1; k++) { const double tc = fma(t2, tb, -ta); ta = tb; tb = tc; }
+                    T8 = ta; T9 = tb;
+                }
+                {
+                    double ta = T8, tb = T9;
+#pragma unroll
+                    for (int k = 0; k < H; k++) {
+                        f0 = fma(ca[k].x, ta, f0); f1 = fma(ca[k].y, ta, f1);
+                        const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);              // (the scheduler would otherwise hoist every load of every
+                if (n + 1 < NMAX) {                             //  channel to the top and spill half of them)
+#pragma unroll
+                    for (int k = 0; k < H; k++) ca[k] = cb[(n + 1) * L + (H + k) * (NF / 2)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    double ta = 1.0, tb = t;
+#pragma unroll
+                    for (int k = 0; k < H; k++) {
+                        f0 = fma(cl[k].x, ta, f0); f1 = fma(cl[k].y, ta, f1);
+                        const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                if (n + 1 < NMAX) {
+#pragma unroll
+                    for (int k = 0; k < H; k++) cl[k] = cb[(n + 1) * L + k * (NF / 2)];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                rec[8 + n * L + l] = nw * (fc * f1 + dfc * f0);
+                rec[8 + NLP + n * L + l] = nw * fc * f0;
+            }
+            if (l == 0) {
+                const double inv_r = 1.0 / r;
+                rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
+            }
+        }
+        __syncthreads();
+        asm volatile("" : "+v"(hi_), "+v"(q_));
+        if (hi_ <= LT && q_ < npc) {                            // Y_l^m, m = hi, of pair q
+            const int m = hi_;
+            double *rec = recs + q_ * REC;
+            const double ux = rec[0], uy = rec[1], ct = rec[2];
+            double er = 1.0, ei = 0.0;                          // (u_x + i u_y)^m
+#pragma unroll
+            for (int k = 1; k <= LT; k++)
+                if (k <= m) {
+                    const double e2 = er * ux - ei * uy;
+                    ei = er * uy + ei * ux; er = e2;
+                }
+            cplx *Y = (cplx *)(rec + 8 + 2 * NLP);
+            // Q_m^m = 1, Q_l^m = ((2l - 1) cos(theta) Q_{l-1}^m - (l + m - 1) Q_{l-2}^m) / (l - m) with Q_{m-1}^m = 0
+            double q2 = 0.0, q1 = 1.0;
+            { const double nrm = sNY[m * YW + m]; Y[m * (m + 1) / 2 + m] = {nrm * er, nrm * ei}; }
+#pragma unroll
+            for (int s_ = 1; s_ <= LT; s_++) {
+                const int l = m + s_;
+                if (l <= LT) {
+                    const double ql = sQA[l * YW + m] * ct * q1 - sQB[l * YW + m] * q2;
+                    q2 = q1; q1 = ql;
+                    const double nrm = sNY[l * YW + m] * ql;
+                    Y[l * (l + 1) / 2 + m] = {nrm * er, nrm * ei};
+                }
+            }
+        }
+        __syncthreads();
+    };
+
+    // ---- pass 1: c_tot[nl][m >= 0] = sum over pairs of B_nl Y_l^m: task = (n, l, m), NGRP groups of lanes take the pairs
+    //      q = g, g + NGRP, ... and their partial sums are added in group order
+    const int nchunks = (p1 - p0 + PC - 1) / PC;
+    {
+        const int grp = vt / NTASK, task = vt - grp * NTASK;
+        const int n = task / TRIL, rem = task - n * TRIL;
+        int l = 0;
+        while ((l + 1) * (l + 2) / 2 <= rem) l++;
+        const int m = rem - l * (l + 1) / 2, nl = n * L + l;
+        const bool mine = grp < NGRP;
+        cplx acc = {0.0, 0.0};
+        for (int c0 = p0; c0 < p1; c0 += PC) {
+            const int npc = min(PC, p1 - c0);
+            build_records(c0, npc);
+            GPR_PHASE_EXIT(P.dbg, 1)
+            if (mine)
+                for (int q = grp; q < npc; q += NGRP) {
+                    const double *rec = recs + q * REC;
+                    const cplx y = ((const cplx *)(rec + 8 + 2 * NLP))[l * (l + 1) / 2 + m];
+                    const double b = rec[8 + NLP + nl];
+                    acc.re = fma(b, y.re, acc.re); acc.im = fma(b, y.im, acc.im);
+                }
+            if (nchunks > 1) __syncthreads();                  // records are rebuilt by the next chunk
+        }
+        cplx *sPart = (cplx *)(smem + F::oPart);
+        if (mine) sPart[grp * NTASK + task] = acc;
+        for (int e = tid; e < NLM; e += 256) ctot[e] = {0.0, 0.0};
+        __syncthreads();
+        if (grp == 0) {
+#pragma unroll
+            for (int g = 1; g < NGRP; g++) { const cplx o = sPart[g * NTASK + task]; acc.re += o.re; acc.im += o.im; }
+            ctot[nl * M + LMAX + m] = acc;
+            if (m > 0) { const double sg = (m & 1) ? -1.0 : 1.0; ctot[nl * M + LMAX - m] = {sg * acc.re, -sg * acc.im}; }
+            sRf[nl * L + m] = (m == 0) ? acc : cplx{2.0 * acc.re, 2.0 * acc.im};
+        }
+    }
+    __syncthreads();
+
+    // ---- power spectrum x_i (the last lanes of the block) and the gradient tables (the first NB) side by side
+    if (vt >= 256 - F::D) {
+        const int c = vt - (256 - F::D), pi = c / L, l = c - pi * L;
+        int n1 = 0;
+        while ((n1 + 1) * (n1 + 2) / 2 <= pi) n1++;
+        const int n2 = pi - n1 * (n1 + 1) / 2;
+        const cplx *a = ctot + (n1 * L + l) * M, *b = ctot + (n2 * L + l) * M;
+        double s = 0.0;
+#pragma unroll
+        for (int mi = 0; mi < M; mi++) s += a[mi].re * b[mi].re + a[mi].im * b[mi].im;
+        P.x[(size_t)ic * F::D + c] = s;
+    }
+    if (vt < NB) {
+        // entry `vt` of the linear map c_tot -> T (so3_grad_map_kernel): [l, nterm <= 4, 4 x (source m, p, q, r, s)], applied to
+        // the three n one after the other
+        const double2 *g2 = (const double2 *)(P.table + tab.oGT + (size_t)vt * SO3_GT_W);
+        const double2 head = g2[0];
+        const int l = (int)head.x, nterm = (int)head.y;
+        if (l >= 1) {
+            double2 tm[10];
+#pragma unroll
+            for (int k = 0; k < 10; k++) tm[k] = g2[1 + k];
+            const double *tv = (const double *)tm;              // 4 x [m, p, q, r, s]
+#pragma unroll
+            for (int n = 0; n < NMAX; n++) {
+                cplx out = {0.0, 0.0};
+#pragma unroll
+                for (int t = 0; t < 4; t++)
+                    if (t < nterm) {
+                        const cplx c = ctot[(n * L + l) * M + LMAX + (int)tv[5 * t]];
+                        out.re += tv[5 * t + 1] * c.re + tv[5 * t + 2] * c.im;
+                        out.im += tv[5 * t + 3] * c.re + tv[5 * t + 4] * c.im;
+                    }
+                sTf[n * NB + vt] = out;
+            }
+        }
+    }
+    __syncthreads();
+    GPR_PHASE_EXIT(P.dbg, 2)
+
+    // ---- pass 2: dP rows.  Lane = (pair q, l), heavy l first: l = L - 1 - vt / PC
+    if (r0 == r1) return;                         // no rows at all: the emptied table of an overflowed capped build (nbr.hip)
+    const int rself = P.self_row[ic];
+    int *sMap = (int *)(recs + PC * REC);                    // [PC] row of the pair (centre-local), [PC] index in its row, max
+    double *rowOut = recs;
+    constexpr int NSP = 256 / NE >= 2 ? 2 : 1;               // (i, i) row: column sums in two interleaved halves
+    const int spart = tid / NE, scol = tid - spart * NE;
+    double selfacc = 0.0;
+    const int l_lane = L - 1 - hi;                           // (negative l: idle lane)
+    // the largest l among the lanes of this wavefront: terms beyond it are skipped by the whole wavefront
+    const int lw = __builtin_amdgcn_readfirstlane(max(0, L - 1 - (64 * wave) / PC));
+    for (int c0 = p0; c0 < p1; c0 += PC) {
+        const int npc = min(PC, p1 - c0), c1 = c0 + npc;
+        if (nchunks > 1) build_records(c0, npc);              // a single chunk is still resident from pass 1
+        if (tid == 0) sMap[2 * PC] = 0;
+        __syncthreads();
+        for (int row = r0 + tid; row < r1; row += 256) {
+            const int a = max(P.row_pair0[row], c0), b = min(P.row_pair0[row + 1], c1);
+            for (int p = a; p < b; p++) { sMap[p - c0] = row - r0; sMap[PC + p - c0] = p - a; }
+            if (b > a) atomicMax(&sMap[2 * PC], b - a);
+        }
+        int l = l_lane, q = q_lane;
+        asm volatile("" : "+v"(l), "+v"(q));                 // (see build_records)
+        const bool active = l >= 0 && q < npc;
+        double outv[NPI * 3];
+        if (active) {
+            const double *rec = recs + q * REC;
+            const cplx *Y = (const cplx *)(rec + 8 + 2 * NLP);
+            double Rn[NMAX], Sn[NMAX][3];
+#pragma unroll
+            for (int n = 0; n < NMAX; n++) { Rn[n] = 0.0; Sn[n][0] = 0.0; Sn[n][1] = 0.0; Sn[n][2] = 0.0; }
+            {
+                const cplx *yl = Y + l * (l + 1) / 2, *rf = sRf + l * L;
+#pragma unroll
+                for (int m = 0; m < L; m++)
+                    if (m <= lw && m <= l) {
+                        const cplx y = yl[m];
+#pragma unroll
+                        for (int n = 0; n < NMAX; n++) { const cplx c = rf[n * L * L + m]; Rn[n] += y.re * c.re + y.im * c.im; }
+                    }
+            }
+            if (l >= 1) {
+                const cplx *y0 = Y + (l - 1) * l / 2, *y1 = Y + (l + 1) * (l + 2) / 2;
+                const cplx *tf = sTf + so3_tf_base(0, l, L);
+                const int kstep = 2 * l + 2;
+#pragma unroll
+                for (int m = 0; m < L - 1; m++)
+                    if (m < lw && m < l) {
+                        const cplx y = y0[m];
+#pragma unroll
+                        for (int n = 0; n < NMAX; n++)
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                const cplx c = tf[n * NB + k * kstep + m];
+                                Sn[n][k] += y.re * c.re + y.im * c.im;
+                            }
+                    }
+#pragma unroll
+                for (int m = 0; m < L + 1; m++)
+                    if (m < lw + 2 && m < l + 2) {
+                        const cplx y = y1[m];
+#pragma unroll
+                        for (int n = 0; n < NMAX; n++)
+#pragma unroll
+                            for (int k = 0; k < 3; k++) {
+                                const cplx c = tf[n * NB + k * kstep + l + m];
+                                Sn[n][k] += y.re * c.re + y.im * c.im;
+                            }
+                    }
+            }
+            const double inv_r = rec[3], u[3] = {rec[0], rec[1], rec[2]};
+            double An[NMAX], Bn[NMAX];
+#pragma unroll
+            for (int n = 0; n < NMAX; n++) { An[n] = rec[8 + n * L + l]; Bn[n] = rec[8 + NLP + n * L + l] * inv_r; }
+#pragma unroll
+            for (int n1 = 0; n1 < NMAX; n1++)
+#pragma unroll
+                for (int n2 = 0; n2 <= n1; n2++) {
+                    const double ar = An[n1] * Rn[n2] + An[n2] * Rn[n1];
+#pragma unroll
+                    for (int k = 0; k < 3; k++)
+                        outv[(n1 * (n1 + 1) / 2 + n2) * 3 + k] = u[k] * ar + Bn[n1] * Sn[n2][k] + Bn[n2] * Sn[n1][k];
+                }
+        }
+        __syncthreads();                                  // records read, pair -> row map complete
+#ifdef GPR_PHASE_ABLATION
+        if (P.dbg == 3) { if (active && outv[0] == 1.234567e300) P.x[0] = 0.0; return; }   // ablation: keep outv alive
+#endif
+        const int myrow = active ? sMap[q] : 0, myj = active ? sMap[PC + q] : -1;
+        const int rowb = sMap[0], nrows_c = sMap[npc - 1] - rowb + 1, maxj = sMap[2 * PC];
+        const bool cont = P.row_pair0[r0 + rowb] < c0;    // the chunk's first row began in the previous chunk
+        __syncthreads();                                  // map read: the row buffer may take its place
+        const bool mine = active && r0 + myrow != rself;  // periodic images of the centre itself cancel (SO3.py:266-273)
+        double *dst = rowOut + (myrow - rowb) * NE + l * 3;
+        for (int j = 0; j < maxj; j++) {
+            if (mine && myj == j) {
+#pragma unroll
+                for (int pi = 0; pi < NPI; pi++)
+#pragma unroll
+                    for (int k = 0; k < 3; k++) {
+                        double *o = dst + pi * L * 3 + k;
+                        *o = j == 0 ? outv[pi * 3 + k] : *o + outv[pi * 3 + k];
+                    }
+            }
+            __syncthreads();
+        }
+        GPR_PHASE_EXIT(P.dbg, 4)
+        // the chunk's slab of dxdr, flat and 16 bytes at a time (a row is NE * 8 = 720 bytes); the (i, i) row is skipped
+        static_assert(NE % 2 == 0, "rows are whole 16-byte pieces");
+        {
+            double2 *gdst = (double2 *)(P.dxdr + (size_t)(r0 + rowb) * NE);
+            const double2 *src = (const double2 *)rowOut;
+            for (int f = tid; f < nrows_c * (NE / 2); f += 256) {
+                const int rl = f / (NE / 2);
+                if (r0 + rowb + rl == rself) continue;
+                double2 v = src[f];
+                if (cont && rl == 0) { const double2 o = gdst[f]; v.x += o.x; v.y += o.y; }
+                gdst[f] = v;
+            }
+        }
+        if (spart < NSP)
+            for (int rl = spart; rl < nrows_c; rl += NSP)
+                if (r0 + rowb + rl != rself) selfacc += rowOut[rl * NE + scol];
+        __syncthreads();                                  // row buffer consumed (the next chunk rebuilds the records)
+    }
+    if (spart < NSP) sSelf[spart * SO3_SELFW + scol] = selfacc;
+    __syncthreads();
+    for (int e = tid; e < NE; e += 256) P.dxdr[(size_t)rself * NE + e] = -(sSelf[e] + (NSP == 2 ? sSelf[SO3_SELFW + e] : 0.0));
+}
+
 int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char *who) {
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1;
     if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > SO3_NCAP || (nmax > 4 && lmax > 3) || nq > SO3_NQCAP || nmax * L > so3_nlp(nmax, lmax) ||
@@ -835,6 +1233,11 @@ int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char
 }
 
 }  // namespace
+
+// 0 (default): configurations that have a compile-time instance take it; 1: always the generic kernel (tests hold the
+// two against each other)
+static std::atomic<int> g_so3_variant{0};
+extern "C" int gpr_so3_set_variant(int generic_only) { g_so3_variant.store(generic_only ? 1 : 0); return GPR_OK; }
 
 extern "C" long long gpr_so3_table_size(int nmax, int lmax, int nseg, int ncheb) {
     return so3_table_layout(nmax, lmax, nseg, ncheb).total;
@@ -949,7 +1352,12 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
     const bool small_l = lmax + 1 <= 5 && nmax <= 3;
-    if (rdxdr) {
+    if (!rdxdr && nmax == 3 && lmax == 4 && g_so3_variant.load() == 0) {
+        // the configuration of the reference's defaults: every size a compile-time constant (so3_fixed_kernel)
+        using F = so3_fx<3, 4>;
+        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4>, F::TOTAL * (int)sizeof(double)))) return rc;
+        hipLaunchKernelGGL((so3_fixed_kernel<3, 4>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
+    } else if (rdxdr) {
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
     } else {

@@ -351,6 +351,10 @@ int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double
                            const double *vec, const double *wj, const int *centre_pair0,
                            const int *centre_row0, const int *row_pair0, const int *self_row,
                            double *x, double *dxdr);
+/* The configuration of the reference's defaults, SO3(nmax = 3, lmax = 4), has a kernel instance with every size known at
+ * compile time; every other (nmax, lmax) -- and the stress rows -- take the generic kernel.  gpr_so3_set_variant(1) sends
+ * everything through the generic kernel (tests compare the two), 0 restores the default. */
+int gpr_so3_set_variant(int generic_only);
 /* same plus the stress rows rdxdr[nrows, d, 3, 3] = -pstress / volume of SO3.calculate(stress=True)
  * (SO3.py:240-306): positions[ncentres, 3] = centre positions as the caller gave them (not wrapped),
  * inv_vol[ncentres] = 1 / cell volume of the centre's structure, both device; rdxdr == NULL: as above */

@@ -280,3 +280,37 @@ def test_gp_end_to_end_with_a_long_descriptor(port_natives, nl):
         E, F, _, E_std, F_std = gp.predict_structure(test, stress=False, return_std=True, f_tol=1e-12)
         assert abs(E - mean[0] * len(test)) < 1e-6 and np.abs(F - mean[1:].reshape(-1, 3)).max() < 1e-5
         assert np.isfinite(E_std) and np.isfinite(F_std).all()
+
+
+def test_compile_time_instance_agrees_with_the_generic_kernel():
+    """SO3(3, 4) runs so3_fixed_kernel<3, 4> (all sizes constants, re-mapped phases); gpr_so3_set_variant(1) sends the same
+    batch through the generic kernel.  Ragged batch: clusters, a dense cell whose centres need several chunks of pairs,
+    two species with sign-flipping weights, an isolated atom (no pairs, one row)."""
+    import torch
+    from gpr_calculator_amd import _lib
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.neighbors import SimpleAtoms
+    from gpr_calculator_amd.synthetic import fcc_cell, neb_images
+    rng = np.random.default_rng(4)
+    dense = fcc_cell(seed=5, reps=2, species=(46, 78), sigma=0.1)
+    dense.positions *= 0.8; dense.cell = dense.cell * 0.8                       # ~80 pairs per centre: two chunks of 42
+    cluster = SimpleAtoms(rng.choice([8, 12, 46], 9), rng.normal(0.0, 1.8, (9, 3)), np.eye(3) * 30.0, [False] * 3)
+    lone = SimpleAtoms(np.array([46]), np.zeros((1, 3)), np.eye(3) * 30.0, [False] * 3)
+    axis = SimpleAtoms(np.array([46, 46, 8]), np.array([[0.0, 0, 0], [0, 0, 2.5], [0, 0, -3.0]]), np.eye(3) * 30.0, [False] * 3)
+    batch = neb_images(3, seed=7) + [dense, cluster, lone, axis]
+    for weight_on in (False, True):
+        des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0, weight_on=weight_on)
+        try:
+            _lib.lib().gpr_so3_set_variant(1)
+            want = des.calculate_batch_dev(batch)
+            torch.cuda.synchronize()
+            want = {k: want[k].clone() for k in ("x", "dxdr")}
+            _lib.lib().gpr_so3_set_variant(0)
+            got = des.calculate_batch_dev(batch)
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib().gpr_so3_set_variant(0)
+        for k in ("x", "dxdr"):
+            assert got[k].shape == want[k].shape
+            err = float((got[k] - want[k]).abs().max() / want[k].abs().max())
+            assert err < 1e-13, (k, weight_on, err)

@@ -1,8 +1,10 @@
 #!/bin/bash
 # VALU / LDS / SALU instruction counts of the descriptor kernel per phase: the kernel ends early with GPR_SO3_DBG = 1..4
 # (tables | + c_tot, x, T | + R/S/dP | + row accumulation | 0 = whole kernel); usage (GPU box): bash tools/pmc_so3_phases.sh
+# needs the tools build of the library (make -C gpr_calculator_amd/csrc ablation): the production library has no early exits
 set -e
 export TMPDIR=/tmp
+export GPR_HIP_LIB=$PWD/gpr_calculator_amd/libgprhip_ablation.so
 OUT=$PWD/gpurun_out/pmc_so3ph
 REPO=$PWD
 for d in 1 2 3 4 0; do
@@ -13,12 +15,14 @@ for d in 1 2 3 4 0; do
   python3 - $OUT/$d $d <<'PY'
 import csv, sys, glob, collections
 f = glob.glob(f"{sys.argv[1]}/**/*counter_collection.csv", recursive=True)[0]
-agg, cnt = collections.defaultdict(float), collections.Counter()
-for r in csv.DictReader(open(f)):
-    if "so3_centre" not in r["Kernel_Name"]: continue
-    agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
-w = agg["SQ_WAVES"] / max(cnt["SQ_WAVES"], 1)
-print(f"dbg={sys.argv[2]}: " + "  ".join(f"{k[3:]}={agg[k]/cnt[k]/max(w,1):.0f}/wave" for k in sorted(agg) if k != "SQ_WAVES") + f"  waves={w:.0f}")
+for kern in ("so3_fixed", "so3_centre"):
+    agg, cnt = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(f)):
+        if kern not in r["Kernel_Name"] or int(r["Grid_Size"]) < 100000: continue        # the batch launches only
+        agg[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
+    if not cnt: continue
+    w = agg["SQ_WAVES"] / max(cnt["SQ_WAVES"], 1)
+    print(f"dbg={sys.argv[2]} {kern:10s}: " + "  ".join(f"{k[3:]}={agg[k]/cnt[k]/max(w,1):.0f}/wave" for k in sorted(agg) if k != "SQ_WAVES") + f"  waves={w:.0f}")
 PY
 done
 rm -rf $OUT

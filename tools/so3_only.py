@@ -5,10 +5,21 @@ from gpr_calculator_amd.SO3 import SO3
 from gpr_calculator_amd.synthetic import neb_images
 from gpr_calculator_amd import device as dev
 des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
-batch = neb_images(64, seed=100)
-des.calculate_batch_dev(batch); torch.cuda.synchronize()
-dev.profile_enable(True)
-for _ in range(5): des.calculate_batch_dev(batch)
-torch.cuda.synchronize()
-ms, n = dev.profile_fetch()["so3"]
-print(f"so3 {os.environ.get('GPR_SO3_DBG','0')}: {ms/n:.3f} ms")
+NB = int(os.environ.get('SO3_NB', '64'))
+batch = neb_images(NB, seed=100)
+from gpr_calculator_amd import _lib
+for variant in (0, 1):                              # 0: compile-time instance where there is one; 1: the generic kernel
+    _lib.lib().gpr_so3_set_variant(variant)
+    out = des.calculate_batch_dev(batch); torch.cuda.synchronize()
+    dev.profile_enable(True)
+    for _ in range(20): des.calculate_batch_dev(batch)
+    torch.cuda.synchronize()
+    ms, n = dev.profile_fetch()["so3"]
+    dev.profile_enable(False)
+    print(f"so3 variant {variant} (phase {os.environ.get('GPR_SO3_DBG','0')}): {ms/n:.4f} ms per launch over {n} launches, "
+          f"{out['x'].shape[0]} centres, {out['dxdr'].shape[0]} seq rows")
+    if variant == 0: ref = out
+    else:
+        for k in ("x", "dxdr"):
+            print(f"   fixed vs generic, {k}: max |diff| / max |value| = {float((ref[k] - out[k]).abs().max() / out[k].abs().max()):.2e}")
+_lib.lib().gpr_so3_set_variant(0)
