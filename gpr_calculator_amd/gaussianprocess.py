@@ -801,6 +801,13 @@ class GP():
 
         E_Pred, E_std, F_Pred, F_std = None, None, None, None
         nE, nF = n_points(test_X_E['energy']), n_points(test_X_F['force'])
+        if test_data is None and not return_std and not total_E:
+            quick = self._train_predictions()
+            if quick is not None:                # the training set itself, right after a fit: K alpha = y - D alpha
+                E_Pred, F_Pred = quick[:nE] if nE > 0 else None, quick[nE:] if nF > 0 else None
+                if show:
+                    self.update_error(E, E_Pred, F, F_Pred)
+                return E, E_Pred, F, F_Pred
         if return_std:
             if nE > 0:
                 E_Pred, E_std = self.predict(test_X_E, total_E=total_E, return_std=True)
@@ -816,6 +823,29 @@ class GP():
         if show:
             self.update_error(E, E_Pred, F, F_Pred)
         return E, E_Pred, F, F_Pred
+
+    def _train_predictions(self):
+        """The model's mean at its own training points without building K(train, train) again: (K + D) alpha = y, so
+        K alpha = y - D alpha with D = diag(noise_e^2 | noise_f^2) -- what `predict` would return for the training set
+        (gaussianprocess.py:319-379 evaluated at X = train_x), up to the residual of the solve (~1e-12 of |y|).  The
+        calculator validates on the training set after every refit (calculator.py:109): at a few thousand rows that was one
+        more covariance assembly per refit.  None when the shortcut does not apply: points queued since the fit, a factor that
+        has not been formed (weight-space fit: its own cheap route), hyper-parameters changed since the fit."""
+        d = self._dense
+        if not self._fitted or self.N_queue != 0 or self._dense_pending or d["alpha"] is None:
+            return None
+        now = (tuple(float(v) for v in self.kernel.parameters()), float(self.noise_e), float(self.noise_f))
+        if self._dense_params != now or self._fit_y is not self.y_train:
+            return None
+        alpha = self.alpha_.reshape(-1)
+        y = np.asarray(self.y_train, dtype=np.float64).reshape(-1)
+        if alpha.shape != y.shape:
+            return None
+        NE = self._n_energy_points(self.train_x)
+        out = y.copy()
+        out[:NE] -= self.noise_e ** 2 * alpha[:NE]
+        out[NE:] -= self.noise_f ** 2 * alpha[NE:]
+        return out
 
     def update_error(self, E, E_Pred, F, F_Pred):
         e_r2, e_mae, e_rmse = metric_values(E, E_Pred)
@@ -1480,6 +1510,41 @@ class GP():
                 break
         return taken
 
+    # A fitted model judges the structure in ONE device pass (device_judge): neighbour search, descriptor, every atom as a force
+    # point, means and standard deviations -- and only the force points that are picked (at most N_max of, e.g., 220) are brought
+    # to the host in the reference's tuple layout.  The route through convert_train_data / validate_data builds all of them on
+    # the host first (gaussianprocess.py:950-954); it stays for unfitted models, several ranks and foreign descriptors, and
+    # tests/test_gpu_edge.py holds the two to each other.
+    device_judge = True
+
+    def _judge_on_device(self, atoms, energy, force):
+        """((E, E_pred, E_std, F, F_pred, F_std), energy tuple, force_point(a) -> tuple) or None when this route does not apply"""
+        des = self.descriptor
+        if (not self.device_judge or not self._fitted or self.comm.size != 1 or not hasattr(des, "calculate_batch_dev")
+                or not getattr(des, "derivative", True) or getattr(des, "_stress", False)):
+            return None
+        from .neighbors import SimpleAtoms, atoms_arrays
+        numbers, pos, cell, pbc = atoms_arrays(atoms)
+        n = len(numbers)
+        bare = SimpleAtoms(numbers, pos, cell, pbc)               # no constraints: every atom is a candidate (utilities.py:97-129)
+        X, _ = self._batch_data_dev([bare])
+        mean, var, _ = self._predict_dev(X, self.get_train_x(), 1e-10, True, want_flat=True)
+        Fp = X["force"]
+        Fp._nbr.check()
+        mean_h, std_h = mean.cpu().numpy(), np.sqrt(var.cpu().numpy())
+        x_host = X["energy"].x.cpu().numpy()
+        ele = np.asarray(numbers, dtype=np.int64)
+        xi, ri = Fp.x_index.cpu().numpy().astype(np.int64), Fp.dxdr_index
+        row0 = np.concatenate(([0], np.cumsum(np.asarray(Fp.counts, dtype=np.int64))))
+        force = np.asarray(force, dtype=np.float64)
+
+        def force_point(a):
+            sl = slice(int(row0[a]), int(row0[a + 1]))
+            rows_x = xi[sl]
+            return (x_host[rows_x], Fp.dxdr.index_select(0, ri[sl].long()).cpu().numpy(), force[a], ele[rows_x])
+        judged = ([energy / n], [float(mean_h[0])], float(std_h[0]), force.flatten(), mean_h[1:], std_h[1:].reshape(n, 3))
+        return judged, (x_host, energy / n, ele), force_point
+
     def add_structure(self, data, N_max=20, tol_e_var=1.2, tol_f_var=1.2, add_force=True):
         """Queue training points from a labelled structure `(atoms, energy, forces)`; returns (points, how many,
         (E, E_pred, E_std, F, F_pred, F_std)) with the base potential's share added back to the energies and forces."""
@@ -1487,13 +1552,19 @@ class GP():
         natoms = len(atoms)
         tol_e, tol_f = tol_e_var * self.noise_e, tol_f_var * self.noise_f
         energy, force, e_off, f_off = self._labels_without_base(atoms, energy, force)
-        my_data = convert_train_data([(atoms, energy, force)], self.descriptor)
-        E, E_pred, E_std, F, F_pred, F_std = self._judge_structure(my_data, natoms, energy, force, tol_e, tol_f)
+        on_device = self._judge_on_device(atoms, energy, force)
+        if on_device is not None:
+            (E, E_pred, E_std, F, F_pred, F_std), energy_point, force_point = on_device
+            energy_points = [energy_point]
+        else:
+            my_data = convert_train_data([(atoms, energy, force)], self.descriptor)
+            E, E_pred, E_std, F, F_pred, F_std = self._judge_structure(my_data, natoms, energy, force, tol_e, tol_f)
+            energy_points, force_point = my_data["energy"], (lambda a: my_data["force"][a])
         F, F_pred = np.asarray(F, dtype=np.float64).reshape(-1), np.asarray(F_pred, dtype=np.float64).reshape(-1)
 
-        x_rows, _, ele_rows = my_data["energy"][0]
+        x_rows, _, ele_rows = energy_points[0]
         atoms_in = self._pick_force_points(x_rows, ele_rows, F, F_pred, F_std, tol_f, N_max) if add_force else []
-        points = {"energy": my_data["energy"], "force": [my_data["force"][a] for a in atoms_in],
+        points = {"energy": energy_points, "force": [force_point(a) for a in atoms_in],
                   "db": [(atoms, energy, force, True, atoms_in)]}
         self.set_train_pts(points, mode="a+")
         back = np.asarray(f_off).reshape(-1)

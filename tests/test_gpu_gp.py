@@ -278,3 +278,75 @@ def test_dot_weight_space_lml_matches_dense_route_and_oracle(port_natives):
     gp.weight_space_fit = True
     gp.fit(show=False, opt=True, maxiter=3)                  # L-BFGS-B on the weight-space objective
     assert gp._fitted and gp._dense_pending
+
+
+def test_validation_on_the_training_set_needs_no_second_covariance_assembly():
+    """validate_data() with no arguments right after a fit -- what the calculator does after every refit -- takes
+    K alpha = y - D alpha instead of predicting at the training points.  Same numbers as the predicting route (forced by
+    making the shortcut's precondition fail), after a plain fit, an optimised one and an appended one; with points in the
+    queue the shortcut must step aside."""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    strucs = training_structures(5, species=(46, 78))
+    gp = GP(kernel=RBF_mb(para=[1.5, 0.8], zeta=2.0), descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002,
+            noise_f=0.1, log_file="/tmp/gpr_test.log")
+    for st in strucs[:3]:
+        gp.add_structure(st)
+
+    def both():
+        assert gp._train_predictions() is not None
+        quick = gp.validate_data(show=True)
+        err_quick = dict(gp.error)
+        saved, gp._dense_params = gp._dense_params, None          # precondition fails -> the predicting route
+        assert gp._train_predictions() is None
+        full = gp.validate_data(show=True)
+        gp._dense_params = saved
+        for a, b in zip(quick, full):
+            assert np.abs(np.asarray(a) - np.asarray(b)).max() < 1e-9 * max(1.0, np.abs(np.asarray(b)).max())
+        for k in err_quick:
+            assert abs(err_quick[k] - gp.error[k]) < 1e-8
+    gp.fit(show=False, opt=False)
+    both()
+    gp.fit(show=False, opt=True, maxiter=3)
+    both()
+    gp.add_structure(strucs[3])
+    assert gp.N_queue > 0 and gp._train_predictions() is None    # queued points: the factor does not cover the training set
+    gp.fit(show=False, opt=False)                                 # (appended to the factor, rows permuted behind the scenes)
+    both()
+
+
+@pytest.mark.parametrize("kind", ["RBF", "Dot"])
+def test_add_structure_judged_on_the_device_queues_what_the_host_route_queues(kind):
+    """A fitted model judges a labelled structure in one device pass and brings only the picked force points to the host
+    (GP._judge_on_device); the route through convert_train_data / validate_data builds every atom's force point on the host
+    first.  Same picked atoms, same queued arrays, same error report -- with fixed atoms present (both routes ignore them,
+    utilities.py:97-129) and two species."""
+    from gpr_calculator_amd.gaussianprocess import GP
+    from gpr_calculator_amd.SO3 import SO3
+    from gpr_calculator_amd.kernels.Dot_mb import Dot_mb
+    from gpr_calculator_amd.kernels.RBF_mb import RBF_mb
+    strucs = training_structures(6, species=(46, 78))
+    strucs[4][0].fixed = np.array([0, 2])
+    out = {}
+    for route in (True, False):
+        kern = RBF_mb(para=[1.5, 0.8], zeta=2.0) if kind == "RBF" else Dot_mb(para=[2.0, 2.0], zeta=2.0)
+        gp = GP(kernel=kern, descriptor=SO3(nmax=3, lmax=4, rcut=5.0), noise_e=0.002, noise_f=0.05, log_file="/tmp/gpr_test.log")
+        gp.device_judge = route
+        for st in strucs[:3]:
+            gp.add_structure((st[0], st[1], st[2].copy()))
+        gp.fit(show=False, opt=False)
+        res = [gp.add_structure((st[0], st[1], st[2].copy()), N_max=3 + k) for k, st in enumerate(strucs[3:])]
+        out[route] = (gp, res)
+    (ga, ra), (gb, rb) = out[True], out[False]
+    for (pa, na, ea), (pb, nb, eb) in zip(ra, rb):
+        assert na == nb and pa["db"][0][4] == pb["db"][0][4] and len(pa["db"][0][4]) >= 1          # the same atoms picked
+        for a, b in zip(ea, eb):
+            assert np.abs(np.asarray(a) - np.asarray(b)).max() < 1e-9
+        for fa, fb in zip(pa["force"], pb["force"]):
+            for u, v in zip(fa, fb):
+                assert np.asarray(u).shape == np.asarray(v).shape and np.abs(np.asarray(u) - np.asarray(v)).max() < 1e-12
+    for key in ("energy", "force"):
+        for u, v in zip(ga.train_x[key], gb.train_x[key]):
+            assert np.abs(np.asarray(u, dtype=np.float64) - np.asarray(v, dtype=np.float64)).max() < 1e-12
+    assert np.abs(ga.y_train - gb.y_train).max() == 0.0 and ga.N_queue == gb.N_queue > 0
