@@ -72,6 +72,7 @@ struct gpr_set {
     int *rowpt = nullptr;           // resident only [rpad] packed point of every padded row (-1: padding)
     int nwu = 0;
     int nchunks = 0, maxgroups = 0;
+    int max_unit_pts = 0;           // resident only: points in the largest wave unit (kblock's split mode takes up to 8)
     // host mirrors used for launch planning
     std::vector<int> h_perm, h_cnt, h_pt_chunk0, h_pt_tiles;
     // host sources of the asynchronous uploads: kept alive with the set so that no stream

@@ -19,9 +19,17 @@
 // in registers and, at the last tile of point i, reduces over its 64 lanes and adds the 3x3
 // (3, 1) result to the output with no-return FP64 atomic adds (exactly one wavefront ever touches a
 // bin and adds to it in program order, so the summation order is deterministic).
+//
+// Small launches (a handful of long points: one 220-atom structure against a training set of a few dozen points -- the
+// on-the-fly loop) leave the chip empty in that decomposition: a wavefront walks the up to fourteen groups of its unit one
+// after the other and the launch is as long as that walk (170 us for a few thousand tiles).  In SPLIT mode a block takes ONE
+// unit and deals its groups to its wavefronts (wavefront w: groups w, w + NW, ...); all of them stream the same staged
+// tiles, and at the end of a stream point their per-point totals meet in LDS and wavefront 0 adds them up in wavefront
+// order and issues the adds -- still one writer per bin per pass, still a fixed summation order.
 #include "gpr_internal.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int KB_SPLIT_PTS = 8;          // points a unit may hold in split mode (the LDS exchange is sized for it)
 
 struct kb_args {
     const double *a_ops; const int *a_ele; const double *a_norm; const gpr_chunk *a_chunks;
@@ -35,6 +43,7 @@ struct kb_args {
     int njb, nir;
     int shard_mod, shard_rem;
     int symmetric, diag_only, eps_mode, norm1, norm2;
+    int split;              // small launches: one wave unit per block, its groups dealt to the block's wavefronts (see below)
     double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
     double scale, dl_scale;
     double *out; long long s_i, s_j, s_a, s_b;
@@ -64,7 +73,7 @@ __device__ __forceinline__ void pair_scalars(double c, const kb_args &P, double 
 
 // KS: k-steps per operand plane, 8 (d <= 32) or 16 (d <= 64; four stream tiles per staged chunk instead of eight)
 template <int MODE, int KIND, bool Z2, bool GRAD, int NW, int KS>
-__global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) kblock_kernel(kb_args P) {   // two wavefronts per SIMD: <= 256 registers
     constexpr int PLANE = KS * GPR_WAVE, CTILES = GPR_CHUNK_TILES * GPR_KSTEPS / KS;
     constexpr int NCB = (MODE == GPR_MODE_EE) ? 1 : 4;            // resident planes per group
     constexpr int NOUT = (MODE == GPR_MODE_FF) ? 9 : (MODE == GPR_MODE_EF ? 3 : 1);
@@ -83,9 +92,13 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
     // resident wave unit of this wavefront (consecutive packed points).  Diagonal launches are tiny, so there every
     // block takes ONE unit and its wavefronts share the unit's points (wave w flushes points w, w + NW, ...: the MFMA
     // passes are repeated per wave, but four times as many blocks exist and each bin still has a single writer)
-    const int ju = P.diag_only ? jb : jb * NW + wave;
+    const bool one_unit = P.diag_only || P.split;
+    const int ju = one_unit ? jb : jb * NW + wave;
     const bool active = ju < P.b_nwu;
-    const int u_first = P.diag_only ? jb : jb * NW, u_end = P.diag_only ? jb + 1 : min((jb + 1) * NW, P.b_nwu);
+    const int u_first = one_unit ? jb : jb * NW, u_end = one_unit ? jb + 1 : min((jb + 1) * NW, P.b_nwu);
+    // split mode: per-point totals of every wavefront, [NW][KB_SPLIT_PTS][value | derivative]
+    constexpr int RW = (GRAD ? 2 : 1) * NOUT;
+    __shared__ double sRed[NW * KB_SPLIT_PTS * RW];
     const int blk_pt0 = P.b_wu_pt0[u_first], blk_pt1 = P.b_wu_pt0[u_end];                           // points of this block
     const int jlast = blk_pt1 - 1;
     if ((jb + ir) % P.shard_mod != P.shard_rem) return;   // multi-GPU: this task belongs to another rank
@@ -105,11 +118,20 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
     __shared__ int sMaxg;                              // the wavefronts of a block walk their groups in lock step
     if (tid == 0) sMaxg = 0;
     __syncthreads();
-    if (lane == 0 && active) atomicMax(&sMaxg, pj.ngroups);
+    if (lane == 0 && active) atomicMax(&sMaxg, P.split ? (pj.ngroups + NW - 1) / NW : pj.ngroups);
     __syncthreads();
     const int maxg = sMaxg;
+    // lane roles of the segmented reductions below (fixed for the kernel): after a reduction lane l holds the total of value
+    // `ridx`; the first NH values sit in the lanes with l % SHARE == 0, the ninth (if any) in lane 1
+    constexpr int NH = (NOUT >= 8) ? 8 : (NOUT >= 2 ? 2 : 1);
+    constexpr int SHARE = 64 / NH;
+    const bool w_main = (lane & (SHARE - 1)) == 0;
+    const bool w_extra = (NOUT > NH) && lane == 1;
+    const int ridx = w_extra ? NH : ((NH == 8) ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)
+                                               : (NH == 2 ? (lane >> 5) & 1 : 0));
 
-    for (int g = 0; g < maxg; ++g) {
+    for (int gp = 0; gp < maxg; ++gp) {
+        const int g = P.split ? gp * NW + wave : gp;
         const bool has = active && g < pj.ngroups;
         double Breg[NCB][KS];
         int eleB = GPR_ELE_PAD_RESIDENT;
@@ -265,76 +287,107 @@ __global__ void __launch_bounds__(NW * 64) kblock_kernel(kb_args P) {
                         }
                     }
                 }
-                if (ch.last) {
-                    const int i_orig = P.a_perm[ch.pt];
-                    const double fac_i = P.norm1 ? P.a_inv[ch.pt] : 1.0;
-                    // one reduction and one set of adds per resident point present in the group
-                    for (int sp = pt_lo; sp <= pt_hi; ++sp) {
-                        if (P.symmetric && ch.pt > sp) continue;          // this point's pair lies below the diagonal
-                        if (P.diag_only && (ch.pt != sp || ((sp - blk_pt0) & (NW - 1)) != wave)) continue;
-                        const bool inseg = (my_pt == sp);
-                        const int j_orig = P.b_perm[sp];
-                        const double fac = fac_i * (P.norm2 ? P.b_inv[sp] : 1.0);
-                        // halving reduction on a masked copy of the bins (lanes of other points contribute zeros): the first
-                        // NH (power of two) values are reduced in log2(NH) exchange steps that each keep half of them, then
-                        // plain xor steps; the value(s) beyond NH take the plain 6-step butterfly.  Afterwards lane l holds
-                        // the total of value `idx` (bits of l above log2(64/NH)), and every lane the totals of the values
-                        // >= NH.  Value and derivative bins go through it one after the other (register pressure).
-                        constexpr int NH = (NOUT >= 8) ? 8 : (NOUT >= 2 ? 2 : 1);
-                        constexpr int SHARE = 64 / NH;
-                        int idx = (NH == 8) ? ((lane >> 5) & 1) * 4 + ((lane >> 4) & 1) * 2 + ((lane >> 3) & 1)
-                                            : (NH == 2 ? (lane >> 5) & 1 : 0);
-                        // writer lanes: (l % SHARE == 0) owns value idx < NH; lane 1 owns the extra value NH (if any)
-                        const bool w_main = (lane & (SHARE - 1)) == 0;
-                        const bool w_extra = (NOUT > NH) && lane == 1;
-                        if (w_extra) idx = NH;
+            }
+            if (ch.last) {
+                const int i_orig = P.a_perm[ch.pt];
+                const double fac_i = P.norm1 ? P.a_inv[ch.pt] : 1.0;
+                // halving reduction on a masked copy of the bins (lanes of other points contribute zeros): the first
+                // NH (power of two) values are reduced in log2(NH) exchange steps that each keep half of them, then
+                // plain xor steps; the value(s) beyond NH take the plain 6-step butterfly.  Afterwards lane l holds
+                // the total of value `ridx`, and every lane the totals of the values >= NH.  Value and derivative bins go
+                // through it one after the other (register pressure).
 #define GPR_HALVE(ARR, OFF, HALF)                                                                 \
-                        {   const bool up_ = (lane & (OFF)) != 0;                                  \
-                            _Pragma("unroll") for (int k_ = 0; k_ < (HALF); k_++) {                \
-                                const double send_ = up_ ? ARR[k_] : ARR[k_ + (HALF)];             \
-                                const double keep_ = up_ ? ARR[k_ + (HALF)] : ARR[k_];             \
-                                ARR[k_] = keep_ + __shfl_xor(send_, (OFF), 64); } }
+                {   const bool up_ = (lane & (OFF)) != 0;                                          \
+                    _Pragma("unroll") for (int k_ = 0; k_ < (HALF); k_++) {                        \
+                        const double send_ = up_ ? ARR[k_] : ARR[k_ + (HALF)];                     \
+                        const double keep_ = up_ ? ARR[k_ + (HALF)] : ARR[k_];                     \
+                        ARR[k_] = keep_ + __shfl_xor(send_, (OFF), 64); } }
 #define GPR_PLAIN(X, FROM)                                                                        \
-                        { _Pragma("unroll") for (int o_ = (FROM); o_ > 0; o_ >>= 1) X += __shfl_xor(X, o_, 64); }
+                { _Pragma("unroll") for (int o_ = (FROM); o_ > 0; o_ >>= 1) X += __shfl_xor(X, o_, 64); }
 #define GPR_SEG_REDUCE(SRC, VAL)                                                                  \
-                        {   double tb_[NOUT];                                                      \
-                            _Pragma("unroll") for (int k_ = 0; k_ < NOUT; k_++) tb_[k_] = inseg ? SRC[k_] : 0.0;  \
-                            if (NH == 8) { GPR_HALVE(tb_, 32, 4) GPR_HALVE(tb_, 16, 2) GPR_HALVE(tb_, 8, 1) GPR_PLAIN(tb_[0], 4) } \
-                            else if (NH == 2) { GPR_HALVE(tb_, 32, 1) GPR_PLAIN(tb_[0], 16) }      \
-                            else { GPR_PLAIN(tb_[0], 32) }                                         \
-                            _Pragma("unroll") for (int k_ = NH; k_ < NOUT; k_++) GPR_PLAIN(tb_[k_], 32)           \
-                            VAL = w_extra ? tb_[NOUT - 1] : tb_[0]; }
-                        double v, v2 = 0.0;
-                        GPR_SEG_REDUCE(bin, v)
-                        if (GRAD) GPR_SEG_REDUCE(bin2, v2)
+                {   double tb_[NOUT];                                                              \
+                    _Pragma("unroll") for (int k_ = 0; k_ < NOUT; k_++) tb_[k_] = inseg ? SRC[k_] : 0.0;  \
+                    if (NH == 8) { GPR_HALVE(tb_, 32, 4) GPR_HALVE(tb_, 16, 2) GPR_HALVE(tb_, 8, 1) GPR_PLAIN(tb_[0], 4) } \
+                    else if (NH == 2) { GPR_HALVE(tb_, 32, 1) GPR_PLAIN(tb_[0], 16) }              \
+                    else { GPR_PLAIN(tb_[0], 32) }                                                 \
+                    _Pragma("unroll") for (int k_ = NH; k_ < NOUT; k_++) GPR_PLAIN(tb_[k_], 32)           \
+                    VAL = w_extra ? tb_[NOUT - 1] : tb_[0]; }
+                // one lane per value adds it to the output.  The hardware FP64 atomic add returns nothing, so
+                // the wavefront does not wait for memory; exactly one wavefront ever adds to a given element
+                // and its adds are issued in program order, so the result does not depend on scheduling.
+                auto emit = [&](int sp, double v, double v2) {
+                    if (!((w_main || w_extra) && ridx < NOUT)) return;
+                    const int j_orig = P.b_perm[sp];
+                    const double fac = fac_i * (P.norm2 ? P.b_inv[sp] : 1.0);
+                    const int a = (MODE == GPR_MODE_FF) ? ridx / 3 : 0;
+                    const int b = (MODE == GPR_MODE_FF) ? ridx % 3 : ridx;
+                    const double val = v * fac * P.scale;
+                    if (P.diag_only) {
+                        if (a == b) unsafeAtomicAdd(P.out + (long long)j_orig * P.s_j + b * P.s_b, val);
+                    } else {
+                        unsafeAtomicAdd(P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b, val);
+                        if (P.symmetric && ch.pt != sp)
+                            unsafeAtomicAdd(P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b, val);
+                        if (GRAD) {
+                            const double vald = v2 * fac * P.dl_scale;
+                            unsafeAtomicAdd(P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b, vald);
+                            if (P.symmetric && ch.pt != sp)
+                                unsafeAtomicAdd(P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b, vald);
+                        }
+                    }
+                };
+                if (!P.split) {
+                    if (mine)
+                        // one reduction and one set of adds per resident point present in the group
+                        for (int sp = pt_lo; sp <= pt_hi; ++sp) {
+                            if (P.symmetric && ch.pt > sp) continue;          // this point's pair lies below the diagonal
+                            if (P.diag_only && (ch.pt != sp || ((sp - blk_pt0) & (NW - 1)) != wave)) continue;
+                            const bool inseg = (my_pt == sp);
+                            double v, v2 = 0.0;
+                            GPR_SEG_REDUCE(bin, v)
+                            if (GRAD) GPR_SEG_REDUCE(bin2, v2)
+                            emit(sp, v, v2);
+                        }
+                } else {
+                    // split mode: every wavefront leaves the totals of its own group for the points of the unit in LDS, then
+                    // wavefront 0 adds them in wavefront order and issues the adds (the loops are uniform over the block)
+                    for (int sp = blk_pt0; sp <= jlast; ++sp) {
+                        if (P.symmetric && ch.pt > sp) continue;
+                        const bool here = mine && sp >= pt_lo && sp <= pt_hi;
+                        double v = 0.0, v2 = 0.0;
+                        if (here) {
+                            const bool inseg = (my_pt == sp);
+                            GPR_SEG_REDUCE(bin, v)
+                            if (GRAD) GPR_SEG_REDUCE(bin2, v2)
+                        }
+                        if ((w_main || w_extra) && ridx < NOUT) {
+                            double *r_ = sRed + (wave * KB_SPLIT_PTS + (sp - blk_pt0)) * RW;
+                            r_[ridx] = v;
+                            if (GRAD) r_[NOUT + ridx] = v2;
+                        }
+                    }
+                    __syncthreads();
+                    if (wave == 0)
+                        for (int sp = blk_pt0; sp <= jlast; ++sp) {
+                            if (P.symmetric && ch.pt > sp) continue;
+                            double v = 0.0, v2 = 0.0;
+                            if ((w_main || w_extra) && ridx < NOUT) {
+#pragma unroll
+                                for (int w_ = 0; w_ < NW; w_++) {
+                                    const double *r_ = sRed + (w_ * KB_SPLIT_PTS + (sp - blk_pt0)) * RW;
+                                    v += r_[ridx];
+                                    if (GRAD) v2 += r_[NOUT + ridx];
+                                }
+                            }
+                            emit(sp, v, v2);
+                        }
+                    __syncthreads();
+                }
 #undef GPR_SEG_REDUCE
 #undef GPR_HALVE
 #undef GPR_PLAIN
-                        // one lane per value adds it to the output.  The hardware FP64 atomic add returns nothing, so
-                        // the wavefront does not wait for memory; exactly one wavefront ever adds to a given element
-                        // and its adds are issued in program order, so the result does not depend on scheduling.
-                        if ((w_main || w_extra) && idx < NOUT) {
-                            const int a = (MODE == GPR_MODE_FF) ? idx / 3 : 0;
-                            const int b = (MODE == GPR_MODE_FF) ? idx % 3 : idx;
-                            const double val = v * fac * P.scale;
-                            if (P.diag_only) {
-                                if (a == b) unsafeAtomicAdd(P.out + (long long)j_orig * P.s_j + b * P.s_b, val);
-                            } else {
-                                unsafeAtomicAdd(P.out + i_orig * P.s_i + j_orig * P.s_j + a * P.s_a + b * P.s_b, val);
-                                if (P.symmetric && ch.pt != sp)
-                                    unsafeAtomicAdd(P.out + j_orig * P.s_i + i_orig * P.s_j + b * P.s_a + a * P.s_b, val);
-                                if (GRAD) {
-                                    const double vald = v2 * fac * P.dl_scale;
-                                    unsafeAtomicAdd(P.dl + i_orig * P.d_i + j_orig * P.d_j + a * P.d_a + b * P.d_b, vald);
-                                    if (P.symmetric && ch.pt != sp)
-                                        unsafeAtomicAdd(P.dl + j_orig * P.d_i + i_orig * P.d_j + b * P.d_a + a * P.d_b, vald);
-                                }
-                            }
-                        }
-                    }
 #pragma unroll
-                    for (int k = 0; k < NOUT; k++) { bin[k] = 0.0; if (GRAD) bin2[k] = 0.0; }
-                }
+                for (int k = 0; k < NOUT; k++) { bin[k] = 0.0; if (GRAD) bin2[k] = 0.0; }
             }
             if (c + 1 < c1) GPR_STAGE_STORE(c + 1, buf ^ 1)
             __syncthreads();
@@ -388,10 +441,18 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     GPR_REQUIRE(s1->ks == s2->ks, "block: sets packed with different plane widths");
     int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
     if (c.diag_only || s1->ks == GPR_KSTEPS_MAX) nw = 4;
-    const int njb = c.diag_only ? s2->nwu : (s2->nwu + nw - 1) / nw;
+    // stream ranges (consecutive packed points, ~128 tiles each; finer for small sets) were laid out at pack time
+    const int nranges = c.diag_only ? 1 : s1->nranges;
+    // Split mode (see the top of the file): when the usual decomposition would not even give every CU a block and the units
+    // have several groups, a block takes one unit and its wavefronts share the unit's groups.
+    static const int split_env = getenv("GPR_KBLOCK_SPLIT") ? atoi(getenv("GPR_KBLOCK_SPLIT")) : -1;     // 0 / 1 force it (A/B, tests)
+    bool split = !c.diag_only && s2->maxgroups >= 2 && s2->max_unit_pts <= KB_SPLIT_PTS &&
+                 (long long)((s2->nwu + nw - 1) / nw) * nranges < gpr_cu_count();
+    if (split_env == 0) split = false;
+    if (split_env == 1) split = !c.diag_only && s2->max_unit_pts <= KB_SPLIT_PTS;
+    const int njb = (c.diag_only || split) ? s2->nwu : (s2->nwu + nw - 1) / nw;
 
-    // stream ranges (consecutive packed points, ~128 tiles each) were laid out at pack time
-    const int nir = c.diag_only ? 1 : s1->nranges;
+    const int nir = nranges;
 
     kb_args a;
     a.a_ops = s1->ops; a.a_ele = s1->ele; a.a_norm = s1->norms; a.a_chunks = s1->chunks;
@@ -403,7 +464,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     a.ir_chunk0 = s1->ir_chunk0; a.ir_pt0 = s1->ir_pt0;
     a.njb = njb; a.nir = nir;
     a.shard_mod = g_shard_mod; a.shard_rem = g_shard_rem;
-    a.symmetric = c.symmetric; a.diag_only = c.diag_only; a.eps_mode = c.eps_mode;
+    a.symmetric = c.symmetric; a.diag_only = c.diag_only; a.eps_mode = c.eps_mode; a.split = split ? 1 : 0;
     a.norm1 = c.norm1; a.norm2 = c.norm2;
     a.zeta = c.zeta; a.sigma2 = c.sigma2; a.sigma02 = c.sigma02; a.tol = c.tol;
     if (c.kind == GPR_KERNEL_RBF) {

@@ -383,6 +383,7 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
             rpts.push_back(gpr_rpoint{unit, groups});
             wu_pt0.push_back(q);
             s->maxgroups = std::max(s->maxgroups, groups);
+            s->max_unit_pts = std::max(s->max_unit_pts, q - p);
             unit += groups;
             p = q;
         }
