@@ -39,7 +39,11 @@ constexpr int GPR_CHUNK_TILES = 8;     // stream tiles staged per LDS buffer (32
 // longer descriptors (32 < d <= 64, e.g. SO3(nmax=4, lmax=4): d = 50): 16 k-steps per plane (8 KiB) and 4 tiles per
 // staged chunk -- the same 32 KiB of LDS per buffer.  A set records which form it was packed in (gpr_set::ks).
 constexpr int GPR_KSTEPS_MAX = 16;
-constexpr int GPR_KPAD_MAX = 4 * GPR_KSTEPS_MAX;
+// still longer ones (64 < d <= 128: SO3(4, 6) has d = 70, SO3(5, 4) 75, SO3(6, 4) 105 -- the reference loops over any d,
+// rbf_kernel.cpp:341-473): 32 k-steps per plane (16 KiB), 2 tiles per staged chunk.  The resident operands of a group are
+// then 256 registers per lane, so these instances run one wavefront per SIMD: correct first, about half the rate.
+constexpr int GPR_KSTEPS_WIDE = 32;
+constexpr int GPR_KPAD_MAX = 4 * GPR_KSTEPS_WIDE;
 constexpr int GPR_GROUP_ROWS = 16;     // rows per resident group (one MFMA N extent)
 constexpr int GPR_WU_MAX_GROUPS = 8;   // resident groups one wavefront owns at most (a wave unit: consecutive points)
 constexpr int GPR_ELE_PAD_STREAM = INT_MIN;        // species code of padded / skipped stream rows
@@ -52,7 +56,7 @@ struct gpr_rpoint { int group0, ngroups; };
 
 struct gpr_set {
     int role, d, width, col0, nc, flags;
-    int ks = GPR_KSTEPS;   // k-steps per operand plane: 8 (d <= 32) or 16 (d <= 64); plane = ks * 64 doubles
+    int ks = GPR_KSTEPS;   // k-steps per operand plane: 8 (d <= 32), 16 (d <= 64) or 32 (d <= 128); plane = ks * 64 doubles
     int npts, nrows, rpad;
     int tile_rows;     // rows per operand plane on this side (stream force: 4, otherwise 16)
     int nunits;        // number of planes-groups: stream tiles or resident groups

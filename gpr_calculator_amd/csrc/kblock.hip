@@ -71,9 +71,10 @@ __device__ __forceinline__ void pair_scalars(double c, const kb_args &P, double 
     } else { Kv = 0.0; g = 1.0; }
 }
 
-// KS: k-steps per operand plane, 8 (d <= 32) or 16 (d <= 64; four stream tiles per staged chunk instead of eight)
+// KS: k-steps per operand plane, 8 (d <= 32), 16 (d <= 64; four stream tiles per staged chunk instead of eight) or 32 (d <= 128; two)
 template <int MODE, int KIND, bool Z2, bool GRAD, int NW, int KS>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2))) kblock_kernel(kb_args P) {   // two wavefronts per SIMD: <= 256 registers
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(KS <= GPR_KSTEPS_MAX ? 2 : 1)))     // two wavefronts per SIMD
+kblock_kernel(kb_args P) {                                                                                // (<= 256 registers) up to d = 64
     constexpr int PLANE = KS * GPR_WAVE, CTILES = GPR_CHUNK_TILES * GPR_KSTEPS / KS;
     constexpr int NCB = (MODE == GPR_MODE_EE) ? 1 : 4;            // resident planes per group
     constexpr int NOUT = (MODE == GPR_MODE_FF) ? 9 : (MODE == GPR_MODE_EF ? 3 : 1);
@@ -398,7 +399,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(2)
 // ---------------------------------------------------------------- host launcher
 template <int MODE, int KIND, bool Z2, bool GRAD>
 static void launch_nw(hipStream_t st, int nw, int ks, int nblocks, const kb_args &a) {
-    if (ks == GPR_KSTEPS_MAX)       // long descriptors: four wavefronts (the resident operands alone are 128 VGPRs per lane)
+    if (ks == GPR_KSTEPS_WIDE)      // d <= 128: the resident operands are 256 registers per lane, one wavefront per SIMD
+        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_WIDE>), dim3(nblocks), dim3(256), 0, st, a);
+    else if (ks == GPR_KSTEPS_MAX)  // long descriptors: four wavefronts (the resident operands alone are 128 VGPRs per lane)
         hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_MAX>), dim3(nblocks), dim3(256), 0, st, a);
     else if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8, GPR_KSTEPS>), dim3(nblocks), dim3(512), 0, st, a);
     else              hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS>), dim3(nblocks), dim3(256), 0, st, a);
@@ -440,7 +443,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     // workgroup width: 8 wavefronts when that still leaves >= 2 blocks per CU, else 4
     GPR_REQUIRE(s1->ks == s2->ks, "block: sets packed with different plane widths");
     int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
-    if (c.diag_only || s1->ks == GPR_KSTEPS_MAX) nw = 4;
+    if (c.diag_only || s1->ks >= GPR_KSTEPS_MAX) nw = 4;
     // stream ranges (consecutive packed points, ~128 tiles each; finer for small sets) were laid out at pack time
     const int nranges = c.diag_only ? 1 : s1->nranges;
     // Split mode (see the top of the file): when the usual decomposition would not even give every CU a block and the units

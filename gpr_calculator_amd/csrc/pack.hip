@@ -315,7 +315,7 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     gpr_set *s = new gpr_set();
     s->role = role; s->d = d; s->width = width; s->col0 = col0; s->flags = flags;
     s->nc = (width == 0) ? 1 : 4;
-    s->ks = (d <= GPR_KPAD) ? GPR_KSTEPS : GPR_KSTEPS_MAX;
+    s->ks = (d <= GPR_KPAD) ? GPR_KSTEPS : (d <= 4 * GPR_KSTEPS_MAX ? GPR_KSTEPS_MAX : GPR_KSTEPS_WIDE);
     const int chunk_tiles = GPR_CHUNK_TILES * GPR_KSTEPS / s->ks;          // same bytes per staged chunk
     const size_t plane = (size_t)s->ks * GPR_WAVE;
     s->npts = npts; s->nrows = nrows;

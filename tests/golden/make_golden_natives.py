@@ -28,6 +28,11 @@ CASES = {
     "d50_mixed":    dict(seed=6, d=50, counts1=[5, 11, 3], counts2=[9, 4, 13, 6], species=(8, 46)),
     "d64_zeta3":    dict(seed=7, d=64, counts1=[7, 6], counts2=[5, 10, 8], species=(13, 79), zeta=3.0, sigma=1.7,
                          l=0.9, sigma0=1.5),
+    # beyond 64 columns (round 4): SO3(nmax=5, lmax=4) has d = 75, SO3(6, 4) 105; 128 is the widest plane now
+    "d75_mixed":    dict(seed=8, d=75, counts1=[6, 9, 4], counts2=[8, 5, 12, 3], species=(8, 12, 46)),
+    "d105_zeta3":   dict(seed=9, d=105, counts1=[5, 7], counts2=[6, 9, 4], species=(8, 46), zeta=3.0, sigma=1.7, l=0.9,
+                         sigma0=1.5),
+    "d128_subrange": dict(seed=10, d=128, counts1=[9, 8], counts2=[7, 11, 6], sigma=1.2, l=0.6, tol=1e-3, n2_range=(4, 20)),
 }
 
 if __name__ == "__main__":

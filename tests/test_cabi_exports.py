@@ -49,7 +49,7 @@ def test_bad_arguments_are_reported_not_executed(built_lib):
     built_lib.gpr_last_error.restype = ctypes.c_char_p
     out = ctypes.c_void_p()
     counts = (ctypes.c_int * 1)(3)
-    rc = built_lib.gpr_set_create(ctypes.byref(out), None, 0, 65, 3, 0, 3, 1, counts, None, None, None, 0)
-    assert rc == -3 and b"unsupported" in built_lib.gpr_last_error()      # d = 65 > 64 (two plane widths: 32 and 64 columns)
+    rc = built_lib.gpr_set_create(ctypes.byref(out), None, 0, 129, 3, 0, 3, 1, counts, None, None, None, 0)
+    assert rc == -3 and b"unsupported" in built_lib.gpr_last_error()      # d = 129 > 128 (three plane widths: 32, 64 and 128 columns)
     rc = built_lib.gpr_set_create(ctypes.byref(out), None, 0, 30, 3, 0, 5, 1, counts, None, None, None, 0)
     assert rc == -2 and b"null device pointer" in built_lib.gpr_last_error()

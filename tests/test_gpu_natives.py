@@ -47,14 +47,14 @@ def test_natives_match_oracle_ragged(seed, species, hip_natives, port_natives):
 
 
 def test_unsupported_descriptor_length_returns_instead_of_aborting():
-    """Descriptors longer than the widest operand plane of this build (d > 64; the reference loops over any d,
+    """Descriptors longer than the widest operand plane of this build (d > 128; the reference loops over any d,
     rbf_kernel.cpp:341-473): the drop-in natives must say so and hand the caller's zeroed buffers back untouched (they
-    are `void`), not kill the host process.  (d <= 64, e.g. SO3(nmax=4, lmax=4) with d = 50, runs: natives_d50_mixed.)"""
+    are `void`), not kill the host process.  (d <= 128 runs: natives_d50_mixed, _d75_mixed, _d105_zeta3, _d128_subrange.)"""
     import ctypes as C
     from gpr_calculator_amd import _lib
     from oracle.natives import SIGS, make_case
     L = C.CDLL(_lib.LIB_PATH)
-    c = make_case(5, 70, [3, 4], [2, 5, 3], species=(8, 46))
+    c = make_case(5, 130, [3, 4], [2, 5, 3], species=(8, 46))
     from oracle.natives import expand_counts
     n1, n2, m1, m2 = len(c["x1"]), len(c["x2"]), 2, 3
     fn = L.rbf_kff_many
@@ -65,7 +65,7 @@ def test_unsupported_descriptor_length_returns_instead_of_aborting():
     x1, x2 = np.ascontiguousarray(c["x1"]), np.ascontiguousarray(c["x2"])
     A, B = np.ascontiguousarray(c["dx1dr"]), np.ascontiguousarray(c["dx2dr"])
     e1, e2, i1, i2 = c["ele1"].astype(np.int32), c["ele2"].astype(np.int32), expand_counts(c["counts1"]), expand_counts(c["counts2"])
-    fn(n1, n2, 0, n2, 70, m2, 2.0, 6.25, 1.69, 1e-12, p(x1, D), p(A, D), p(e1, I), p(i1, I), p(x2, D), p(B, D), p(e2, I), p(i2, I), p(out, D))
+    fn(n1, n2, 0, n2, 130, m2, 2.0, 6.25, 1.69, 1e-12, p(x1, D), p(A, D), p(e1, I), p(i1, I), p(x2, D), p(B, D), p(e2, I), p(i2, I), p(out, D))
     L.gpr_l0_last_status.restype = C.c_int
     assert L.gpr_l0_last_status() == -3 and not out.any()                  # GPR_ERR_UNSUPPORTED, nothing written
     # ... and the library is still usable afterwards
