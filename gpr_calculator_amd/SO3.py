@@ -82,18 +82,19 @@ class SO3:
 
     @staticmethod
     def _check_device_limits(nmax, lmax):
-        """The device kernels cover nmax <= 4 with lmax <= 6, nmax = 5 and 6 with lmax <= 3, and ncoef <= 64 power-spectrum
-        components (the widest MFMA operand plane of the covariance kernels is 64 columns; csrc/so3.hip, csrc/pack.hip):
-        say so when the object is configured, not deep inside a launch (the reference allows nmax <= 11, SO3.py:76-77;
-        with ncoef <= 64 that leaves (5, <= 3) and (6, <= 2) beyond nmax = 4).  Stress rows (stress=True) additionally
-        need nmax <= 4, nmax (lmax + 1) <= 16 and ncoef <= 32, checked at the launch."""
+        """The device kernels cover nmax <= 4 with lmax <= 6, nmax = 5 with lmax <= 4 and nmax = 6 with lmax <= 3 -- up to
+        85 power-spectrum components (one thread per column of a dxdr row in the descriptor kernel; the covariance kernels
+        take up to 128 columns; csrc/so3.hip, csrc/pack.hip): say so when the object is configured, not deep inside a
+        launch (the reference allows nmax <= 11, SO3.py:76-77).  Stress rows (stress=True) additionally need nmax <= 4,
+        nmax (lmax + 1) <= 16 and ncoef <= 32, checked at the launch."""
         if nmax is None or lmax is None:
             return
         ncoef = nmax * (nmax + 1) // 2 * (lmax + 1)
-        if nmax > 6 or lmax > 6 or (nmax > 4 and lmax > 3) or ncoef > 64:
+        if nmax > 6 or lmax > 6 or (nmax == 5 and lmax > 4) or (nmax > 5 and lmax > 3) or ncoef > 85:
             raise NotImplementedError(
                 f"SO3(nmax={nmax}, lmax={lmax}) gives ncoef = {ncoef}; this build's device kernels cover nmax <= 4 with "
-                f"lmax <= 6, nmax <= 6 with lmax <= 3, and ncoef <= 64 (the reference's default is nmax=3, lmax=4: ncoef = 30)")
+                f"lmax <= 6, nmax = 5 with lmax <= 4, nmax = 6 with lmax <= 3 (ncoef <= 85; the reference's default is "
+                f"nmax=3, lmax=4: ncoef = 30)")
 
     # -- validated attributes (gpr_calc/SO3.py:67-182)
     @property

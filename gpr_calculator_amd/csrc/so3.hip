@@ -339,7 +339,8 @@ constexpr int SO3_PC = 44;       // pairs whose tables are resident in LDS at a 
                                  // four workgroups per CU)
 constexpr int SO3_NLP = 16;      // padded number of radial-angular channels nmax (lmax+1) when there are at most 16
 constexpr int SO3_NLP_BIG = 32;  // ... when there are more (nmax <= 4, lmax <= 6: up to 28)
-constexpr int SO3_SELFW = 192;   // stride of the (i, i)-row partial sums: 3 d <= 192
+constexpr int SO3_SELFW = 256;   // stride of the (i, i)-row partial sums: 3 d <= 256 (one thread per column of a dxdr row)
+constexpr int SO3_LDS_DOUBLES = 96 * 1024 / 8;   // dynamic LDS the centre kernels may ask for
 __host__ __device__ inline int so3_nlp(int nmax, int lmax) { return nmax * (lmax + 1) <= SO3_NLP ? SO3_NLP : SO3_NLP_BIG; }
 
 // dynamic LDS layout (doubles).  Per-centre tables: NY | RI | NL constants, c_tot [NLM] cplx, Rf [NL][L] cplx
@@ -373,6 +374,9 @@ __host__ __device__ inline so3_lds so3_layout(int nmax, int lmax, bool stress) {
     o.tri = (LT + 1) * (LT + 2) / 2;
     o.rec = 8 + 2 * so3_nlp(nmax, lmax) + 2 * o.tri;
     o.pc = stress ? SO3_PC : (SO3_PC < 256 / L ? SO3_PC : 256 / L);
+    // long descriptors (round 4: up to 85 components, e.g. SO3(4, 6), SO3(5, 4), SO3(6, 3)): fewer pairs per chunk so that the
+    // staging area of the chunk's rows still fits
+    while (!stress && o.pc > 8 && off + (o.pc + 1) * ne > SO3_LDS_DOUBLES) o.pc--;
     o.oRec = off;
     int area_rec = o.pc * o.rec + o.pc, area_rows = (o.pc + 1) * ne;    // records + pair->row map | row staging
     if (!stress && area_rec < 2 * SO3_SELFW) area_rec = 2 * SO3_SELFW;   // the (i, i)-row partial sums end up here
@@ -1222,10 +1226,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
 
 int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char *who) {
     const int d = nmax * (nmax + 1) / 2 * (lmax + 1), L = lmax + 1;
-    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > SO3_NCAP || (nmax > 4 && lmax > 3) || nq > SO3_NQCAP || nmax * L > so3_nlp(nmax, lmax) ||
-        d * 3 > SO3_SELFW || nmax * L * (L + 1) / 2 > 256 || nseg < 1 || ncheb != SO3_NCHEB) {
+    if (nmax < 1 || lmax < 0 || lmax > SO3_LCAP - 1 || nmax > SO3_NCAP || (nmax == 5 && lmax > 4) || (nmax > 5 && lmax > 3) || nq > SO3_NQCAP ||
+        nmax * L > so3_nlp(nmax, lmax) || d * 3 > SO3_SELFW || nmax * L * (L + 1) / 2 > 256 || nseg < 1 || ncheb != SO3_NCHEB) {
         gpr_set_error("%s: (nmax=%d, lmax=%d, nq=%d, nseg=%d, ncheb=%d) outside this build's limits "
-                      "(nmax <= 4 with lmax <= %d, nmax <= %d with lmax <= 3, nq <= %d, ncoef <= 64, ncheb == %d)",
+                      "(nmax <= 4 with lmax <= %d, nmax = 5 with lmax <= 4, nmax <= %d with lmax <= 3, nq <= %d, ncoef <= 85, ncheb == %d)",
                       who, nmax, lmax, nq, nseg, ncheb, SO3_LCAP - 1, SO3_NCAP, SO3_NQCAP, SO3_NCHEB);
         return GPR_ERR_UNSUPPORTED;
     }
@@ -1348,6 +1352,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<5, 3, true>, 96 * 1024);
         if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<SO3_LCAP, 4, true>, 96 * 1024);
         if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<4, SO3_NCAP, false>, 96 * 1024);
+        if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<5, 5, false>, 96 * 1024);
         if (rc_) return rc_;
     }
     const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
@@ -1363,7 +1368,8 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     } else {
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else if (nmax <= 4) hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
-        else hipLaunchKernelGGL((so3_centre_kernel<4, SO3_NCAP, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);   // nmax 5, 6: lmax <= 3
+        else if (lmax <= 3) hipLaunchKernelGGL((so3_centre_kernel<4, SO3_NCAP, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);   // nmax 5, 6: lmax <= 3
+        else hipLaunchKernelGGL((so3_centre_kernel<5, 5, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);           // nmax = 5, lmax = 4 (d = 75)
     }
     gpr_prof_end(st, pid);
     hipError_t e = hipGetLastError();

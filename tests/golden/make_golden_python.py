@@ -90,6 +90,13 @@ def structures():
                                pbc=[False] * 3, nmax=5, lmax=3, rcut=4.0, alpha=2.0, stress=False)
     out["fcc4_n6l2"] = dict(numbers=[46, 78, 46, 46], positions=fcc + np.random.default_rng(7).normal(0, 0.1, (4, 3)),
                             cell=np.eye(3) * a, pbc=[True] * 3, nmax=6, lmax=2, rcut=5.0, alpha=2.0, stress=False)
+    # beyond 64 components (round 4): SO3(4, 6) -> 70, SO3(5, 4) -> 75, SO3(6, 3) -> 84
+    out["cluster_n4l6"] = dict(numbers=[46, 8, 12, 8, 46, 12], positions=clu, cell=np.zeros((3, 3)),
+                               pbc=[False] * 3, nmax=4, lmax=6, rcut=4.0, alpha=2.0, stress=False)
+    out["fcc4_n5l4"] = dict(numbers=[46, 78, 46, 46], positions=fcc + np.random.default_rng(9).normal(0, 0.1, (4, 3)),
+                            cell=np.eye(3) * a, pbc=[True] * 3, nmax=5, lmax=4, rcut=5.0, alpha=2.0, stress=False)
+    out["cluster_n6l3"] = dict(numbers=[46, 8, 12, 8, 46, 12], positions=clu, cell=np.zeros((3, 3)),
+                               pbc=[False] * 3, nmax=6, lmax=3, rcut=4.0, alpha=2.0, stress=False)
     return out
 
 

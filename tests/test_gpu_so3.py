@@ -184,8 +184,10 @@ def test_so3_other_configurations_match_oracle(cfg):
 
 
 @pytest.mark.parametrize("cfg", [(4, 4, 4.0, 2.0), (3, 6, 4.2, 1.5), (4, 5, 4.0, 2.0), (4, 3, 5.0, 2.0), (5, 3, 4.0, 2.0),
-                                 (6, 2, 5.0, 2.0), (5, 1, 5.0, 1.5), (6, 0, 4.0, 2.0)],
-                         ids=["n4l4_d50", "n3l6_d42", "n4l5_d60", "n4l3_d40", "n5l3_d60", "n6l2_d63", "n5l1_d30", "n6l0_d21"])
+                                 (6, 2, 5.0, 2.0), (5, 1, 5.0, 1.5), (6, 0, 4.0, 2.0), (4, 6, 5.0, 2.0), (5, 4, 5.0, 2.0),
+                                 (6, 3, 4.0, 2.0)],
+                         ids=["n4l4_d50", "n3l6_d42", "n4l5_d60", "n4l3_d40", "n5l3_d60", "n6l2_d63", "n5l1_d30", "n6l0_d21",
+                              "n4l6_d70", "n5l4_d75", "n6l3_d84"])
 def test_so3_long_descriptors_match_oracle(cfg):
     """more than 32 power-spectrum components (up to 64) and more than 16 radial-angular channels (up to 28): the wider
     record layout of the general kernel instance, periodic cell; nmax = 5 and 6 (lmax <= 3) take the third instance.  The
@@ -218,16 +220,18 @@ def test_atom_ids_subset_and_derivative_false_follow_the_reference_layout():
     nod = SO3(nmax=3, lmax=4, rcut=5.0, derivative=False).calculate(a)
     assert nod["dxdr"] is None and nod["rdxdr"] is None and "seq" not in nod and np.array_equal(nod["x"], full["x"])
     with pytest.raises(NotImplementedError):
-        SO3(nmax=4, lmax=6, rcut=5.0)             # ncoef = 70: beyond the device kernels, said at construction
+        SO3(nmax=5, lmax=5, rcut=5.0)             # ncoef = 90: beyond the device kernels, said at construction
     with pytest.raises(NotImplementedError):
         SO3(nmax=7, lmax=0, rcut=5.0)             # nmax > 6
+    assert SO3(nmax=4, lmax=6, rcut=5.0).ncoefs == 70 and SO3(nmax=5, lmax=4, rcut=5.0).ncoefs == 75
     assert SO3(nmax=6, lmax=2, rcut=5.0).ncoefs == 63
     assert SO3(nmax=4, lmax=4, rcut=5.0).ncoefs == 50
 
 
-@pytest.mark.parametrize("nl", [(4, 4), (6, 2)], ids=["n4l4_d50", "n6l2_d63"])
+@pytest.mark.parametrize("nl", [(4, 4), (6, 2), (5, 4)], ids=["n4l4_d50", "n6l2_d63", "n5l4_d75"])
 def test_gp_end_to_end_with_a_long_descriptor(port_natives, nl):
-    """SO3(nmax=4, lmax=4) / SO3(nmax=6, lmax=2) -> 64-column operand planes of the covariance kernels -> fit -> predict,
+    """SO3(nmax=4, lmax=4) / SO3(nmax=6, lmax=2) -> 64-column operand planes of the covariance kernels, SO3(nmax=5, lmax=4)
+    -> 128-column planes (round 4) -> fit -> predict,
     against the oracle (numpy descriptor + plain-C natives + scipy) on the same structures; RBF and Dot (pair route: the
     degree-2 feature map covers 32 columns)"""
     NMAX, LMAX = nl
