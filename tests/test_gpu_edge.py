@@ -235,14 +235,14 @@ def test_error_paths_fail_loudly():
         gp.fit(gp.points_from_structures([(s, E, F, True, [0, 1]), (s, E, F, True, [0, 1])]), show=False, opt=False)
     # descriptor longer than the packed operand width
     with pytest.raises(_lib.GprHipError):
-        dev.PackedSet(_lib.ROLE_STREAM, np.ones((4, 70)), None, np.full(4, 46), [4])          # 64 columns at most
+        dev.PackedSet(_lib.ROLE_STREAM, np.ones((4, 130)), None, np.full(4, 46), [4])         # 128 columns at most
     # counts that do not add up
     with pytest.raises(ValueError):
         dev.PackedSet(_lib.ROLE_STREAM, np.ones((4, 30)), None, np.full(4, 46), [3])
     # SO3 configuration outside the descriptor kernel's limits
     from gpr_calculator_amd.SO3 import SO3
     with pytest.raises(NotImplementedError):                  # said when the object is configured
-        SO3(nmax=4, lmax=6, rcut=5.0)
+        SO3(nmax=5, lmax=5, rcut=5.0)
 
 
 @pytest.mark.parametrize("kind", ["Dot", "RBF"])
