@@ -1,9 +1,9 @@
 #!/bin/bash
 # everything profiles/ holds for one round, in one GPU-box call: bench lines, rocprofv3 kernel-trace summaries (+ the split
 # by launch shape), device timelines, PMC traffic passes, per-kernel micro-benchmarks, the two-rank rehearsal.
-# usage (GPU box, repo root): bash tools/collect_round.sh r03
+# usage (GPU box, repo root): bash tools/collect_round.sh r04
 set -e
-R=${1:-r03}
+R=${1:-r04}
 O=gpurun_out/$R
 mkdir -p $O
 python bench.py > $O/${R}_dot_bench.json 2> $O/${R}_dot_bench.err
@@ -15,8 +15,12 @@ python bench.py --mode fit --steps 10 --warmup 2 --no-cpu-baseline > $O/${R}_fit
 python bench.py --mode fit --kernel RBF --steps 5 --warmup 1 --no-cpu-baseline > $O/${R}_fit_rbf_bench.json 2> $O/${R}_fit_rbf.err
 python bench.py --n-train 8000 --steps 50 --warmup 5 --no-cpu-baseline --no-pair-route > $O/${R}_cfg4_dot_bench.json 2> $O/${R}_cfg4_dot.err
 python bench.py --n-train 500 --batch 1 --steps 100 --warmup 5 --no-cpu-baseline --no-pair-route > $O/${R}_cfg2_dot_bench.json 2> $O/${R}_cfg2_dot.err
+# BASELINE.json configs[1] as it is stated: RBF, N_train = 500, single-shot fit() + predict() (batch 1, synchronous)
+python bench.py --kernel RBF --n-train 500 --batch 1 --depth 1 --steps 50 --warmup 5 > $O/${R}_cfg2_rbf_bench.json 2> $O/${R}_cfg2_rbf.err
+python bench.py --kernel RBF --n-train 500 --mode fit --steps 10 --warmup 2 --no-cpu-baseline > $O/${R}_cfg2_fit_rbf_bench.json 2> $O/${R}_cfg2_fit_rbf.err
 echo "fit / cfg2 / cfg4 done"
 python tools/potrf_check.py 1516 6063 24250 > $O/${R}_potrf_check.log 2>&1
+python tools/trsv_check.py > $O/${R}_trsv_check.log 2>&1 || true
 python tools/tail_bench.py > $O/${R}_tail_bench.log 2>&1
 GPR_TAIL_FORM=1 python tools/tail_bench.py >> $O/${R}_tail_bench.log 2>&1
 GPR_TAIL_FORM=1 GPR_TAIL_NO_GLDS=1 python tools/tail_bench.py >> $O/${R}_tail_bench.log 2>&1
@@ -26,6 +30,15 @@ python tools/pipeline_split.py 3 > $O/${R}_pipeline_split.log 2>&1
 python tools/single_latency.py 1 500 > $O/${R}_single_latency.log 2>&1
 python tools/single_latency.py 8 >> $O/${R}_single_latency.log 2>&1
 python tools/cfg5_loop.py > $O/${R}_cfg5_loop.log 2>&1
+python tools/cfg5_neb.py 50 2 > $O/${R}_cfg5_neb.log 2>&1
+bash tools/prof_cfg5.sh ${R}cfg5 > /dev/null 2>&1 && cp gpurun_out/${R}cfg5/${R}cfg5_cfg5_refit_stages.log $O/${R}_cfg5_refit_stages.log && cp gpurun_out/${R}cfg5/${R}cfg5_cfg5_refit_kernel_stats.csv $O/${R}_cfg5_refit_kernel_stats.csv && cp gpurun_out/${R}cfg5/${R}cfg5_cfg5_refit_kernel_stats_by_grid.csv $O/${R}_cfg5_refit_kernel_stats_by_grid.csv
+# the band under a kernel trace: what a refit is made of once the training set has a few thousand rows
+( export TMPDIR=/tmp; P=$PWD/gpurun_out/prof_${R}neb; mkdir -p $P; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $P -o neb -- python3 $OLDPWD/tools/cfg5_neb.py 25 1 > $OLDPWD/$O/${R}_cfg5_neb_under_rocprof.log 2>&1; cd $OLDPWD; find $P -name "*kernel_stats*.csv" | head -1 | xargs -I{} cp {} $O/${R}_cfg5_neb_kernel_stats.csv; rm -rf $P ) || true
+python tools/so3_only.py > $O/${R}_so3_only.log 2>&1
+python tools/so3_scan.py > $O/${R}_so3_scan.log 2>&1
+bash tools/so3_phases.sh > $O/${R}_so3_phases.log 2>&1 || true
+bash tools/pmc_so3_phases.sh > $O/${R}_so3_pmc_phases.log 2>&1 || true
+bash tools/pmc_so3_wait.sh > $O/${R}_so3_pmc_wait.log 2>&1 || true
 python tools/fit_opt_time.py > $O/${R}_fit_opt_time.log 2>&1 || true
 echo "micro done"
 bash tools/prof_bench.sh ${R}dot > /dev/null
