@@ -743,25 +743,32 @@ static int fused_admit(int nstruct, size_t lds, int *slot) {
             hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
         it = g_fused_capacity.emplace(std::make_pair(devid, lds_key), per_cu * cus).first;
     }
-    int flying = 0, free_slot = -1;
-    for (int k = 0; k < 32; k++) {
-        fused_flight &f = g_fused_flight[k];
-        if (f.busy && hipEventQuery(f.ev) != hipErrorNotReady) f.busy = false;      // finished (or failed: the stream will say)
-        if (f.busy) flying += f.wgs; else if (free_slot < 0) free_slot = k;
-    }
-    (void)hipGetLastError();
     const int forced_cap = g_fused_forced_capacity.load();          // tests (gpr_nbr_debug_fused_capacity)
     const int capacity = forced_cap >= 0 ? forced_cap : it->second;
+    // launches counted as in flight: first by the records alone (an upper bound -- finished launches are only struck off when
+    // somebody asks the runtime), and only if that bound does not admit the build by asking (an event query costs about a
+    // microsecond; a prediction step keeps two or three launches in flight and never gets here)
+    int flying = 0, free_slot = -1;
+    for (int pass = 0; pass < 2; pass++) {
+        flying = 0; free_slot = -1;
+        for (int k = 0; k < 32; k++) {
+            fused_flight &f = g_fused_flight[k];
+            if (pass == 1 && f.busy && hipEventQuery(f.ev) != hipErrorNotReady) f.busy = false;      // finished (or failed: the stream will say)
+            if (f.busy) flying += f.wgs; else if (free_slot < 0) free_slot = k;
+        }
+        if (free_slot >= 0 && 2 * (flying + nstruct) <= capacity) break;
+    }
+    (void)hipGetLastError();
     if (free_slot < 0 || 2 * (flying + nstruct) > capacity) return 0;
-    fused_flight &f = g_fused_flight[free_slot];
-    if (!f.ev && hipEventCreateWithFlags(&f.ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); f.ev = nullptr; return 0; }
     *slot = free_slot;
     return 1;
 }
-static void fused_arm(int slot, int nstruct, hipStream_t st) {
+// `ev`: the event the builder records behind the launch anyway (it guards the staging buffer; a later re-recording of it
+// only makes this record look busy for longer)
+static void fused_arm(int slot, int nstruct, hipEvent_t ev) {
     std::lock_guard<std::mutex> lk(g_fused_mu);
     fused_flight &f = g_fused_flight[slot];
-    if (hipEventRecord(f.ev, st) == hipSuccess) { f.wgs = nstruct; f.busy = true; } else (void)hipGetLastError();
+    f.ev = ev; f.wgs = nstruct; f.busy = true;
 }
 // resident workgroups the runtime reported for the last admitted shape on this device, launches counted as in flight (tests)
 extern "C" int gpr_nbr_fused_state(int *capacity, int *in_flight) {
@@ -925,8 +932,8 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.mask_off = mask_off;
         hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) fused_arm(flight_slot, nstruct, st);
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
+        if (e == hipSuccess) fused_arm(flight_slot, nstruct, sb.ev);
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fused launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
         nb->fused_rows = row_index_dev != nullptr;
         *out = nb;

@@ -205,6 +205,10 @@ def potrf_distributed(K, comm, ops, nb=NB):
     makes every rank raise, as the reference does, instead of leaving some of them in the next collective."""
     n = K.shape[0]
     dist = RowBlockCyclic(n, comm.size, nb)
+    if hasattr(ops, "lookahead") and "GPR_DIST_LOOKAHEAD" not in __import__("os").environ:
+        # two lanes where the collectives move device memory themselves (RCCL); a backend that stages through the host
+        # (gloo: rehearsals with several ranks on one device) serialises the lanes anyway and only pays for the second stream
+        ops.lookahead = bool(getattr(comm, "device_collectives", True))
     Aloc = ops.take_rows(K, ops.index_tables([dist.global_rows(comm.rank)])[0])
     cholesky_block_cyclic(Aloc, dist, comm, ops)
     L = gather_factor(Aloc, dist, comm, ops)
@@ -269,8 +273,14 @@ class DeviceOps(OpsBase):
     # (device.stream_ptr), and torch.distributed orders a collective behind the current stream and lets the current
     # stream wait for it -- so `with ops.side():` moves the chain of a step, collectives included, off the main lane.
     _side = _main = None
+    # GPR_DIST_LOOKAHEAD=0: one lane -- the chain and the update of a step run one after the other in the order they are
+    # written (what HostOps does; for A/B runs and for rehearsals in which several ranks share ONE device, where a second
+    # stream per process only adds context switches between the processes)
+    lookahead = __import__("os").environ.get("GPR_DIST_LOOKAHEAD", "1") != "0"
 
     def side(self):
+        if not self.lookahead:
+            return OpsBase.side(self)
         if self._side is None:
             self._side = torch.cuda.Stream(device=self.dev.device())
         self._main = torch.cuda.current_stream(self.dev.device())
@@ -278,12 +288,13 @@ class DeviceOps(OpsBase):
 
     def fork_side(self):
         """(called on the side lane) wait for everything the main lane has queued so far"""
-        self._side.wait_stream(self._main)
+        if self.lookahead:
+            self._side.wait_stream(self._main)
 
     def join_side(self, *tensors):
         """(called on the main lane) wait for everything the side lane has queued so far; tensors made there are about
         to be read here"""
-        if self._side is None:
+        if self._side is None or not self.lookahead:
             return
         torch.cuda.current_stream(self.dev.device()).wait_stream(self._side)
         for t in tensors:

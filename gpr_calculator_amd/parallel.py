@@ -65,6 +65,11 @@ class Comm:
             return torch.device("cuda", torch.cuda.current_device())
         return torch.device("cpu")
 
+    @property
+    def device_collectives(self):
+        """True when the backend moves device memory itself (RCCL over xGMI); gloo stages through the host"""
+        return not self.active or dist.get_backend(self.group) == "nccl"
+
     def all_gather_rows(self, local, counts, out=None):
         """row slabs [counts[r], ncols] of every rank -> [sum(counts), ncols], rank-major, written straight into `out`
         (allocated here when None).  Equal slabs: one all_gather_into_tensor.  Ragged slabs: rank r's slab is broadcast

@@ -66,4 +66,5 @@ python bench.py --gpus 2 --steps 50 --warmup 5 --no-pair-route --no-cpu-baseline
 python bench.py --gpus 2 --mode fit --steps 5 --warmup 1 > $O/${R}_world2_gloo_fit_dot.json 2> $O/${R}_world2_fit_dot.err
 python bench.py --gpus 2 --mode fit --kernel RBF --steps 3 --warmup 1 > $O/${R}_world2_gloo_fit_rbf.json 2> $O/${R}_world2_fit_rbf.err
 GPR_DIST_CHOL_MIN_N=1024 python bench.py --gpus 2 --mode fit --kernel RBF --steps 3 --warmup 1 > $O/${R}_world2_gloo_fit_rbf_cyclic.json 2> $O/${R}_world2_fit_rbf_cyclic.err
+GPR_DIST_LOOKAHEAD=0 GPR_DIST_CHOL_MIN_N=1024 python bench.py --gpus 2 --mode fit --kernel RBF --steps 3 --warmup 1 > $O/${R}_world2_gloo_fit_rbf_cyclic_one_lane.json 2> $O/${R}_world2_fit_rbf_cyclic_one_lane.err
 echo "all done"
