@@ -104,6 +104,7 @@ _L1_SIGNATURES = {
     "gpr_predict_dot2_batch": ([_vp, _i, _i, _d, _d, _i, _i, _vp, _i, c_int_p, c_double_p, c_double_p, c_int_p, c_int_p, _i,
                                C.POINTER(C.c_ubyte), _i, c_int_p, _d, _d, _vp, _vp, _vp, _i, _i, _i, _vp, _ll], _i),
     "gpr_so3_set_variant": ([_i], _i),
+    "gpr_so3_set_prepass_min": ([_i], _i),
     "gpr_so3_table_size": ([_i, _i, _i, _i], _ll),
     "gpr_so3_tables": ([_vp, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp], _i),
     "gpr_so3_radial": ([_vp, _i, _i, _i, _d, _d, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _vp], _i),

@@ -333,6 +333,9 @@ struct so3_args {
     const double *positions;    // [nc][3] centre positions as the caller gave them (not wrapped)
     const double *inv_vol;      // [nc] 1 / cell volume of the centre's structure
     double *rdxdr;              // NULL: not wanted
+    // large batches (so3_fixed_kernel only): the radial channels of every pair, [P][2][NLP] = A_nl | B_nl, formed by
+    // so3_radial_pairs_kernel in a streaming pass of its own; NULL: the centre kernel forms them itself
+    const double *ab;
 };
 
 constexpr int SO3_PC = 44;       // pairs whose tables are resident in LDS at a time (with the tables below: < 40 KB,
@@ -870,10 +873,85 @@ struct so3_fx {
     static_assert(L * PC <= 256 && (LT + 1) * PC <= 256 && NE <= SO3_SELFW && NB <= 256 && D <= 64 && NGRP >= 1, "lane maps");
 };
 
+// The radial channels of all pairs of a batch in a pass of their own.  Inside the centre kernel this is the half of a workgroup's
+// life that does not shrink: 48 sixteen-byte coefficient loads per lane behind the chain load -> root -> segment -> load, at three
+// workgroups per CU.  Per pair the work is independent of the centre, so for large batches it runs as a streaming kernel -- lane =
+// (pair, l), no LDS, no barrier, as many wavefronts per SIMD as the registers allow -- and leaves A_nl | B_nl ([P][2][NLP] doubles)
+// for the centre kernel to copy (10 KB per centre, contiguous).  Same arithmetic as the radial half of build_records below.
+template <int NMAX, int LMAX>
+__global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int ncentres, double *ab) {
+    using F = so3_fx<NMAX, LMAX>;
+    constexpr int L = F::L, NLP = F::NLP, NF = F::NF, H = SO3_NCHEB / 2;
+    const int npairs = P.centre_pair0[ncentres];              // (the caller's pair count may be a capacity: nbr.hip, capped builds)
+    const long long t_ = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int p = (int)(t_ / L), l = (int)(t_ - (long long)p * L);
+    if (p >= npairs) return;
+    const so3_tab tab = so3_table_layout(NMAX, LMAX, P.nseg, SO3_NCHEB);
+    const double seg_scale = (double)P.nseg / P.rcut, inv_rcut = 1.0 / P.rcut;
+    const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+    const double r2 = vx * vx + vy * vy + vz * vz, w = P.wj[p];
+    int seg = (int)(__builtin_sqrtf((float)r2) * (float)seg_scale);
+    seg = seg < 0 ? 0 : (seg > P.nseg - 1 ? P.nseg - 1 : seg);
+    const double2 *cb = (const double2 *)(P.table + (size_t)seg * SO3_NCHEB * NF) + l;
+    double2 ca[H], cl[H];
+#pragma unroll
+    for (int k = 0; k < H; k++) ca[k] = cb[(H + k) * (NF / 2)];
+#pragma unroll
+    for (int k = 0; k < H; k++) cl[k] = cb[k * (NF / 2)];
+    const double r = sqrt(r2);
+    double sarg, carg;
+    sincospi(r * inv_rcut, &sarg, &carg);
+    const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI * inv_rcut * sarg;
+    const double t = (r * seg_scale - (seg + 0.5)) * 2.0, t2 = 2.0 * t;
+    const double nw = P.table[tab.oNL + l] * w;
+    double *out = ab + (size_t)p * 2 * NLP;
+    double T8, T9;
+#pragma unroll
+    for (int n = 0; n < NMAX; n++) {
+        double f0 = 0.0, f1 = 0.0;
+        if (n == 0) {
+            double ta = 1.0, tb = t;
+#pragma unroll
+            for (int k = 2; k <= H + 1; k++) { const double tc = fma(t2, tb, -ta); ta = tb; tb = tc; }
+            T8 = ta; T9 = tb;
+        }
+        {
+            double ta = T8, tb = T9;
+#pragma unroll
+            for (int k = 0; k < H; k++) {
+                f0 = fma(ca[k].x, ta, f0); f1 = fma(ca[k].y, ta, f1);
+                const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + 1 < NMAX) {
+#pragma unroll
+            for (int k = 0; k < H; k++) ca[k] = cb[(n + 1) * L + (H + k) * (NF / 2)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            double ta = 1.0, tb = t;
+#pragma unroll
+            for (int k = 0; k < H; k++) {
+                f0 = fma(cl[k].x, ta, f0); f1 = fma(cl[k].y, ta, f1);
+                const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + 1 < NMAX) {
+#pragma unroll
+            for (int k = 0; k < H; k++) cl[k] = cb[(n + 1) * L + k * (NF / 2)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        out[n * L + l] = nw * (fc * f1 + dfc * f0);
+        out[NLP + n * L + l] = nw * fc * f0;
+    }
+}
+
 #ifndef GPR_SO3_FIXED_WAVES
 #define GPR_SO3_FIXED_WAVES 3
 #endif
-template <int NMAX, int LMAX>
+template <int NMAX, int LMAX, bool PREPASS>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO3_FIXED_WAVES, 4))) so3_fixed_kernel(so3_args P) {
     using F = so3_fx<NMAX, LMAX>;
     constexpr int L = F::L, M = F::M, YW = F::YW, LT = F::LT, NPI = F::NPI, NE = F::NE, NLP = F::NLP, REC = F::REC,
@@ -912,7 +990,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
     auto build_records = [&](int c0, int npc) {
         int hi_ = hi, q_ = q_lane;
         asm volatile("" : "+v"(hi_), "+v"(q_));
-        if (hi_ < L && q_ < npc) {                              // radial channels (n, l = hi) of pair q
+        if constexpr (PREPASS) {
+            // radial channels from the pre-pass: the chunk's [npc][2][NLP] block is contiguous; geometry by one lane per pair
+            const double2 *src = (const double2 *)(P.ab + (size_t)c0 * 2 * NLP);
+            for (int e = tid; e < npc * NLP; e += 256) {
+                const int q = e / NLP, j = e - q * NLP;             // NLP double2 per pair
+                *(double2 *)(recs + q * REC + 8 + 2 * j) = src[e];
+            }
+            if (tid < npc) {
+                const int p = c0 + tid;
+                double *rec = recs + tid * REC;
+                const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+                const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
+                rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
+            }
+        } else if (hi_ < L && q_ < npc) {                       // radial channels (n, l = hi) of pair q  (not PREPASS)
             const int l = hi_, p = c0 + q_;
             double *rec = recs + q_ * REC;
             const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
@@ -1242,6 +1334,10 @@ int so3_check_limits(int nmax, int lmax, int nq, int nseg, int ncheb, const char
 // two against each other)
 static std::atomic<int> g_so3_variant{0};
 extern "C" int gpr_so3_set_variant(int generic_only) { g_so3_variant.store(generic_only ? 1 : 0); return GPR_OK; }
+// smallest number of centres for which the radial channels are formed by the streaming pre-pass (tests / A-B: 0 always,
+// a huge number never)
+static std::atomic<int> g_so3_prepass_min{512};
+extern "C" int gpr_so3_set_prepass_min(int ncentres) { g_so3_prepass_min.store(ncentres < 0 ? 0 : ncentres); return GPR_OK; }
 
 extern "C" long long gpr_so3_table_size(int nmax, int lmax, int nseg, int ncheb) {
     return so3_table_layout(nmax, lmax, nseg, ncheb).total;
@@ -1339,7 +1435,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     A.dbg = GPR_PHASE_ENV("GPR_SO3_DBG");          // phase ablation: tools build only (gpr_internal.h); 0 otherwise
     A.table = table; A.vec = vec; A.wj = wj; A.centre_pair0 = centre_pair0; A.centre_row0 = centre_row0;
     A.row_pair0 = row_pair0; A.self_row = self_row; A.x = x; A.dxdr = dxdr;
-    A.positions = positions; A.inv_vol = inv_vol; A.rdxdr = rdxdr;
+    A.positions = positions; A.inv_vol = inv_vol; A.rdxdr = rdxdr; A.ab = nullptr;
     const so3_lds lay = so3_layout(nmax, lmax, rdxdr != nullptr);
     const size_t lds_bytes = (size_t)lay.total * sizeof(double);
     if (lds_bytes > 96 * 1024) {
@@ -1360,8 +1456,20 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     if (!rdxdr && nmax == 3 && lmax == 4 && g_so3_variant.load() == 0) {
         // the configuration of the reference's defaults: every size a compile-time constant (so3_fixed_kernel)
         using F = so3_fx<3, 4>;
-        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4>, F::TOTAL * (int)sizeof(double)))) return rc;
-        hipLaunchKernelGGL((so3_fixed_kernel<3, 4>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
+        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4, false>, F::TOTAL * (int)sizeof(double)))) return rc;
+        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4, true>, F::TOTAL * (int)sizeof(double)))) return rc;
+        // large batches: the radial channels in a streaming pass of their own (so3_radial_pairs_kernel); a few structures are
+        // quicker in one launch
+        void *ab = nullptr;
+        if (ncentres >= g_so3_prepass_min.load() && npairs > 0) {
+            if ((rc = gpr_dev_alloc(&ab, (size_t)npairs * 2 * F::NLP * sizeof(double), st))) return rc;
+            const long long lanes = (long long)npairs * F::L;
+            hipLaunchKernelGGL((so3_radial_pairs_kernel<3, 4>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, A, ncentres, (double *)ab);
+            A.ab = (const double *)ab;
+        }
+        if (ab) hipLaunchKernelGGL((so3_fixed_kernel<3, 4, true>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
+        else hipLaunchKernelGGL((so3_fixed_kernel<3, 4, false>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
+        if (ab) gpr_dev_free(ab, st);
     } else if (rdxdr) {
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);

@@ -355,6 +355,9 @@ int gpr_so3_power_spectrum(void *stream, int nmax, int lmax, double rcut, double
  * compile time; every other (nmax, lmax) -- and the stress rows -- take the generic kernel.  gpr_so3_set_variant(1) sends
  * everything through the generic kernel (tests compare the two), 0 restores the default. */
 int gpr_so3_set_variant(int generic_only);
+/* The compile-time instance forms the radial channels of large batches in a streaming pre-pass of its own (a second, small
+ * launch); batches with fewer than `ncentres` centres (default 512) keep everything in one launch.  0: always, INT_MAX: never. */
+int gpr_so3_set_prepass_min(int ncentres);
 /* same plus the stress rows rdxdr[nrows, d, 3, 3] = -pstress / volume of SO3.calculate(stress=True)
  * (SO3.py:240-306): positions[ncentres, 3] = centre positions as the caller gave them (not wrapped),
  * inv_vol[ncentres] = 1 / cell volume of the centre's structure, both device; rdxdr == NULL: as above */

@@ -8,8 +8,9 @@ des = SO3(nmax=3, lmax=4, rcut=5.0, alpha=2.0)
 NB = int(os.environ.get('SO3_NB', '64'))
 batch = neb_images(NB, seed=100)
 from gpr_calculator_amd import _lib
-for variant in (0, 1):                              # 0: compile-time instance where there is one; 1: the generic kernel
-    _lib.lib().gpr_so3_set_variant(variant)
+for variant in (0, 2, 1):                           # 0: compile-time instance (radial pre-pass for large batches); 2: the same in one launch; 1: the generic kernel
+    _lib.lib().gpr_so3_set_variant(1 if variant == 1 else 0)
+    _lib.lib().gpr_so3_set_prepass_min(1 << 30 if variant == 2 else 512)
     out = des.calculate_batch_dev(batch); torch.cuda.synchronize()
     dev.profile_enable(True)
     for _ in range(20): des.calculate_batch_dev(batch)
@@ -22,4 +23,4 @@ for variant in (0, 1):                              # 0: compile-time instance w
     else:
         for k in ("x", "dxdr"):
             print(f"   fixed vs generic, {k}: max |diff| / max |value| = {float((ref[k] - out[k]).abs().max() / out[k].abs().max()):.2e}")
-_lib.lib().gpr_so3_set_variant(0)
+_lib.lib().gpr_so3_set_variant(0); _lib.lib().gpr_so3_set_prepass_min(512)
