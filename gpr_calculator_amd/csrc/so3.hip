@@ -333,7 +333,7 @@ struct so3_args {
     const double *positions;    // [nc][3] centre positions as the caller gave them (not wrapped)
     const double *inv_vol;      // [nc] 1 / cell volume of the centre's structure
     double *rdxdr;              // NULL: not wanted
-    // large batches (so3_fixed_kernel only): the radial channels of every pair, [P][2][NLP] = A_nl | B_nl, formed by
+    // large batches (so3_fixed_kernel only): geometry and radial channels of every pair, [P][8 + 2 NLP] = u, 1/r, r | A_nl | B_nl, formed by
     // so3_radial_pairs_kernel in a streaming pass of its own; NULL: the centre kernel forms them itself
     const double *ab;
 };
@@ -847,14 +847,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4))
 //   pass 2        lane = (pair, l) with the heavy l first (a wavefront pays for the largest l it holds).
 // Same arithmetic as the generic kernel up to the order of a few sums; tests/test_gpu_so3.py holds both to the goldens of the
 // reference's own SO3.calculate and to each other.
-template <int NMAX, int LMAX>
+template <int NMAX, int LMAX, bool PRE = false>
 struct so3_fx {
     static constexpr int L = LMAX + 1, M = 2 * LMAX + 1, NL = NMAX * L, YW = LMAX + 3, LT = LMAX + 1;
     static constexpr int NPI = NMAX * (NMAX + 1) / 2, D = NPI * L, NE = 3 * D;
     static constexpr int TRI = (LT + 1) * (LT + 2) / 2;       // Y_l^m, 0 <= m <= l <= LT
     static constexpr int TRIL = L * (L + 1) / 2;              // (l, m >= 0) with l <= LMAX
     static constexpr int NLP = (NL + 1) & ~1;                 // channel tables padded to an even length (16-byte records)
-    static constexpr int REC = 8 + 2 * NLP + 2 * TRI;
+    // record of a pair in LDS: [ux uy uz 1/r r - - -] | A [NLP] | B [NLP] | Y_l^m; with the radial pre-pass (PRE) A stays in
+    // global memory (pass 2 reads its three values per lane from there): [geometry] | B | Y
+    static constexpr int OA = 8, OB = PRE ? 8 : 8 + NLP, OY = OB + NLP;
+    static constexpr int REC = OY + 2 * TRI;
+    static constexpr int HEAD = 8 + 2 * NLP;                  // record head the pre-pass writes per pair: geometry | B | A
+    // rows of dxdr staged at a time: all rows of a chunk, or -- PRE, to fit five workgroups on a CU -- slabs of 31
+    static constexpr int RCAP = PRE ? 31 : 256 / (LT + 1) + 1;
     static constexpr int PC = 256 / (LT + 1);                 // pairs per chunk: (pair, m) lanes for m = 0 .. LT
     static constexpr int NB = (L * L + L) * 3;                // gradient-table entries per n
     static constexpr int NLM = NL * M;
@@ -867,7 +873,7 @@ struct so3_fx {
     static constexpr int oTf = oRf + 2 * NL * L;
     static constexpr int oPart = oTf;                           // the partial sums of c_tot are consumed before T is written
     static constexpr int oRec = oTf + (2 * NMAX * NB > 2 * NTASK * NGRP ? 2 * NMAX * NB : 2 * NTASK * NGRP);
-    static constexpr int AREA_REC = PC * REC + PC + 2, AREA_ROWS = (PC + 1) * NE;
+    static constexpr int AREA_REC = PC * REC + PC + 2, AREA_ROWS = RCAP * NE;
     static constexpr int AREA = AREA_REC > AREA_ROWS ? AREA_REC : AREA_ROWS;
     static constexpr int TOTAL = oRec + (AREA > 2 * SO3_SELFW ? AREA : 2 * SO3_SELFW);
     static_assert(L * PC <= 256 && (LT + 1) * PC <= 256 && NE <= SO3_SELFW && NB <= 256 && D <= 64 && NGRP >= 1, "lane maps");
@@ -876,8 +882,8 @@ struct so3_fx {
 // The radial channels of all pairs of a batch in a pass of their own.  Inside the centre kernel this is the half of a workgroup's
 // life that does not shrink: 48 sixteen-byte coefficient loads per lane behind the chain load -> root -> segment -> load, at three
 // workgroups per CU.  Per pair the work is independent of the centre, so for large batches it runs as a streaming kernel -- lane =
-// (pair, l), no LDS, no barrier, as many wavefronts per SIMD as the registers allow -- and leaves A_nl | B_nl ([P][2][NLP] doubles)
-// for the centre kernel to copy (10 KB per centre, contiguous).  Same arithmetic as the radial half of build_records below.
+// (pair, l), no LDS, no barrier, as many wavefronts per SIMD as the registers allow -- and leaves the head of the pair's record,
+// geometry | A_nl | B_nl ([P][8 + 2 NLP] doubles), for the centre kernel to copy (13 KB per centre, contiguous).  Same arithmetic as the radial half of build_records below.
 template <int NMAX, int LMAX>
 __global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int ncentres, double *ab) {
     using F = so3_fx<NMAX, LMAX>;
@@ -904,7 +910,11 @@ __global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int n
     const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI * inv_rcut * sarg;
     const double t = (r * seg_scale - (seg + 0.5)) * 2.0, t2 = 2.0 * t;
     const double nw = P.table[tab.oNL + l] * w;
-    double *out = ab + (size_t)p * 2 * NLP;
+    double *out = ab + (size_t)p * (8 + 2 * NLP) + 8;           // the pair's record head: [ux uy uz 1/r r - - -] | B | A
+    if (l == 0) {
+        const double inv_r = 1.0 / r;
+        out[-8] = vx * inv_r; out[-7] = vy * inv_r; out[-6] = vz * inv_r; out[-5] = inv_r; out[-4] = r;
+    }
     double T8, T9;
 #pragma unroll
     for (int n = 0; n < NMAX; n++) {
@@ -943,8 +953,8 @@ __global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int n
             for (int k = 0; k < H; k++) cl[k] = cb[(n + 1) * L + k * (NF / 2)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        out[n * L + l] = nw * (fc * f1 + dfc * f0);
-        out[NLP + n * L + l] = nw * fc * f0;
+        out[NLP + n * L + l] = nw * (fc * f1 + dfc * f0);
+        out[n * L + l] = nw * fc * f0;
     }
 }
 
@@ -952,8 +962,9 @@ __global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int n
 #define GPR_SO3_FIXED_WAVES 3
 #endif
 template <int NMAX, int LMAX, bool PREPASS>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO3_FIXED_WAVES, 4))) so3_fixed_kernel(so3_args P) {
-    using F = so3_fx<NMAX, LMAX>;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PREPASS ? 5 : GPR_SO3_FIXED_WAVES, PREPASS ? 5 : 4)))
+so3_fixed_kernel(so3_args P) {      // with the pre-pass: <= 96 registers and 31 KB of LDS, five workgroups per CU
+    using F = so3_fx<NMAX, LMAX, PREPASS>;
     constexpr int L = F::L, M = F::M, YW = F::YW, LT = F::LT, NPI = F::NPI, NE = F::NE, NLP = F::NLP, REC = F::REC,
                   PC = F::PC, NB = F::NB, NLM = F::NLM, NTASK = F::NTASK, NGRP = F::NGRP, NF = F::NF, TRIL = F::TRIL;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -991,18 +1002,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
         int hi_ = hi, q_ = q_lane;
         asm volatile("" : "+v"(hi_), "+v"(q_));
         if constexpr (PREPASS) {
-            // radial channels from the pre-pass: the chunk's [npc][2][NLP] block is contiguous; geometry by one lane per pair
-            const double2 *src = (const double2 *)(P.ab + (size_t)c0 * 2 * NLP);
-            for (int e = tid; e < npc * NLP; e += 256) {
-                const int q = e / NLP, j = e - q * NLP;             // NLP double2 per pair
-                *(double2 *)(recs + q * REC + 8 + 2 * j) = src[e];
-            }
-            if (tid < npc) {
-                const int p = c0 + tid;
-                double *rec = recs + tid * REC;
-                const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
-                const double r = sqrt(vx * vx + vy * vy + vz * vz), inv_r = 1.0 / r;
-                rec[0] = vx * inv_r; rec[1] = vy * inv_r; rec[2] = vz * inv_r; rec[3] = inv_r; rec[4] = r;
+            // geometry and B_nl from the pre-pass: the first 8 + NLP doubles of every pair's head (A_nl stays behind them in
+            // global memory for pass 2)
+            constexpr int COPY2 = (8 + NLP) / 2;                 // double2 per pair
+            const double2 *src = (const double2 *)(P.ab + (size_t)c0 * F::HEAD);
+            for (int e = tid; e < npc * COPY2; e += 256) {
+                const int q = e / COPY2, j = e - q * COPY2;
+                *(double2 *)(recs + q * REC + 2 * j) = src[q * (F::HEAD / 2) + j];
             }
         } else if (hi_ < L && q_ < npc) {                       // radial channels (n, l = hi) of pair q  (not PREPASS)
             const int l = hi_, p = c0 + q_;
@@ -1069,8 +1075,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
                     for (int k = 0; k < H; k++) cl[k] = cb[(n + 1) * L + k * (NF / 2)];
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                rec[8 + n * L + l] = nw * (fc * f1 + dfc * f0);
-                rec[8 + NLP + n * L + l] = nw * fc * f0;
+                rec[F::OA + n * L + l] = nw * (fc * f1 + dfc * f0);
+                rec[F::OB + n * L + l] = nw * fc * f0;
             }
             if (l == 0) {
                 const double inv_r = 1.0 / r;
@@ -1090,7 +1096,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
                     const double e2 = er * ux - ei * uy;
                     ei = er * uy + ei * ux; er = e2;
                 }
-            cplx *Y = (cplx *)(rec + 8 + 2 * NLP);
+            cplx *Y = (cplx *)(rec + F::OY);
             // Q_m^m = 1, Q_l^m = ((2l - 1) cos(theta) Q_{l-1}^m - (l + m - 1) Q_{l-2}^m) / (l - m) with Q_{m-1}^m = 0
             double q2 = 0.0, q1 = 1.0;
             { const double nrm = sNY[m * YW + m]; Y[m * (m + 1) / 2 + m] = {nrm * er, nrm * ei}; }
@@ -1126,8 +1132,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
             if (mine)
                 for (int q = grp; q < npc; q += NGRP) {
                     const double *rec = recs + q * REC;
-                    const cplx y = ((const cplx *)(rec + 8 + 2 * NLP))[l * (l + 1) / 2 + m];
-                    const double b = rec[8 + NLP + nl];
+                    const cplx y = ((const cplx *)(rec + F::OY))[l * (l + 1) / 2 + m];
+                    const double b = rec[F::OB + nl];
                     acc.re = fma(b, y.re, acc.re); acc.im = fma(b, y.im, acc.im);
                 }
             if (nchunks > 1) __syncthreads();                  // records are rebuilt by the next chunk
@@ -1213,7 +1219,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
         double outv[NPI * 3];
         if (active) {
             const double *rec = recs + q * REC;
-            const cplx *Y = (const cplx *)(rec + 8 + 2 * NLP);
+            const cplx *Y = (const cplx *)(rec + F::OY);
             double Rn[NMAX], Sn[NMAX][3];
 #pragma unroll
             for (int n = 0; n < NMAX; n++) { Rn[n] = 0.0; Sn[n][0] = 0.0; Sn[n][1] = 0.0; Sn[n][2] = 0.0; }
@@ -1259,7 +1265,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
             const double inv_r = rec[3], u[3] = {rec[0], rec[1], rec[2]};
             double An[NMAX], Bn[NMAX];
 #pragma unroll
-            for (int n = 0; n < NMAX; n++) { An[n] = rec[8 + n * L + l]; Bn[n] = rec[8 + NLP + n * L + l] * inv_r; }
+            for (int n = 0; n < NMAX; n++) {
+                An[n] = PREPASS ? P.ab[(size_t)(c0 + q) * F::HEAD + 8 + NLP + n * L + l] : rec[F::OA + n * L + l];
+                Bn[n] = rec[F::OB + n * L + l] * inv_r;
+            }
 #pragma unroll
             for (int n1 = 0; n1 < NMAX; n1++)
 #pragma unroll
@@ -1279,37 +1288,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GPR_SO
         const bool cont = P.row_pair0[r0 + rowb] < c0;    // the chunk's first row began in the previous chunk
         __syncthreads();                                  // map read: the row buffer may take its place
         const bool mine = active && r0 + myrow != rself;  // periodic images of the centre itself cancel (SO3.py:266-273)
-        double *dst = rowOut + (myrow - rowb) * NE + l * 3;
-        for (int j = 0; j < maxj; j++) {
-            if (mine && myj == j) {
-#pragma unroll
-                for (int pi = 0; pi < NPI; pi++)
-#pragma unroll
-                    for (int k = 0; k < 3; k++) {
-                        double *o = dst + pi * L * 3 + k;
-                        *o = j == 0 ? outv[pi * 3 + k] : *o + outv[pi * 3 + k];
-                    }
-            }
-            __syncthreads();
-        }
-        GPR_PHASE_EXIT(P.dbg, 4)
-        // the chunk's slab of dxdr, flat and 16 bytes at a time (a row is NE * 8 = 720 bytes); the (i, i) row is skipped
         static_assert(NE % 2 == 0, "rows are whole 16-byte pieces");
-        {
-            double2 *gdst = (double2 *)(P.dxdr + (size_t)(r0 + rowb) * NE);
-            const double2 *src = (const double2 *)rowOut;
-            for (int f = tid; f < nrows_c * (NE / 2); f += 256) {
-                const int rl = f / (NE / 2);
-                if (r0 + rowb + rl == rself) continue;
-                double2 v = src[f];
-                if (cont && rl == 0) { const double2 o = gdst[f]; v.x += o.x; v.y += o.y; }
-                gdst[f] = v;
+        // the chunk's rows go through the staging buffer in slabs of at most RCAP rows (one slab unless the buffer was made
+        // smaller than a chunk's rows: PREPASS)
+        for (int rb = 0; rb < nrows_c; rb += F::RCAP) {
+            const int nr = min(F::RCAP, nrows_c - rb), lrow = myrow - rowb - rb;
+            const bool here = mine && lrow >= 0 && lrow < nr;
+            double *dst = rowOut + lrow * NE + l * 3;
+            for (int j = 0; j < maxj; j++) {
+                if (here && myj == j) {
+#pragma unroll
+                    for (int pi = 0; pi < NPI; pi++)
+#pragma unroll
+                        for (int k = 0; k < 3; k++) {
+                            double *o = dst + pi * L * 3 + k;
+                            *o = j == 0 ? outv[pi * 3 + k] : *o + outv[pi * 3 + k];
+                        }
+                }
+                __syncthreads();
             }
+            GPR_PHASE_EXIT(P.dbg, 4)
+            // the slab of dxdr, flat and 16 bytes at a time (a row is NE * 8 = 720 bytes); the (i, i) row is skipped
+            {
+                double2 *gdst = (double2 *)(P.dxdr + (size_t)(r0 + rowb + rb) * NE);
+                const double2 *src = (const double2 *)rowOut;
+                for (int f = tid; f < nr * (NE / 2); f += 256) {
+                    const int rl = f / (NE / 2);
+                    if (r0 + rowb + rb + rl == rself) continue;
+                    double2 v = src[f];
+                    if (cont && rb + rl == 0) { const double2 o = gdst[f]; v.x += o.x; v.y += o.y; }
+                    gdst[f] = v;
+                }
+            }
+            if (spart < NSP)
+                for (int rl = spart; rl < nr; rl += NSP)
+                    if (r0 + rowb + rb + rl != rself) selfacc += rowOut[rl * NE + scol];
+            __syncthreads();                              // staging buffer consumed (the next slab / chunk reuses it)
         }
-        if (spart < NSP)
-            for (int rl = spart; rl < nrows_c; rl += NSP)
-                if (r0 + rowb + rl != rself) selfacc += rowOut[rl * NE + scol];
-        __syncthreads();                                  // row buffer consumed (the next chunk rebuilds the records)
     }
     if (spart < NSP) sSelf[spart * SO3_SELFW + scol] = selfacc;
     __syncthreads();
@@ -1455,19 +1470,20 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
     const bool small_l = lmax + 1 <= 5 && nmax <= 3;
     if (!rdxdr && nmax == 3 && lmax == 4 && g_so3_variant.load() == 0) {
         // the configuration of the reference's defaults: every size a compile-time constant (so3_fixed_kernel)
-        using F = so3_fx<3, 4>;
+        using F = so3_fx<3, 4, false>;
+        using FP = so3_fx<3, 4, true>;
         if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4, false>, F::TOTAL * (int)sizeof(double)))) return rc;
-        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4, true>, F::TOTAL * (int)sizeof(double)))) return rc;
+        if ((rc = gpr_func_lds_once((const void *)so3_fixed_kernel<3, 4, true>, FP::TOTAL * (int)sizeof(double)))) return rc;
         // large batches: the radial channels in a streaming pass of their own (so3_radial_pairs_kernel); a few structures are
         // quicker in one launch
         void *ab = nullptr;
         if (ncentres >= g_so3_prepass_min.load() && npairs > 0) {
-            if ((rc = gpr_dev_alloc(&ab, (size_t)npairs * 2 * F::NLP * sizeof(double), st))) return rc;
+            if ((rc = gpr_dev_alloc(&ab, (size_t)npairs * (8 + 2 * F::NLP) * sizeof(double), st))) return rc;
             const long long lanes = (long long)npairs * F::L;
             hipLaunchKernelGGL((so3_radial_pairs_kernel<3, 4>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, A, ncentres, (double *)ab);
             A.ab = (const double *)ab;
         }
-        if (ab) hipLaunchKernelGGL((so3_fixed_kernel<3, 4, true>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
+        if (ab) hipLaunchKernelGGL((so3_fixed_kernel<3, 4, true>), dim3(ncentres), dim3(256), FP::TOTAL * sizeof(double), st, A);
         else hipLaunchKernelGGL((so3_fixed_kernel<3, 4, false>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
         if (ab) gpr_dev_free(ab, st);
     } else if (rdxdr) {
