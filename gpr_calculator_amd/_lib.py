@@ -71,6 +71,7 @@ _L1_SIGNATURES = {
     "gpr_trtri_lower": ([_vp, _i, _vp, _ll, _vp, _ll], _i),
     "gpr_mirror_lower": ([_vp, _i, _vp, _ll], _i),
     "gpr_trmm_lower": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp, _ll], _i),
+    "gpr_trmm_lower_sumsq": ([_vp, _i, _i, _vp, _ll, _vp, _ll, _vp], _i),
     "gpr_add_diag": ([_vp, _i, _vp, _ll, _i, _d, _d], _i),
     "gpr_colsumsq": ([_vp, _i, _i, _vp, _ll, _vp], _i),
     "gpr_sum_log_diag": ([_vp, _i, _vp, _ll, _vp], _i),

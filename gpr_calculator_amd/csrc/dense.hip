@@ -16,6 +16,7 @@ namespace {
 
 constexpr int BM = 64, BN = 64, BK = 16, LDS_LD = BM + 16;   // +16 doubles: rows k, k+1 hit disjoint banks
 constexpr int NB = 64;                                        // Cholesky / TRSM panel width
+constexpr int GPR_FEW_COLS = 256;                             // up to here the column reductions / the variance product take their few-column forms
 
 // C[m,n] = alpha * op(A) op(B) + beta * C ;  op(A) is m x k, op(B) is k x n
 // one 64x64 C tile per 256-thread workgroup; each wavefront owns a 32x32 quadrant = 2x2 MFMA tiles
@@ -320,6 +321,184 @@ __global__ void colsum_final_kernel(int nparts, int ncols, const double *part, d
     double acc = 0.0;
     for (int p = 0; p < nparts; p++) acc += part[(long long)p * ncols + j];
     out[j] = acc;
+}
+
+// ---- few columns (one structure: 1 + 3 n_atoms quantities): the thread-per-column kernels above leave most of the chip idle
+// and walk their rows serially.  Here a block of 256 threads is (256 / CW row lanes) x (CW columns); the row lanes are added in
+// lane order through LDS, the blocks by colsum_final_kernel in block order.
+template <int CW, bool SQ>
+__global__ void __launch_bounds__(256) colred_few_kernel(int n, int ncols, const double *__restrict__ a, long long lda,
+                                                        const double *__restrict__ x, double *__restrict__ part, int rows_per) {
+    constexpr int RL = 256 / CW;
+    __shared__ double red[256];
+    const int j = blockIdx.x * CW + (threadIdx.x % CW), rl = threadIdx.x / CW;
+    const int r0 = blockIdx.y * rows_per, r1 = min(n, r0 + rows_per);
+    double acc = 0.0;
+    if (j < ncols)
+        for (int i = r0 + rl; i < r1; i += RL) {
+            const double t = a[(long long)i * lda + j];
+            acc += SQ ? t * t : t * x[i];
+        }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && j < ncols) {
+#pragma unroll
+        for (int k = 1; k < RL; k++) acc += red[k * CW + threadIdx.x];
+        part[(long long)blockIdx.y * ncols + j] = acc;
+    }
+}
+
+// second pass of the few-column reductions: four lanes per column take every fourth part, then are added in lane order
+__global__ void __launch_bounds__(256) colsum_final_few_kernel(int nparts, int ncols, const double *__restrict__ part, long long ldp,
+                                                               double *__restrict__ out) {
+    __shared__ double red[256];
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+    double acc = 0.0;
+    if (j < ncols)
+        for (int p = rl; p < nparts; p += 4) acc += part[(long long)p * ldp + j];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && j < ncols) out[j] = ((acc + red[64 + threadIdx.x]) + red[128 + threadIdx.x]) + red[192 + threadIdx.x];
+}
+
+// Bp[i][0 .. ldp) = B[i][0 .. ncols) followed by zeros: the few-column product below reads whole, aligned rows
+__global__ void pad_cols_kernel(int n, int ncols, const double *__restrict__ B, long long ldb, double *__restrict__ Bp, int ldp) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (long long)n * ldp) return;
+    const int i = (int)(e / ldp), j = (int)(e % ldp);
+    Bp[e] = j < ncols ? B[(long long)i * ldb + j] : 0.0;
+}
+
+// part[w][j] = sum over the rows i of block w of (sum_k T[i][k] Bp[k][j])^2 for a LOWER-triangular T [n x n] and FEW columns
+// (16 CT per blockIdx.y): the subtracted term of the predictive variance, |L^-1 k_j|^2 (gaussianprocess.py:903-907), without
+// V = T B ever reaching memory.  T is streamed from HBM exactly once (n^2 / 2 doubles, the traffic that bounds the kernel);
+// Bp (n x ldp, a few MB, zero-padded to whole tiles by pad_cols_kernel) is re-read from L2 by every block.  A block owns
+// 16-row blocks of T; triangular rows cost in proportion to their index, so block w takes the pair (NB - 1 - w, w),
+// every pair the same length.  Its eight wavefronts split the k range in runs of 16, and both operands go straight from
+// memory into the MFMA operand registers with one wide load per lane: lane (r = l & 15, q = l >> 4) takes
+// T[i0 + r][k0 + 4q .. + 3] (a full 128-byte line per row and run) and, for each of those four k, Bp[k][CT r .. CT r + CT - 1]
+// -- so MFMA step e of a run multiplies k = k0 + 4q + e, and column tile t holds the columns CT r + t (a permutation that
+// the column sums do not care about).  Rows of T are only 8-byte aligned (odd n), which the wide global loads accept.
+// Every load of the main loop is unconditional (no divergent control flow, so the loads of later runs stay in flight
+// across the MFMA steps of earlier ones: the T loads of four runs and the Bp loads of two per wavefront, 64 KB of T per
+// CU); only the run that holds the diagonal block masks what lies above the diagonal.
+// The eight partial tiles are folded in a fixed order through LDS; wavefront 0 squares and adds the 16 rows.
+template <int W> struct dvec_u;
+template <> struct dvec_u<1> { typedef double type; };
+template <> struct dvec_u<2> { typedef double type __attribute__((ext_vector_type(2), aligned(8))); };
+template <> struct dvec_u<4> { typedef double type __attribute__((ext_vector_type(4), aligned(8))); };
+template <int W> __device__ __forceinline__ double dvec_get(const typename dvec_u<W>::type &v, int e) { return v[e]; }
+template <> __device__ __forceinline__ double dvec_get<1>(const double &v, int) { return v; }
+
+template <int CT>                                  // columns per lane: 1, 2 or 4 (16 CT columns per blockIdx.y)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))     // one block per CU is all a launch has (n <= 8192)
+trmm_sumsq_few_kernel(int n, const double *__restrict__ T, long long ldt, const double *__restrict__ Bp, int ldp,
+                      double *__restrict__ part) {
+    constexpr int NWV = 8, RUN = 16, DA = 4;
+    typedef typename dvec_u<4>::type avec;
+    typedef typename dvec_u<CT>::type bvec;
+    __shared__ double sR[4][16 * 16 * CT];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int nb = (n + 15) >> 4;
+    const int j0 = blockIdx.y * 16 * CT + CT * lr;                      // first column of this lane
+    double colacc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; t++) colacc[t] = 0.0;
+    for (int leg = 0; leg < 2; leg++) {
+        const int b = leg == 0 ? nb - 1 - (int)blockIdx.x : (int)blockIdx.x;
+        if (leg == 1 && b >= nb - 1 - (int)blockIdx.x) break;            // the middle block of an odd count comes once
+        const int i0 = b * 16, irow = i0 + lr;
+        const int nrun = b + 1;                                          // run b holds the diagonal block
+        const double *tp = T + (long long)min(irow, n - 1) * ldt + 4 * lq;      // rows past the end repeat the last one; dropped below
+        const double *bp = Bp + (long long)(4 * lq) * ldp + j0;
+        d4 acc[CT];
+#pragma unroll
+        for (int t = 0; t < CT; t++) acc[t] = d4{0.0, 0.0, 0.0, 0.0};
+        auto load_a = [&](int run, double (&a)[4]) {                    // run < b: entirely below the diagonal
+            const avec v = *(const avec *)(tp + run * RUN);
+#pragma unroll
+            for (int e = 0; e < 4; e++) a[e] = v[e];
+        };
+        auto load_b = [&](int run, double (&bb)[4][CT]) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const bvec v = *(const bvec *)(bp + (long long)(run * RUN + e) * ldp);
+#pragma unroll
+                for (int t = 0; t < CT; t++) bb[e][t] = dvec_get<CT>(v, t);
+            }
+        };
+        auto mma = [&](const double (&a)[4], const double (&bb)[4][CT]) {
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int t = 0; t < CT; t++) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[e], bb[e][t], acc[t], 0, 0, 0);
+        };
+        // runs 0 .. b - 1 through the pipeline.  The prefetches past the last run repeat it (unused), so that the loop body has
+        // no conditional load and the only branches are the scalar loop exits.
+        const int nfull = nrun - 1, last = max(nfull - 1, 0);
+        double aq[DA][4], bq[2][4][CT];
+#pragma unroll
+        for (int u = 0; u < DA; u++) load_a(min(wave + u * NWV, last), aq[u]);
+        load_b(min(wave, last), bq[0]);
+        for (int run = wave; run < nfull;) {
+#pragma unroll
+            for (int u = 0; u < DA; u++) {
+                if (run >= nfull) break;
+                load_b(min(run + NWV, last), bq[(u + 1) & 1]);
+                double a[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) a[e] = aq[u][e];
+                load_a(min(run + DA * NWV, last), aq[u]);
+                mma(a, bq[u & 1]);
+                run += NWV;
+            }
+        }
+        if (wave == (b & (NWV - 1))) {                                  // the diagonal run: k <= i only, and k < n
+            double a[4], bb[4][CT];
+            const int k = b * RUN + 4 * lq;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                const int kc = min(k + e, n - 1);
+                const double av = T[(long long)min(irow, n - 1) * ldt + kc];
+                const bvec v = *(const bvec *)(Bp + (long long)kc * ldp + j0);
+                a[e] = (k + e <= irow && irow < n) ? av : 0.0;
+#pragma unroll
+                for (int t = 0; t < CT; t++) bb[e][t] = dvec_get<CT>(v, t);
+            }
+            mma(a, bb);
+        }
+        // fold the eight partial tiles: 4..7 onto 0..3, 2..3 onto 0..1, 1 onto 0
+#pragma unroll
+        for (int half = 4; half >= 1; half >>= 1) {
+            if (wave >= half && wave < 2 * half)
+#pragma unroll
+                for (int t = 0; t < CT; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) sR[wave - half][(t * 4 + r) * 64 + lane] = acc[t][r];
+            __syncthreads();
+            if (wave < half)
+#pragma unroll
+                for (int t = 0; t < CT; t++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[t][r] += sR[wave][(t * 4 + r) * 64 + lane];
+            __syncthreads();
+        }
+        if (wave == 0) {                                                // acc[t][r] = V[row i0 + (l >> 4) + 4 r][column j0 + t]
+#pragma unroll
+            for (int t = 0; t < CT; t++) {
+                double q = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) q += (i0 + lq + 4 * r < n) ? acc[t][r] * acc[t][r] : 0.0;
+                q += __shfl_xor(q, 16, 64);
+                q += __shfl_xor(q, 32, 64);
+                colacc[t] += q;
+            }
+        }
+    }
+    if (wave == 0 && lane < 16)
+#pragma unroll
+        for (int t = 0; t < CT; t++) part[(long long)blockIdx.x * ldp + j0 + t] = colacc[t];
 }
 
 __global__ void __launch_bounds__(256) sum_log_diag_kernel(int n, const double *a, long long lda, double *out) {
@@ -1674,18 +1853,65 @@ extern "C" int gpr_colsumsq(void *stream, int n, int ncols, const double *v, lon
     hipStream_t st = (hipStream_t)stream;
     if (ncols <= 0) return GPR_OK;
     GPR_REQUIRE(out && (n == 0 || v), "gpr_colsumsq: null pointer");
-    const int rows_per = 512;
+    const bool few = ncols <= GPR_FEW_COLS;
+    const int rows_per = few ? 64 : 512;
     const int nparts = (n + rows_per - 1) / rows_per > 0 ? (n + rows_per - 1) / rows_per : 1;
     void *part;
     int rc = gpr_dev_alloc(&part, (size_t)nparts * ncols * 8, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsumsq_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, v, ldv,
-                       (double *)part, rows_per);
+    if (few) hipLaunchKernelGGL((colred_few_kernel<64, true>), dim3((ncols + 63) / 64, nparts), dim3(256), 0, st, n, ncols, v, ldv,
+                                (const double *)nullptr, (double *)part, rows_per);
+    else hipLaunchKernelGGL(colsumsq_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, v, ldv,
+                            (double *)part, rows_per);
     LAUNCH_CHECK("colsumsq_partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
-                       (const double *)part, out);
+    if (few) hipLaunchKernelGGL(colsum_final_few_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, nparts, ncols, (const double *)part, (long long)ncols, out);
+    else hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
+                            (const double *)part, out);
     LAUNCH_CHECK("colsum_final");
     return gpr_dev_free(part, st);
+}
+
+// out[j] = |T B[:, j]|^2 with T lower triangular: gpr_trmm_lower followed by gpr_colsumsq, in one kernel when B has few
+// columns (a single structure's 1 + 3 n quantities) and T is large enough for the product to matter
+extern "C" int gpr_trmm_lower_sumsq(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
+                                    long long ldb, double *out) {
+    hipStream_t st = (hipStream_t)stream;
+    GPR_REQUIRE(n >= 0 && nrhs >= 0, "gpr_trmm_lower_sumsq: negative dimension");
+    if (nrhs == 0) return GPR_OK;
+    GPR_REQUIRE(out, "gpr_trmm_lower_sumsq: null output");
+    if (n == 0) { GPR_HIP_TRY(hipMemsetAsync(out, 0, (size_t)nrhs * 8, st)); return GPR_OK; }
+    GPR_REQUIRE(t && b && ldt >= n && ldb >= nrhs, "gpr_trmm_lower_sumsq: bad arguments");
+    if (nrhs > GPR_FEW_COLS || n < 64) {             // wide (or tiny): the tiled product, then the column reduction
+        void *v;
+        int rc = gpr_dev_alloc(&v, (size_t)n * nrhs * 8, st);
+        if (rc) return rc;
+        rc = gpr_trmm_lower(stream, n, nrhs, t, ldt, b, ldb, (double *)v, nrhs);
+        if (!rc) rc = gpr_colsumsq(stream, n, nrhs, (const double *)v, nrhs, out);
+        const int rf = gpr_dev_free(v, st);
+        return rc ? rc : rf;
+    }
+    const int nb = (n + 15) / 16, nwg = (nb + 1) / 2;
+    const int ct = nrhs <= 16 ? 1 : (nrhs <= 32 ? 2 : 4);             // columns per lane; 16 ct columns per blockIdx.y
+    const int ngy = (nrhs + 16 * ct - 1) / (16 * ct), ldp = ngy * 16 * ct;
+    void *buf;                                                         // [n x ldp] padded copy of B, then [nwg x ldp] partial sums
+    int rc = gpr_dev_alloc(&buf, ((size_t)n + nwg) * ldp * 8, st);
+    if (rc) return rc;
+    double *bp = (double *)buf, *part = bp + (size_t)n * ldp;
+    const int pid = gpr_prof_begin(st, GPR_PROF_TRMM);
+    const long long npad = (long long)n * ldp;
+    hipLaunchKernelGGL(pad_cols_kernel, dim3((unsigned)((npad + 255) / 256)), dim3(256), 0, st, n, nrhs, b, ldb, bp, ldp);
+    LAUNCH_CHECK("pad_cols");
+    const dim3 grid(nwg, ngy), block(512);
+    switch (ct) {
+        case 1: hipLaunchKernelGGL((trmm_sumsq_few_kernel<1>), grid, block, 0, st, n, t, ldt, (const double *)bp, ldp, part); break;
+        case 2: hipLaunchKernelGGL((trmm_sumsq_few_kernel<2>), grid, block, 0, st, n, t, ldt, (const double *)bp, ldp, part); break;
+        default: hipLaunchKernelGGL((trmm_sumsq_few_kernel<4>), grid, block, 0, st, n, t, ldt, (const double *)bp, ldp, part); break;
+    }
+    LAUNCH_CHECK("trmm_sumsq_few");
+    hipLaunchKernelGGL(colsum_final_few_kernel, dim3((nrhs + 63) / 64), dim3(256), 0, st, nwg, nrhs, (const double *)part, (long long)ldp, out);
+    LAUNCH_CHECK("colsum_final");
+    gpr_prof_end(st, pid);
+    return gpr_dev_free(buf, st);
 }
 
 extern "C" int gpr_sum_log_diag(void *stream, int n, const double *a, long long lda, double *out) {
@@ -1901,17 +2127,21 @@ extern "C" int gpr_gemv_t(void *stream, int n, int ncols, const double *a, long 
     hipStream_t st = (hipStream_t)stream;
     if (ncols <= 0) return GPR_OK;
     GPR_REQUIRE(out && (n == 0 || (a && x && lda >= ncols)), "gpr_gemv_t: bad arguments");
-    const int rows_per = 128;
+    const bool few = ncols <= GPR_FEW_COLS;
+    const int rows_per = few ? 64 : 128;
     const int nparts = n > 0 ? (n + rows_per - 1) / rows_per : 1;
     void *part;
     int rc = gpr_dev_alloc(&part, (size_t)nparts * ncols * 8, st);
     if (rc) return rc;
     const int pid = gpr_prof_begin(st, GPR_PROF_GEMV);
-    hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, a, lda, x,
-                       (double *)part, rows_per);
+    if (few) hipLaunchKernelGGL((colred_few_kernel<64, false>), dim3((ncols + 63) / 64, nparts), dim3(256), 0, st, n, ncols, a, lda, x,
+                                (double *)part, rows_per);
+    else hipLaunchKernelGGL(gemv_t_partial_kernel, dim3((ncols + 255) / 256, nparts), dim3(256), 0, st, n, ncols, a, lda, x,
+                            (double *)part, rows_per);
     LAUNCH_CHECK("gemv_t_partial");
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
-                       (const double *)part, out);
+    if (few) hipLaunchKernelGGL(colsum_final_few_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, nparts, ncols, (const double *)part, (long long)ncols, out);
+    else hipLaunchKernelGGL(colsum_final_kernel, dim3((ncols + 255) / 256), dim3(256), 0, st, nparts, ncols,
+                            (const double *)part, out);
     LAUNCH_CHECK("colsum_final");
     gpr_prof_end(st, pid);
     return gpr_dev_free(part, st);

@@ -91,8 +91,9 @@ kblock_kernel(kb_args P) {                                                      
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int jb = blockIdx.x % P.njb, ir = blockIdx.x / P.njb;
     // resident wave unit of this wavefront (consecutive packed points).  Diagonal launches are tiny, so there every
-    // block takes ONE unit and its wavefronts share the unit's points (wave w flushes points w, w + NW, ...: the MFMA
-    // passes are repeated per wave, but four times as many blocks exist and each bin still has a single writer)
+    // block takes ONE unit.  Usually they run in split form (the unit's groups dealt to the wavefronts, below); a unit of
+    // more than KB_SPLIT_PTS points keeps the older form: its wavefronts share the unit's points (wave w flushes points
+    // w, w + NW, ...: the MFMA passes are repeated per wave, but each bin still has a single writer)
     const bool one_unit = P.diag_only || P.split;
     const int ju = one_unit ? jb : jb * NW + wave;
     const bool active = ju < P.b_nwu;
@@ -354,6 +355,7 @@ kblock_kernel(kb_args P) {                                                      
                     // wavefront 0 adds them in wavefront order and issues the adds (the loops are uniform over the block)
                     for (int sp = blk_pt0; sp <= jlast; ++sp) {
                         if (P.symmetric && ch.pt > sp) continue;
+                        if (P.diag_only && ch.pt != sp) continue;             // a point against itself only
                         const bool here = mine && sp >= pt_lo && sp <= pt_hi;
                         double v = 0.0, v2 = 0.0;
                         if (here) {
@@ -371,6 +373,7 @@ kblock_kernel(kb_args P) {                                                      
                     if (wave == 0)
                         for (int sp = blk_pt0; sp <= jlast; ++sp) {
                             if (P.symmetric && ch.pt > sp) continue;
+                            if (P.diag_only && ch.pt != sp) continue;
                             double v = 0.0, v2 = 0.0;
                             if ((w_main || w_extra) && ridx < NOUT) {
 #pragma unroll
@@ -444,6 +447,10 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     GPR_REQUIRE(s1->ks == s2->ks, "block: sets packed with different plane widths");
     int nw = (s2->nwu >= 8 * 512) ? 8 : 4;
     if (c.diag_only || s1->ks >= GPR_KSTEPS_MAX) nw = 4;
+    // a diagonal launch is one block per unit; in split form the unit's groups are dealt to the wavefronts, so eight of them
+    // finish a full unit in one pass over the unit's own chunks
+    const bool diag_split = c.diag_only && s2->max_unit_pts <= KB_SPLIT_PTS && s2->maxgroups >= 2;
+    if (diag_split && s2->maxgroups > 4 && s1->ks < GPR_KSTEPS_MAX) nw = 8;
     // stream ranges (consecutive packed points, ~128 tiles each; finer for small sets) were laid out at pack time
     const int nranges = c.diag_only ? 1 : s1->nranges;
     // Split mode (see the top of the file): when the usual decomposition would not even give every CU a block and the units
@@ -451,8 +458,9 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     static const int split_env = getenv("GPR_KBLOCK_SPLIT") ? atoi(getenv("GPR_KBLOCK_SPLIT")) : -1;     // 0 / 1 force it (A/B, tests)
     bool split = !c.diag_only && s2->maxgroups >= 2 && s2->max_unit_pts <= KB_SPLIT_PTS &&
                  (long long)((s2->nwu + nw - 1) / nw) * nranges < gpr_cu_count();
+    if (diag_split) split = true;
     if (split_env == 0) split = false;
-    if (split_env == 1) split = !c.diag_only && s2->max_unit_pts <= KB_SPLIT_PTS;
+    if (split_env == 1) split = s2->max_unit_pts <= KB_SPLIT_PTS;
     const int njb = (c.diag_only || split) ? s2->nwu : (s2->nwu + nw - 1) / nw;
 
     const int nir = nranges;

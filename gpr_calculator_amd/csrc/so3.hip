@@ -1351,7 +1351,7 @@ static std::atomic<int> g_so3_variant{0};
 extern "C" int gpr_so3_set_variant(int generic_only) { g_so3_variant.store(generic_only ? 1 : 0); return GPR_OK; }
 // smallest number of centres for which the radial channels are formed by the streaming pre-pass (tests / A-B: 0 always,
 // a huge number never)
-static std::atomic<int> g_so3_prepass_min{512};
+static std::atomic<int> g_so3_prepass_min{getenv("GPR_SO3_PREPASS_MIN") ? atoi(getenv("GPR_SO3_PREPASS_MIN")) : 512};    // centres from which the radial pre-pass pays (A/B: env or gpr_so3_set_prepass_min)
 extern "C" int gpr_so3_set_prepass_min(int ncentres) { g_so3_prepass_min.store(ncentres < 0 ? 0 : ncentres); return GPR_OK; }
 
 extern "C" long long gpr_so3_table_size(int nmax, int lmax, int nseg, int ncheb) {

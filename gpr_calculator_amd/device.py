@@ -377,6 +377,15 @@ def trmm_lower(t, b, out=None):
     return out
 
 
+def trmm_lower_sumsq(t, b):
+    """column sums of squares of t @ b, t lower triangular [n, n], b [n, nrhs]: |L^-1 k*|^2 per predicted quantity"""
+    n, nrhs = b.shape
+    out = torch.empty(nrhs, dtype=F64, device=b.device)
+    check(_lib.lib().gpr_trmm_lower_sumsq(stream_ptr(), n, nrhs, ptr(t), max(int(t.stride(0)), n), ptr(b),
+                                          max(int(b.stride(0)), nrhs), ptr(out)), "gpr_trmm_lower_sumsq")
+    return out
+
+
 def add_diag_(a, n_first, add_first, add_rest):
     n = a.shape[0]
     check(_lib.lib().gpr_add_diag(stream_ptr(), n, ptr(a), max(int(a.stride(0)), n), int(n_first), float(add_first),

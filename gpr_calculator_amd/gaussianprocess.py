@@ -643,8 +643,7 @@ class GP():
             if Kt is None:
                 Kt = self.kernel.k_total_dev(X, train_x, transpose=True)
             Ktp = Kt if self._perm_dev is None else Kt.index_select(0, self._perm_dev)
-            V = dev.trmm_lower(self._Linv(), Ktp)                                 # V = L^-1 K_trans^T
-            var = var - dev.colsumsq(V)
+            var = var - dev.trmm_lower_sumsq(self._Linv(), Ktp)                   # |L^-1 K_trans^T|^2 per column
         var = torch.clamp_min(var, 0.0)
         return (mean, var, None) if want_flat else (mean, var)
 

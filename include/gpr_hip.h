@@ -431,6 +431,13 @@ int gpr_trsv_debug_max_polls(int polls);
  * 128-column blocks to the right of a row block's diagonal block are skipped (never read) */
 int gpr_trmm_lower(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
                    long long ldb, double *c, long long ldc);
+
+/* out[j] = | T B[:, j] |^2, T lower triangular [n x n], B [n x nrhs] row-major: gpr_trmm_lower followed by gpr_colsumsq.
+ * With nrhs <= 256 (the 1 + 3 n quantities of one structure) a single kernel streams T once and never writes the product;
+ * wider B goes through the two calls.  This is the subtracted term of the predictive variance, |L^-1 k*|^2
+ * (reference gaussianprocess.py:903-907 evaluates k*^T K^-1 k*). */
+int gpr_trmm_lower_sumsq(void *stream, int n, int nrhs, const double *t, long long ldt, const double *b,
+                         long long ldb, double *out);
 /* C[m,n] = alpha * op(A) op(B) + beta * C, row-major, op = transpose if the flag is set */
 int gpr_gemm(void *stream, int transa, int transb, int m, int n, int k, double alpha,
              const double *a, long long lda, const double *b, long long ldb, double beta,

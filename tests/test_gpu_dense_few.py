@@ -1,0 +1,56 @@
+"""Few-column forms of the dense reductions around a single structure's prediction (1 + 3 n quantities): the fused
+|L^-1 k*|^2 kernel (gpr_trmm_lower_sumsq), gpr_gemv_t and gpr_colsumsq -- against torch FP64 products of the same
+operands, tolerance 1e-12 relative (sums of n products in a different order), and against the wide two-call path."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n,cols", [(64, 1), (100, 5), (777, 13), (1516, 61), (2050, 17), (2050, 33), (2049, 64), (1000, 97), (900, 256)])
+def test_fused_variance_term_matches_the_product(n, cols):
+    from gpr_calculator_amd import device as dev
+    torch.manual_seed(n + cols)
+    d = dev.device()
+    T = torch.tril(torch.randn(n, n, dtype=torch.float64, device=d)) / n ** 0.5
+    T += torch.triu(torch.full((n, n), float("nan"), dtype=torch.float64, device=d), 1)        # the upper triangle must never be read
+    B = torch.randn(n, cols, dtype=torch.float64, device=d)
+    ref = ((torch.tril(T) @ B) ** 2).sum(0)
+    got = dev.trmm_lower_sumsq(T, B)
+    assert torch.isfinite(got).all()
+    assert float(((got - ref).abs() / ref).max()) < 1e-12
+    # a strided B (a column block of a wider matrix) and a strided T (leading dimension > n)
+    wide = torch.randn(n, cols + 7, dtype=torch.float64, device=d)
+    Bv = wide[:, 3:3 + cols]
+    Tbig = torch.zeros(n, n + 5, dtype=torch.float64, device=d)
+    Tbig[:, :n] = torch.tril(T)
+    got2 = dev.trmm_lower_sumsq(Tbig[:, :n], Bv)
+    ref2 = ((torch.tril(T) @ Bv) ** 2).sum(0)
+    assert float(((got2 - ref2).abs() / ref2).max()) < 1e-12
+
+
+def test_small_and_wide_operands_take_the_two_call_path():
+    from gpr_calculator_amd import device as dev
+    torch.manual_seed(5)
+    d = dev.device()
+    for n, cols in ((20, 4), (63, 61), (500, 300)):
+        T = torch.tril(torch.randn(n, n, dtype=torch.float64, device=d))
+        B = torch.randn(n, cols, dtype=torch.float64, device=d)
+        ref = ((T @ B) ** 2).sum(0)
+        got = dev.trmm_lower_sumsq(T, B)
+        assert float(((got - ref).abs() / ref).max()) < 1e-12
+
+
+@pytest.mark.parametrize("n,cols", [(1, 1), (37, 3), (700, 61), (6063, 61), (1200, 256), (1200, 257), (333, 1000)])
+def test_column_reductions_few_and_wide(n, cols):
+    from gpr_calculator_amd import device as dev
+    torch.manual_seed(n * 7 + cols)
+    d = dev.device()
+    A = torch.randn(n, cols, dtype=torch.float64, device=d)
+    x = torch.randn(n, dtype=torch.float64, device=d)
+    gv, ref = dev.gemv_t(A, x), A.T @ x
+    assert float((gv - ref).abs().max()) <= 1e-12 * max(1.0, float(ref.abs().max())) * n ** 0.5
+    cs, ref2 = dev.colsumsq(A), (A * A).sum(0)
+    assert float(((cs - ref2).abs() / ref2).max()) < 1e-12
+    # deterministic: the same call twice gives the same bits (fixed summation order)
+    assert torch.equal(dev.gemv_t(A, x), gv) and torch.equal(dev.colsumsq(A), cs)
