@@ -227,7 +227,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pair-route", action="store_true", help="skip the extra pair-kernel measurement of the Dot run")
     ap.add_argument("--mode", default="predict", choices=["predict", "fit"])
-    ap.add_argument("--depth", type=int, default=2, help="batches in flight in the timed region (1 = the synchronous call)")
+    # four chains side by side (each slot stream has a hardware queue of its own up to four): 0.1235 ms per step sustained against
+    # 0.1405 with two; between two synchronisations only 20 steps apart (what the driver times) the fill and drain of the deeper
+    # pipeline eat most of that: 0.150 against 0.156 (profiles/r04_depth_sweep.log)
+    ap.add_argument("--depth", type=int, default=4, help="batches in flight in the timed region (1 = the synchronous call)")
     ap.add_argument("--sustain", type=float, default=2.0, help="seconds of the untimed sustained leg after the timed region")
     ap.add_argument("--dry-run", action="store_true", help="ranks only rendezvous and report (no GPU work): checks the launch path")
     args = ap.parse_args()

@@ -155,10 +155,29 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     d4 acc[4][4];
+    // alpha = +-1 with beta != 0 (the trailing update of the factorisation, C -= A B^T): the accumulators START from
+    // (beta / alpha) C, requested before the first operand tile, so the tile's read of C is in flight during the k loop's
+    // prologue and the epilogue is a plain store -- instead of a read-modify-write whose read nothing hides (at k = 256 that
+    // read was a quarter of the kernel: 0.514 ms with beta = 1 against 0.387 ms with beta = 0 at m = n = 5807)
+    const bool init_c = beta != 0.0 && (alpha == 1.0 || alpha == -1.0);
+    if (init_c) {
+        const double sc = alpha * beta;
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+        for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gm = bm0 + wm + i * 16 + (lane >> 4) + 4 * r;
+                    const int gn = bn0 + wn + j * 16 + (lane & 15);
+                    acc[i][j][r] = (gm < m && gn < n) ? sc * C[(long long)gm * ldc + gn] : 0.0;
+                }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    }
 
     double ra[8], rb[8];
     auto load_tile = [&](int k0) {
@@ -225,7 +244,7 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
                 if (gm < m && gn < n) {
                     double *c = C + (long long)gm * ldc + gn;
                     const double v = alpha * acc[i][j][r];
-                    *c = (beta == 0.0) ? v : v + beta * *c;
+                    *c = (beta == 0.0 || init_c) ? v : v + beta * *c;
                 }
             }
 }
@@ -441,10 +460,10 @@ trmm_sumsq_few_kernel(int n, const double *__restrict__ T, long long ldt, const 
 #pragma unroll
         for (int u = 0; u < DA; u++) load_a(min(wave + u * NWV, last), aq[u]);
         load_b(min(wave, last), bq[0]);
-        for (int run = wave; run < nfull;) {
+        for (int run = wave;;) {                                          // (exits by goto: see ws_tail_rows_kernel)
 #pragma unroll
             for (int u = 0; u < DA; u++) {
-                if (run >= nfull) break;
+                if (run >= nfull) goto runs_done;
                 load_b(min(run + NWV, last), bq[(u + 1) & 1]);
                 double a[4];
 #pragma unroll
@@ -454,6 +473,7 @@ trmm_sumsq_few_kernel(int n, const double *__restrict__ T, long long ldt, const 
                 run += NWV;
             }
         }
+    runs_done:
         if (wave == (b & (NWV - 1))) {                                  // the diagonal run: k <= i only, and k < n
             double a[4], bb[4][CT];
             const int k = b * RUN + 4 * lq;
@@ -1014,28 +1034,35 @@ __global__ void __launch_bounds__(64 * TRW_NW) ws_tail_rows_kernel(int m, int n,
         const int col = 16 * j + c;
         const int nts = min(2 * (j + 1), ntmax);                     // steps of 8 columns: k < 16 (j + 1)
         const bool cok = col < n;
-        const double *bp = Ci + (long long)min(col, n - 1) * ldc + 2 * q;
-        auto loadb = [&](int t) -> d2v {
-            // columns beyond the row's end are zeros by predicate (the pair never straddles n: n is even)
-            return (cok && 8 * t + 2 * q < n) ? *(const d2v *)(bp + 8 * t) : d2v{0.0, 0.0};
-        };
+        const double *bp = Ci + (long long)min(col, n - 1) * ldc;
+        // Every load is unconditional -- the address is clamped into the row, what lies beyond the row's end (or belongs to a
+        // column past n) becomes zero by a select on the loaded value WHEN IT IS USED, and the prefetches past the last step repeat it -- so
+        // the loop has no divergent branch and no load under a branch: the compiler then counts the loads in flight
+        // (s_waitcnt vmcnt(3) in the steady state) instead of draining them at every join, which is what made the ring
+        // four deep in name only.  (The pair never straddles n: n is even.)
+        auto loadb = [&](int t) -> d2v { return *(const d2v *)(bp + min(8 * t + 2 * q, n - 2)); };     // raw: the select waits until use
         d2v ring[TRW_D];
 #pragma unroll
-        for (int u = 0; u < TRW_D; u++) ring[u] = u < nts ? loadb(u) : d2v{0.0, 0.0};
+        for (int u = 0; u < TRW_D; u++) {
+            ring[u] = loadb(min(u, nts - 1));
+            __builtin_amdgcn_sched_barrier(0);                       // issued in ring order: the loop waits for the OLDEST load only
+        }
         d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        // The steps go in groups of TRW_D with no exit inside a group (a step beyond nts multiplies by a zero B: the A read
+        // stays inside the block or its slack): an exit between two steps is a place below which the compiler sinks the
+        // refills -- they are not needed on the way out -- and the ring is then refilled in a burst at the end of the group.
         for (int t0 = 0; t0 < nts; t0 += TRW_D) {
 #pragma unroll
             for (int u = 0; u < TRW_D; u++) {
                 const int t = t0 + u;
-                if (t < nts) {
-                    const d2v b = ring[u];
-                    if (t + TRW_D < nts) ring[u] = loadb(t + TRW_D);
-                    const d2v a0 = *(const d2v *)(a0p + 8 * t), a1 = *(const d2v *)(a1p + 8 * t);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.y, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.y, acc1, 0, 0, 0);
-                }
+                const bool ok = cok && t < nts && 8 * t + 2 * q < n;
+                const d2v b = d2v{ok ? ring[u].x : 0.0, ok ? ring[u].y : 0.0};
+                ring[u] = loadb(min(t + TRW_D, nts - 1));
+                const d2v a0 = *(const d2v *)(a0p + 8 * t), a1 = *(const d2v *)(a1p + 8 * t);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.x, b.x, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.x, b.x, acc1, 0, 0, 0);
+                acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0.y, b.y, acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1.y, b.y, acc1, 0, 0, 0);
             }
         }
 #pragma unroll
@@ -1046,8 +1073,10 @@ __global__ void __launch_bounds__(64 * TRW_NW) ws_tail_rows_kernel(int m, int n,
     auto is_early = [&](int j) { return early && 16 * (j + 1) <= 256; };
     for (int pr = wave; pr < npair; pr += TRW_NW)
         if (is_early(pr)) tile(pr);
-    // ... then, once the whole block is there (every wavefront passes here exactly once), all the others
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ... then, once the whole block is there (every wavefront passes here exactly once), all the others.  (The wait as a
+    // builtin, not as inline assembly: the compiler has to SEE that no LDS DMA is pending any more -- otherwise it guards
+    // every LDS read of the loops below with a full vmcnt(0), which also drains the ring of C^-1 loads.)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                              // vmcnt(0)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     for (int pr = wave; pr < npair; pr += TRW_NW) {
