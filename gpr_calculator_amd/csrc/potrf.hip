@@ -667,11 +667,14 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         GPR_HIP_TRY(wait(g_la.mid, e0)); GPR_HIP_TRY(wait(g_la.side, e0));
     }
     int step = 0;
-    bool deferred = false;                                   // panel K - 1 has not been applied beyond column block K + 1 yet
+    int deferred = 0;                                        // panels K - deferred .. K - 1 have not been applied beyond column block K + 1 yet
     // pairing pays where the bulk dominates (N = 24 250: 148 -> 127 ms); at N = 6063 the chain of diagonal blocks does, and
     // a bulk launch twice as long beside it only lengthens the steps it overlaps (4.2 -> 4.4 ms): pairs from 8192 rows on
     static const bool pair_env = !getenv("GPR_POTRF_NO_PAIR");
     const bool pair_bulk = pair_env && n >= 8192;
+    // ... and FOUR panels at a time (k = 1024: 49.5 TF against 43 at k = 512, tools/gemm_k.py) where the bulk is nearly all there is
+    static const int group_env = getenv("GPR_POTRF_GROUP") ? atoi(getenv("GPR_POTRF_GROUP")) : 0;
+    const int group = !pair_bulk ? 1 : (group_env > 0 ? group_env : (n >= 16384 ? 4 : 2));
     static const int reserve_cus = getenv("GPR_POTRF_RESERVE_CUS") ? atoi(getenv("GPR_POTRF_RESERVE_CUS")) : 24;
     for (int K0 = 0; K0 < n && rc == GPR_OK; K0 += DB, step++) {
         const int KB = (n - K0 < DB) ? n - K0 : DB;
@@ -728,13 +731,22 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
         // blocks have received panel K (K + 1 on mid, K + 2 here); the odd step that follows brings block K + 2 up to date
         // with both panels and then updates everything beyond with k = 512 -- the tiled GEMM runs at more than twice the
         // rate there than at k = 256, and it has two steps of the chain to hide behind instead of one.
-        if (deferred) launch_narrow(g_la.side, Rrest, KB2, at(c2, K0 - DB), at(c2, K0 - DB), at(c2, c2), lda, 1);   // U_{K-1}(K + 2)
-        launch_narrow(g_la.side, Rrest, KB2, at(c2, K0), at(c2, K0), at(c2, c2), lda, 1);     // U_K(K + 2)
+        if (pair_bulk && Rrest >= 12288) {
+            // long panels: column block K + 2 takes its pending panels and panel K in ONE tiled product (k up to `group` x 256;
+            // the 32 x 32-tile kernel does 22 TF on these shapes -- 30 of 119 ms at N = 24 250 -- the 128 x 128 one 35-49 once the
+            // panel has enough 128-row tiles to fill the chip twice over; below that the small tiles win)
+            rc = gpr_gemm_internal(g_la.side, 0, 1, Rrest, KB2, KB + deferred * DB, -1.0, at(c2, K0 - deferred * DB), lda,
+                                   at(c2, K0 - deferred * DB), lda, 1.0, at(c2, c2), lda, 1);
+        } else {
+            for (int b = deferred; b >= 1; b--)                                                // U_{K-b}(K + 2), oldest first
+                launch_narrow(g_la.side, Rrest, KB2, at(c2, K0 - b * DB), at(c2, K0 - b * DB), at(c2, c2), lda, 1);
+            launch_narrow(g_la.side, Rrest, KB2, at(c2, K0), at(c2, K0), at(c2, c2), lda, 1); // U_K(K + 2)
+        }
         bulk_last = bulk_first = mark(g_la.side);
         if (c3 < n) {                                                                          // U(K + 3 ...)
-            if (!deferred && pair_bulk && KB == DB) deferred = true;                           // wait for the next panel
+            if (deferred + 1 < group && KB == DB) deferred++;                                  // wait for the next panel(s)
             else {
-                const int k0 = deferred ? K0 - DB : K0, kk = deferred ? KB + DB : KB;
+                const int k0 = K0 - deferred * DB, kk = KB + deferred * DB;
                 // where the chain of diagonal blocks decides the time (not pair_bulk) the bulk runs as a persistent kernel
                 // on all but a few CUs, which stay free for the chain; elsewhere the plain tiled GEMM on every CU
                 if (reserve_cus > 0 && !pair_bulk && kk % 16 == 0 && n - c3 >= 1024)
@@ -742,9 +754,9 @@ extern "C" int gpr_potrf_lower_dinv(void *stream, int n, double *a, long long ld
                 else
                     rc = gpr_gemm_internal(g_la.side, 0, 1, n - c3, n - c3, kk, -1.0, at(c3, k0), lda, at(c3, k0), lda, 1.0, at(c3, c3), lda, 1);
                 bulk_last = mark(g_la.side);
-                deferred = false;
+                deferred = 0;
             }
-        } else deferred = false;
+        } else deferred = 0;
     }
     if (la) { GPR_HIP_TRY(wait(st, mid_last)); GPR_HIP_TRY(wait(st, bulk_last)); }
     hipLaunchKernelGGL(tri_inv64_kernel, dim3((n + 63) / 64), dim3(64), 0, st, a, lda, n, dinv);
