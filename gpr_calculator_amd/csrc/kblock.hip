@@ -44,6 +44,7 @@ struct kb_args {
     int shard_mod, shard_rem;
     int symmetric, diag_only, eps_mode, norm1, norm2;
     int split;              // small launches: one wave unit per block, its groups dealt to the block's wavefronts (see below)
+    int xcd;                // stream ranges dealt to the XCDs (block index -> (jb, ir), see the kernel)
     double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
     double scale, dl_scale;
     double *out; long long s_i, s_j, s_a, s_b;
@@ -89,7 +90,18 @@ kblock_kernel(kb_args P) {                                                      
     __shared__ double sNorm[2][GPR_CHUNK_TILES * 16];
 
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int jb = blockIdx.x % P.njb, ir = blockIdx.x / P.njb;
+    // block -> (resident block jb, stream range ir).  Workgroups are dealt to the eight XCDs in turn, and every XCD has an L2
+    // of its own: with `xcd` set the ranges are dealt to the XCDs (range ir lives on XCD ir % 8) and an XCD walks its ranges
+    // one after the other, all resident blocks of a range side by side -- the range's stream tiles (re-read by every group
+    // pass of every block) then stay in ONE L2 instead of being pulled into all eight and pushed out again by the ranges
+    // the other blocks in flight are working on.
+    int jb, ir;
+    if (P.xcd) {
+        const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
+        jb = sq % P.njb;
+        ir = (sq / P.njb) * 8 + x;
+        if (ir >= P.nir) return;
+    } else { jb = blockIdx.x % P.njb; ir = blockIdx.x / P.njb; }
     // resident wave unit of this wavefront (consecutive packed points).  Diagonal launches are tiny, so there every
     // block takes ONE unit.  Usually they run in split form (the unit's groups dealt to the wavefronts, below); a unit of
     // more than KB_SPLIT_PTS points keeps the older form: its wavefronts share the unit's points (wave w flushes points
@@ -487,7 +499,10 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
 
     const int prof_id = gpr_prof_begin(st, c.diag_only ? GPR_PROF_DIAG : c.mode);
     const bool z2 = (c.zeta == 2.0);
-    const int nblocks = c.diag_only ? njb : njb * nir;
+    static const int xcd_env = getenv("GPR_KBLOCK_XCD") ? atoi(getenv("GPR_KBLOCK_XCD")) : -1;          // 0 / 1 force it (A/B)
+    const bool xcd = !c.diag_only && (xcd_env >= 0 ? xcd_env != 0 : nir >= 16);
+    a.xcd = xcd ? 1 : 0;
+    const int nblocks = c.diag_only ? njb : (xcd ? 8 * ((nir + 7) / 8) * njb : njb * nir);
     const bool grad = c.grad != 0;
     switch (c.mode * 2 + c.kind) {
         case GPR_MODE_FF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_FF, GPR_KERNEL_RBF>(st, z2, grad, nw, s1->ks, nblocks, a); break;
