@@ -45,6 +45,7 @@ struct kb_args {
     int symmetric, diag_only, eps_mode, norm1, norm2;
     int split;              // small launches: one wave unit per block, its groups dealt to the block's wavefronts (see below)
     int xcd;                // stream ranges dealt to the XCDs (block index -> (jb, ir), see the kernel)
+    int merge, npacked;     // packed stream ranges per launch range; packed ranges in all
     double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
     double scale, dl_scale;
     double *out; long long s_i, s_j, s_a, s_b;
@@ -95,13 +96,23 @@ kblock_kernel(kb_args P) {                                                      
     // one after the other, all resident blocks of a range side by side -- the range's stream tiles (re-read by every group
     // pass of every block) then stay in ONE L2 instead of being pulled into all eight and pushed out again by the ranges
     // the other blocks in flight are working on.
+    // Symmetric launches skip what lies below the diagonal, so a range's work shrinks with its index: there the ranges are dealt
+    // back and forth (0 .. 7, 7 .. 0, ...), which gives every XCD the same share.  `merge` packed ranges make one launch range
+    // (a block reloads its resident operands once per launch range: longer ranges, fewer reloads; the symmetric launches
+    // keep the short ones, whose triangular skipping is finer).
     int jb, ir;
-    if (P.xcd) {
-        const int x = blockIdx.x & 7, sq = blockIdx.x >> 3;
+    // The ranges left over after the last full round of eight are dealt block by block again (an XCD without a range would idle:
+    // workgroups are dispatched in order).
+    const int nfull = (P.nir >> 3) * 8 * P.njb;                // blocks of the full rounds
+    if (P.xcd && (int)blockIdx.x < nfull) {
+        const int x = blockIdx.x & 7, sq = blockIdx.x >> 3, rnd = sq / P.njb;
         jb = sq % P.njb;
-        ir = (sq / P.njb) * 8 + x;
-        if (ir >= P.nir) return;
-    } else { jb = blockIdx.x % P.njb; ir = blockIdx.x / P.njb; }
+        ir = rnd * 8 + ((P.symmetric && (rnd & 1)) ? 7 - x : x);
+    } else {
+        const int t = P.xcd ? (int)blockIdx.x - nfull : (int)blockIdx.x, r0_ = P.xcd ? (P.nir >> 3) * 8 : 0;
+        jb = t % P.njb; ir = r0_ + t / P.njb;
+    }
+    const int ir0 = ir * P.merge, ir1 = min(ir0 + P.merge, P.npacked);
     // resident wave unit of this wavefront (consecutive packed points).  Diagonal launches are tiny, so there every
     // block takes ONE unit.  Usually they run in split form (the unit's groups dealt to the wavefronts, below); a unit of
     // more than KB_SPLIT_PTS points keeps the older form: its wavefronts share the unit's points (wave w flushes points
@@ -122,9 +133,9 @@ kblock_kernel(kb_args P) {                                                      
         c0 = P.a_pt_chunk0[blk_pt0];
         c1 = P.a_pt_chunk0[blk_pt1];
     } else {
-        if (P.symmetric && P.ir_pt0[ir] > jlast) return;   // range entirely below the diagonal
-        c0 = P.ir_chunk0[ir];
-        c1 = P.ir_chunk0[ir + 1];
+        if (P.symmetric && P.ir_pt0[ir0] > jlast) return;  // range entirely below the diagonal
+        c0 = P.ir_chunk0[ir0];
+        c1 = P.ir_chunk0[ir1];
     }
     if (c0 >= c1) return;
 
@@ -475,7 +486,12 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     if (split_env == 1) split = s2->max_unit_pts <= KB_SPLIT_PTS;
     const int njb = (c.diag_only || split) ? s2->nwu : (s2->nwu + nw - 1) / nw;
 
-    const int nir = nranges;
+    // GPR_KBLOCK_MERGE=2: predict-shaped launches take the packed ranges two at a time (see the kernel) -- the resident reloads,
+    // most of what is left of the fetch traffic, halve (3.35 -> 2.17 GB per launch at the cfg3 shape) but the tasks are twice
+    // as long and the last round of workgroups leaves more of the chip idle: +1.2 % on the RBF bench, so it is not the default
+    static const int merge_env = getenv("GPR_KBLOCK_MERGE") ? atoi(getenv("GPR_KBLOCK_MERGE")) : 0;
+    const int merge = (c.diag_only || c.symmetric || merge_env <= 1) ? 1 : merge_env;
+    const int nir = (nranges + merge - 1) / merge;
 
     kb_args a;
     a.a_ops = s1->ops; a.a_ele = s1->ele; a.a_norm = s1->norms; a.a_chunks = s1->chunks;
@@ -501,8 +517,8 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     const bool z2 = (c.zeta == 2.0);
     static const int xcd_env = getenv("GPR_KBLOCK_XCD") ? atoi(getenv("GPR_KBLOCK_XCD")) : -1;          // 0 / 1 force it (A/B)
     const bool xcd = !c.diag_only && (xcd_env >= 0 ? xcd_env != 0 : nir >= 16);
-    a.xcd = xcd ? 1 : 0;
-    const int nblocks = c.diag_only ? njb : (xcd ? 8 * ((nir + 7) / 8) * njb : njb * nir);
+    a.xcd = xcd ? 1 : 0; a.merge = merge; a.npacked = nranges;
+    const int nblocks = c.diag_only ? njb : njb * nir;
     const bool grad = c.grad != 0;
     switch (c.mode * 2 + c.kind) {
         case GPR_MODE_FF * 2 + GPR_KERNEL_RBF: launch_zg<GPR_MODE_FF, GPR_KERNEL_RBF>(st, z2, grad, nw, s1->ks, nblocks, a); break;

@@ -397,14 +397,12 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     int rc = GPR_OK;
     auto fail = [&](int code) { gpr_set_destroy(s, stream); return code; };
     if (role == GPR_ROLE_STREAM) {
-        // launch ranges: consecutive packed points, up to 256 tiles each (one task = range x resident block; a block reloads its
-        // resident operands once per range, so longer ranges mean fewer reloads -- and with the ranges dealt to the XCDs
-        // (kblock.hip) a range of 1 MB still sits in the one L2 that works on it); small
-        // sets are cut finer (down to 8 tiles) so that a launch against them still has a few dozen ranges to spread
-        // over the CUs -- the resident side contributes only npts / (points per wave unit) / NW blocks
+        // launch ranges: consecutive packed points, about 128 tiles each (one task = range x resident block; a launch may take
+        // them two at a time, kblock.hip); small sets are cut finer (down to 8 tiles) so that a launch against them still has
+        // a few dozen ranges to spread over the CUs -- the resident side contributes only npts / (points per wave unit) / NW blocks
         std::vector<int> &irc = s->hk_irc, &irp = s->hk_irp;
         irc.assign(1, 0); irp.assign(1, 0);
-        static const int range_cap = getenv("GPR_RANGE_TILES") ? atoi(getenv("GPR_RANGE_TILES")) : 256;    // (A/B: tools/kff_traffic.sh)
+        static const int range_cap = getenv("GPR_RANGE_TILES") ? atoi(getenv("GPR_RANGE_TILES")) : 128;    // (A/B: tools/kff_traffic.sh)
         const int range_tiles = std::max(8, std::min(range_cap, unit / 64));
         int tiles = 0;
         for (int p = 0; p < npts; p++) {
