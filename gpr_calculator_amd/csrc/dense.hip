@@ -2014,7 +2014,9 @@ static int *tail_stream_counters(hipStream_t st) {
     int *&slot = counters[{dev, st}];
     if (!slot) {
         const size_t bytes = (WT_FEW_MAX_RB + 2) * sizeof(int);
-        if (hipMalloc((void **)&slot, bytes) != hipSuccess || hipMemset(slot, 0, bytes) != hipSuccess) {
+        // cleared on the stream that uses them (a plain hipMemset goes to the null stream, which a non-blocking stream does not
+        // wait for: the first launch could count arrivals on top of whatever the memory held, or be cleared half way)
+        if (hipMalloc((void **)&slot, bytes) != hipSuccess || hipMemsetAsync(slot, 0, bytes, st) != hipSuccess) {
             gpr_set_error("gpr_ws_tail: arrival counters could not be allocated");
             slot = nullptr;
         }

@@ -402,14 +402,20 @@ __global__ void __launch_bounds__(256) nbr_force_rows_kernel(frow_args f) {
 //   geometry of the structure from the page-locked blob into LDS (and on to the device copy later kernels read),
 //   count per centre (one wavefront per centre, the loops of nbr_centre_kernel), exclusive scan inside the workgroup,
 //   the structure's offsets among all structures by LOOKING BACK: every workgroup publishes its totals (tagged with the
-//   call's epoch, so that nobody has to clear the slots -- which are memory of their own and never hold anything else) right after its count, and sums the totals of its predecessors
-//   and of everybody else (the grand totals decide, identically everywhere, whether the guessed capacities hold); all
-//   workgroups reach that point at about the same time, the wait is bounded, and giving up fails loudly,
+//   call's epoch, so that nobody has to clear the slots -- which are memory of their own and never hold anything else) right
+//   after its count, and sums the totals of its PREDECESSORS -- only of them: workgroups are dispatched in index order, so
+//   whoever a workgroup waits for is resident or done, and the launch makes progress however few of its workgroups the
+//   device holds at a time (the first form also read the totals of its successors, to decide everywhere alike whether the
+//   guessed capacities hold; with four batches in flight two such launches, each partly resident, could then hold each
+//   other's CUs until the polls ran out -- seen once under a profiler as a 1.4 s kernel),
 //   fill (pairs ordered by (j, image), rows by j: bit-identical to the other builders), and -- the neighbour relation
 //   being exactly symmetric -- the force-point regrouping by table look-up: row k of force point a is the seq row
 //   (i, a) of a's k-th neighbour i, whose position among i's rows centre i noted in an n x n table in LDS while counting.
-// Capacity overflow: every workgroup sees the same grand totals; if they exceed the guess nobody fills anything, every
-// offset is zero and the last structure raises the flag (the caller repeats the build with exact sizes).
+// Capacity overflow: a structure whose running totals (its predecessors' and its own) exceed the guess fills nothing and
+// closes every one of its centres at the totals of the last structure that fitted -- as do all structures after it -- so
+// the tables describe a prefix of the batch and empty ranges behind it, whatever is queued behind this kernel stays
+// inside the arrays, and the last structure (which has seen every total) raises the flag and reports the true sizes:
+// the caller discards the call and repeats the build with exact sizes.
 struct nbrf_args {
     const char *blob_host;           // device alias of the page-locked blob [wpos | shifts | sinfo | numbers | sid | atom0]
     char *blob_dev;                  // its device copy
@@ -419,6 +425,8 @@ struct nbrf_args {
     double rc2;
     int *cr0, *cp0, *info;           // [natoms + 1] each; info = [missing, overflow, pairs, rows]
     unsigned long long *agg;         // [nstruct][3]: rows | pairs | missing, each tagged (epoch << 32) | value
+    unsigned *ticket;                // counts the workgroups of every launch on this stream; this launch's start at ticket_base
+    unsigned ticket_base;
     double *vec, *w;
     int *rp0, *self_row, *seq;
     int *row_index, *x_index;        // force-point regrouping (may be NULL)
@@ -444,7 +452,18 @@ __device__ __forceinline__ bool nbrf_wait(const unsigned long long *p, unsigned 
 
 __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a) {
     extern __shared__ __attribute__((aligned(16))) double nf_smem[];
-    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // The structure a workgroup takes is the order in which it STARTED (a ticket), not its index: whoever it will wait for --
+    // the holders of the earlier tickets -- is then resident or done by construction, wherever the dispatcher put the
+    // workgroups and whatever else fills the device (an index only promises that per XCD).
+    __shared__ int s_ticket;
+    if (tid == 0) s_ticket = (int)(atomicAdd(a.ticket, 1u) - a.ticket_base);
+    __syncthreads();
+    const int s = s_ticket;
+    if ((unsigned)s >= (unsigned)a.nstruct) {                 // the counter and the host's count disagree: say so instead of reading past the arguments
+        if (tid == 0) { a.info[0] = 0x3ffffff0; a.info[1] = 1; a.info[2] = s; a.info[3] = (int)a.ticket_base; }
+        return;
+    }
     const nbr_sinfo si = a.si[s];
     const int n = si.n, nimg = si.nimg;
     double *pos = nf_smem;                                   // [3 nmax]
@@ -530,38 +549,47 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
             __hip_atomic_store(&a.agg[3 * s], tag | (unsigned)runR, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&a.agg[3 * s + 1], tag | (unsigned)runP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        // totals of EVERY structure: those before this one give its offsets, all of them together decide -- the same way
-        // in every workgroup -- whether the guessed capacities hold.  (Workgroups of one launch that are not resident yet
-        // are dispatched as soon as a CU has room, whatever the resident ones do: the wait ends.)
-        int baseR = 0, baseP = 0, allR = 0, allP = 0, ok = 1;
-        for (int b = 0; b < a.nstruct; b += 64) {
+        // running totals over the structures 0 .. s (the predecessors' from their slots, this one's own): the exclusive value at s
+        // is this structure's offset; the first structure whose inclusive totals exceed a capacity ends the part of the batch
+        // that fits, at the exclusive totals there
+        int baseR = 0, baseP = 0, validR = 0, validP = 0, over = 0, ok = 1, carryR = 0, carryP = 0;
+        for (int b = 0; b <= s && !over; b += 64) {
             const int q = b + lane;
             unsigned vr = 0, vp = 0;
-            if (q < a.nstruct) { if (!nbrf_wait(&a.agg[3 * q], a.epoch, vr)) ok = 0; if (!nbrf_wait(&a.agg[3 * q + 1], a.epoch, vp)) ok = 0; }
-            allR += (int)vr; allP += (int)vp;
-            if (q < s) { baseR += (int)vr; baseP += (int)vp; }
+            if (q < s) { if (!nbrf_wait(&a.agg[3 * q], a.epoch, vr)) ok = 0; if (!nbrf_wait(&a.agg[3 * q + 1], a.epoch, vp)) ok = 0; }
+            else if (q == s) { vr = (unsigned)runR; vp = (unsigned)runP; }
+            const int inR = carryR + wave_incl_scan((int)vr, lane), inP = carryP + wave_incl_scan((int)vp, lane);
+            const unsigned long long bad = __ballot(q <= s && (inR > a.cap_rows || inP > a.cap_pairs));
+            if (bad) {
+                const int f = __ffsll((long long)bad) - 1;
+                validR = __shfl(inR - (int)vr, f); validP = __shfl(inP - (int)vp, f);
+                over = 1;
+            } else if (s - b < 64) {
+                baseR = __shfl(inR - (int)vr, s - b); baseP = __shfl(inP - (int)vp, s - b);
+            }
+            carryR = __shfl(inR, 63); carryP = __shfl(inP, 63);
         }
-        for (int o = 32; o > 0; o >>= 1) {
-            baseR += __shfl_xor(baseR, o); baseP += __shfl_xor(baseP, o); allR += __shfl_xor(allR, o); allP += __shfl_xor(allP, o);
-            ok &= __shfl_xor(ok, o);
-        }
-        if (lane == 0) { misc[0] = runR; misc[1] = runP; misc[2] = baseR; misc[3] = baseP; misc[4] = ok; misc[6] = allR; misc[7] = allP; }
+        for (int o = 32; o > 0; o >>= 1) ok &= __shfl_xor(ok, o);
+        if (lane == 0) { misc[0] = runR; misc[1] = runP; misc[2] = over ? validR : baseR; misc[3] = over ? validP : baseP; misc[4] = ok; misc[6] = over; }
     }
     __syncthreads();
     GPR_PHASE_EXIT(a.dbg, 3)
     const int TR = misc[0], TP = misc[1], baseR = misc[2], baseP = misc[3];
-    // too small a guess (or a wait that gave up): every offset of every structure is zero -- each centre then has no
-    // pairs and no rows, and whatever is queued behind this kernel runs over empty ranges -- and the flag goes up
-    const bool over = !misc[4] || misc[6] > a.cap_rows || misc[7] > a.cap_pairs;
+    // does not fit (or a wait gave up): every centre of this structure is closed at the totals of the part that fitted
+    const bool over = !misc[4] || misc[6];
     {
+        // a workgroup writes the END of each of its centres (entry i + 1): the entry between two structures then comes from
+        // the earlier one, which knows it whether or not the later one fits
         for (int i = tid; i < n; i += blockDim.x) {
-            a.cr0[si.atom0 + i] = over ? 0 : baseR + offR[i];
-            a.cp0[si.atom0 + i] = over ? 0 : baseP + offP[i];
+            const int er = i + 1 < n ? offR[i + 1] : TR, ep = i + 1 < n ? offP[i + 1] : TP;
+            a.cr0[si.atom0 + i + 1] = over ? baseR : baseR + er;
+            a.cp0[si.atom0 + i + 1] = over ? baseP : baseP + ep;
         }
+        if (s == 0 && tid == 0) { a.cr0[0] = 0; a.cp0[0] = 0; }
         if (s == a.nstruct - 1 && tid == 0) {
-            a.cr0[a.natoms] = over ? 0 : baseR + TR;
-            a.cp0[a.natoms] = over ? 0 : baseP + TP;
-            a.info[1] = over ? 1 : 0; a.info[2] = misc[7]; a.info[3] = misc[6];
+            // the last structure has seen every total: true sizes (its prefix + itself when everything fitted; else unknown
+            // beyond the point of overflow -- the totals are then summed from the slots below)
+            a.info[1] = over ? 1 : 0;
         }
         if (!over && tid == 0) a.rp0[baseR + TR] = baseP + TP;
     }
@@ -676,15 +704,21 @@ __global__ void __launch_bounds__(64 * NBRF_WAVES) nbr_fused_kernel(nbrf_args a)
     if (tid == 0)
         __hip_atomic_store(&a.agg[3 * s + 2], ((unsigned long long)a.epoch << 32) | (unsigned)misc[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (s == a.nstruct - 1 && wave == 0) {
-        int tot = 0, ok = 1;
+        int tot = 0, ok = 1, allR = 0, allP = 0;
         for (int b = 0; b < a.nstruct; b += 64) {
             const int q = b + lane;
-            unsigned v = 0;
-            if (q < a.nstruct && !nbrf_wait(&a.agg[3 * q + 2], a.epoch, v)) ok = 0;
-            tot += (int)v;
+            unsigned v = 0, vr = 0, vp = 0;
+            if (q < a.nstruct) {
+                if (!nbrf_wait(&a.agg[3 * q + 2], a.epoch, v)) ok = 0;
+                if (!nbrf_wait(&a.agg[3 * q], a.epoch, vr)) ok = 0;
+                if (!nbrf_wait(&a.agg[3 * q + 1], a.epoch, vp)) ok = 0;
+            }
+            tot += (int)v; allR += (int)vr; allP += (int)vp;
         }
-        for (int o = 32; o > 0; o >>= 1) { tot += __shfl_xor(tot, o); ok &= __shfl_xor(ok, o); }
-        if (lane == 0) { a.info[0] = tot; if (!ok) a.info[1] = 1; }
+        for (int o = 32; o > 0; o >>= 1) {
+            tot += __shfl_xor(tot, o); ok &= __shfl_xor(ok, o); allR += __shfl_xor(allR, o); allP += __shfl_xor(allP, o);
+        }
+        if (lane == 0) { a.info[0] = tot; a.info[2] = allP; a.info[3] = allR; if (!ok) a.info[1] = 1; }       // [missing, overflow, pairs, rows]
     }
 }
 
@@ -697,16 +731,15 @@ thread_local stage_buf g_stage[NSTAGE];
 thread_local int g_stage_next = 0;
 }
 
-// ---- when may a build take the one-launch kernel?  Its workgroups wait for each other (every structure needs the totals
-// of all), so every workgroup of a launch -- and of every other such launch that may be running -- has to be resident at the
-// same time: two partly resident launches would otherwise hold each other's CUs until the polls run out.  The host therefore
-//   * asks the runtime how many of these workgroups (1024 threads, `lds` bytes of dynamic LDS) a CU takes and multiplies by
-//     the device's CU count (cached per device and LDS size);
+// ---- when may a build take the one-launch kernel?  Its workgroups wait for their PREDECESSORS only (ticket order, see the
+// kernel), so a launch needs no particular number of them resident at the same time and any number of such launches may
+// share the device with each other and with anything else.  What the host still does:
 //   * raises the kernel's dynamic-LDS limit when a build needs more than the 64 KB default and the device has it, and
-//     declines the build when it does not;
-//   * keeps count of the workgroups of fused launches that have not finished yet (an event behind each launch), on every
-//     stream of the process, and admits a build only while all of them together fill at most half of that capacity.
-// A declined build takes the five-launch path: same tables, bit for bit.
+//     declines the build when it does not (a declined build takes the five-launch path: same tables, bit for bit);
+//   * keeps the residency figure (occupancy x CU count for the build's LDS need) and the count of launches in flight that the
+//     first form of the kernel -- whose workgroups waited for ALL the others -- needed as an admission rule; the rule
+//     (all such workgroups in flight within half of the residency) applies only while a test pretends a capacity
+//     (gpr_nbr_debug_fused_capacity), which is how the declined path is exercised.
 namespace {
 struct fused_flight { hipEvent_t ev = nullptr; int wgs = 0; bool busy = false; };
 std::mutex g_fused_mu;
@@ -744,7 +777,8 @@ static int fused_admit(int nstruct, size_t lds, int *slot) {
         it = g_fused_capacity.emplace(std::make_pair(devid, lds_key), per_cu * cus).first;
     }
     const int forced_cap = g_fused_forced_capacity.load();          // tests (gpr_nbr_debug_fused_capacity)
-    const int capacity = forced_cap >= 0 ? forced_cap : it->second;
+    if (forced_cap < 0) { *slot = -1; return 1; }                   // no admission rule (see above)
+    const int capacity = forced_cap;
     // launches counted as in flight: first by the records alone (an upper bound -- finished launches are only struck off when
     // somebody asks the runtime), and only if that bound does not admit the build by asking (an event query costs about a
     // microsecond; a prediction step keeps two or three launches in flight and never gets here)
@@ -766,6 +800,7 @@ static int fused_admit(int nstruct, size_t lds, int *slot) {
 // `ev`: the event the builder records behind the launch anyway (it guards the staging buffer; a later re-recording of it
 // only makes this record look busy for longer)
 static void fused_arm(int slot, int nstruct, hipEvent_t ev) {
+    if (slot < 0) return;
     std::lock_guard<std::mutex> lk(g_fused_mu);
     fused_flight &f = g_fused_flight[slot];
     f.ev = ev; f.wgs = nstruct; f.busy = true;
@@ -895,6 +930,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         nb->d_sid = nb->d_numbers + natoms;
         nb->d_atom0 = nb->d_sid + natoms;
         nbrf_args fa{};
+        unsigned *ticket_count = nullptr;
         fa.blob_host = (const char *)sb.dev; fa.blob_dev = nb->d_in;
         fa.off_shift = (long long)b_wpos; fa.off_sinfo = (long long)(b_wpos + b_shift); fa.off_num = (long long)(b_wpos + b_shift + b_sinfo);
         fa.off_sid = fa.off_num + (long long)b_num; fa.off_a0 = fa.off_sid + (long long)b_num; fa.bytes = (long long)b_total;
@@ -911,19 +947,27 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         // zeroed once.  (They used to sit in the call's recycled temporaries, where an old row count in the upper half of
         // a word could equal a small epoch: a stale total was then taken for a published one.)
         {
+            struct lookback { unsigned long long *ag = nullptr; unsigned issued = 0; };     // slots + ticket word, tickets handed out so far
             static std::mutex mu;
-            static std::unordered_map<hipStream_t, unsigned long long *> slots;
+            static std::unordered_map<hipStream_t, lookback> slots;
             std::lock_guard<std::mutex> lk(mu);
-            unsigned long long *&ag = slots[st];
-            if (!ag) {
-                if (hipMalloc((void **)&ag, 3 * NBRF_MAX_STRUCT * sizeof(unsigned long long)) != hipSuccess ||
-                    hipMemset(ag, 0, 3 * NBRF_MAX_STRUCT * sizeof(unsigned long long)) != hipSuccess) {
-                    ag = nullptr;
+            lookback &lb = slots[st];
+            if (!lb.ag) {
+                // zeroed ON THE STREAM that will use them: a plain hipMemset runs on the null stream, which a non-blocking stream
+                // does not wait for -- the first launch could then see the words before they were cleared, or have them cleared
+                // under its feet (stale totals taken for published ones, or a wait that never ends)
+                if (hipMalloc((void **)&lb.ag, (3 * NBRF_MAX_STRUCT + 1) * sizeof(unsigned long long)) != hipSuccess ||
+                    hipMemsetAsync(lb.ag, 0, (3 * NBRF_MAX_STRUCT + 1) * sizeof(unsigned long long), st) != hipSuccess) {
+                    lb.ag = nullptr;
                     gpr_set_error("gpr_nbr_build_device: cannot allocate the look-back slots");
                     return fail(GPR_ERR_HIP);
                 }
+                lb.issued = 0;
             }
-            fa.agg = ag;
+            fa.agg = lb.ag;
+            fa.ticket = (unsigned *)(lb.ag + 3 * NBRF_MAX_STRUCT);
+            fa.ticket_base = lb.issued;
+            ticket_count = &lb.issued;
         }
         fa.vec = nb->d_vec; fa.w = nb->d_w; fa.rp0 = nb->d_rp0; fa.self_row = nb->d_self; fa.seq = nb->d_seq;
         fa.row_index = row_index_dev; fa.x_index = row_index_dev ? x_index_dev : nullptr;
@@ -932,6 +976,7 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.mask_off = mask_off;
         hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
         hipError_t e = hipGetLastError();
+        if (e == hipSuccess) *ticket_count += (unsigned)nstruct;        // (single host thread per stream: the map entry outlives the call)
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e == hipSuccess) fused_arm(flight_slot, nstruct, sb.ev);
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fused launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }

@@ -159,7 +159,7 @@ def test_guessed_neighbour_capacities_and_their_overflow():
         for k in range(len(batch)):
             assert exact[0][k] == other[0][k] and np.array_equal(exact[1][k], other[1][k])
             assert exact[2][k] == other[2][k] and np.array_equal(exact[3][k], other[3][k])
-    # the capped builder on its own: same table as the exact one, or an empty one with the overflow flag
+    # the capped builder on its own: same table as the exact one, or the overflow flag over a table that stays inside the capacities
     import ctypes as C
     import torch
     from gpr_calculator_amd import _lib, device as dev
@@ -210,7 +210,12 @@ def test_guessed_neighbour_capacities_and_their_overflow():
     for caps in ((P - 1, S), (P, S - 1)):
         small = build(caps)
         assert small["info"][1] == 1 and (int(small["info"][2]), int(small["info"][3])) == (P, S)
-        assert not small["cp0"].any() and not small["cr0"].any()
+        # the structures that fitted (a prefix of the batch) as in the exact table, every centre behind them empty, and
+        # nothing beyond the capacities (the one-launch builder; the five launches empty the whole table)
+        cp0, cr0 = small["cp0"], small["cr0"]
+        assert (np.diff(cp0) >= 0).all() and (np.diff(cr0) >= 0).all() and cp0[-1] <= caps[0] and cr0[-1] <= caps[1]
+        k = int(np.argmax(cp0 == cp0[-1]))                       # first centre closed at the end of the part that fitted
+        assert np.array_equal(cp0[:k + 1], ref["cp0"][:k + 1]) and np.array_equal(cr0[:k + 1], ref["cr0"][:k + 1])
 
 
 def test_error_paths_fail_loudly():

@@ -2,7 +2,7 @@
 offsets across structures by look-back, fill, force-point regrouping by table look-up) against the five-launch path it
 replaces -- bit for bit, array by array -- on batches that reach its corners: more structures than lanes of a wavefront,
 clusters without periodic images next to small cells with 125 of them, 108 atoms (two passes of 64 lanes per centre), two
-species with the sign-flipping weights; and the all-or-nothing overflow answer."""
+species with the sign-flipping weights; and the answer to capacities that are too small."""
 import ctypes as C
 
 import numpy as np
@@ -88,15 +88,29 @@ def test_one_launch_build_is_the_five_launch_build(name, weight_on):
     assert a["info"][3] == a["cr0"][-1] and a["info"][2] == a["cp0"][-1]
 
 
-def test_overflow_is_all_or_nothing():
+def test_overflow_leaves_a_prefix_of_the_batch_and_empty_ranges_behind_it():
+    """capacities that are too small: the flag goes up and the true sizes are reported; the tables describe the structures
+    that fitted (the same entries as the full build) and close every later centre at their end -- nothing queued behind
+    the build can leave the arrays.  (The five-launch builder empties the whole table instead.)"""
     strucs = _batches()["mixed"]
     natoms = sum(len(s) for s in strucs)
+    a0 = np.concatenate([[0], np.cumsum([len(s) for s in strucs])])
     full = _build(strucs, natoms * 140, natoms * 40, True)
     P, S = int(full["info"][2]), int(full["info"][3])
-    for capP, capR in ((P - 1, S), (P, S - 1), (64, 64)):
+    for capP, capR in ((P - 1, S), (P, S - 1), (64, 64), (P // 2, S // 2)):
         o = _build(strucs, capP, capR, True)
         assert o["info"][1] == 1 and int(o["info"][2]) == P and int(o["info"][3]) == S          # flag up, true sizes reported
-        assert not o["cr0"].any() and not o["cp0"].any()                                      # every range empty
+        cr0, cp0 = o["cr0"], o["cp0"]
+        assert (np.diff(cr0) >= 0).all() and (np.diff(cp0) >= 0).all() and cr0[-1] <= capR and cp0[-1] <= capP
+        # the structures that fit: the longest prefix whose totals stay inside both capacities
+        k = 0
+        while k < len(strucs) and full["cr0"][a0[k + 1]] <= capR and full["cp0"][a0[k + 1]] <= capP:
+            k += 1
+        assert k < len(strucs)
+        assert np.array_equal(cr0[:a0[k] + 1], full["cr0"][:a0[k] + 1]) and np.array_equal(cp0[:a0[k] + 1], full["cp0"][:a0[k] + 1])
+        assert (cr0[a0[k]:] == cr0[a0[k]]).all() and (cp0[a0[k]:] == cp0[a0[k]]).all()       # every later centre empty
+        o5 = _build(strucs, capP, capR, False)                                                  # the five launches: all or nothing
+        assert o5["info"][1] == 1 and not o5["cr0"].any() and not o5["cp0"].any()
     exact = _build(strucs, P, S, True)                                                         # capacities that just fit
     assert exact["info"][1] == 0 and np.array_equal(exact["seq"], full["seq"])
 
@@ -117,10 +131,11 @@ def _rows_done(strucs, capP, capR):
     return done.value
 
 
-def test_the_one_launch_build_is_declined_when_its_workgroups_could_not_all_be_resident():
-    """The kernel's workgroups wait for each other: the host admits a build only while all such workgroups in flight fill
-    at most half of what the device keeps resident (occupancy x CU count).  A build that does not fit takes the five-launch
-    path -- same tables -- instead of spinning until the polls run out."""
+def test_the_admission_rule_of_the_one_launch_build_when_a_capacity_is_pretended():
+    """The kernel's workgroups wait for their predecessors only (ticket order), so a build needs no particular residency and
+    is always admitted.  The rule the first form of the kernel needed -- all such workgroups in flight within half of what
+    the device keeps resident -- still exists behind gpr_nbr_debug_fused_capacity: a build that does not fit the pretended
+    capacity takes the five-launch path, with the same tables."""
     import torch
     from gpr_calculator_amd import _lib
     from gpr_calculator_amd.synthetic import neb_images

@@ -49,7 +49,7 @@ for k in dot rbf; do
   cp $P/bench_stdout.log $O/${R}_${k}_bench_under_rocprof.log
   python tools/trace_by_grid.py $(find $P -name "*kernel_trace.csv" | head -1) $O/${R}_${k}_kernel_stats_by_grid.csv
 done
-bash tools/prof_pipeline.sh ${R}pipe --depth 3 > $O/${R}_overlap_depth3.txt 2>&1
+bash tools/prof_pipeline.sh ${R}pipe --depth 4 > $O/${R}_overlap_depth4.txt 2>&1
 bash tools/prof_pipeline.sh ${R}sync --depth 1 > $O/${R}_overlap_sync.txt 2>&1
 bash tools/prof_potrf.sh ${R}pt 6063 0 3 > $O/${R}_potrf_timeline.txt 2>&1
 echo "traces done"
