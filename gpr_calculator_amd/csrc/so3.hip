@@ -884,77 +884,65 @@ struct so3_fx {
 // workgroups per CU.  Per pair the work is independent of the centre, so for large batches it runs as a streaming kernel -- lane =
 // (pair, l), no LDS, no barrier, as many wavefronts per SIMD as the registers allow -- and leaves the head of the pair's record,
 // geometry | A_nl | B_nl ([P][8 + 2 NLP] doubles), for the centre kernel to copy (13 KB per centre, contiguous).  Same arithmetic as the radial half of build_records below.
+// The Chebyshev table of the radial functions is small (nseg x 16 x 30 doubles = 34.5 KB): every workgroup copies it into LDS once
+// and then walks its share of the (pair, l) lanes -- the 48 sixteen-byte coefficient reads of a lane come from LDS (twice the rate of
+// the texture path, no address arithmetic per load) instead of through L1.  A segment's block is padded to SO3_RSEG 16-byte pieces
+// (245: an odd multiple of five, so the five l of pairs in neighbouring segments fall into different bank groups).
+constexpr int SO3_RSEG = 245;
 template <int NMAX, int LMAX>
 __global__ void __launch_bounds__(256) so3_radial_pairs_kernel(so3_args P, int ncentres, double *ab) {
     using F = so3_fx<NMAX, LMAX>;
-    constexpr int L = F::L, NLP = F::NLP, NF = F::NF, H = SO3_NCHEB / 2;
+    constexpr int L = F::L, NLP = F::NLP, NF = F::NF;
+    static_assert(SO3_NCHEB * (NF / 2) <= SO3_RSEG, "a segment's coefficients fit its padded block");
+    extern __shared__ __attribute__((aligned(16))) double2 rtab[];              // [nseg][SO3_RSEG]
     const int npairs = P.centre_pair0[ncentres];              // (the caller's pair count may be a capacity: nbr.hip, capped builds)
-    const long long t_ = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int p = (int)(t_ / L), l = (int)(t_ - (long long)p * L);
-    if (p >= npairs) return;
+    const long long nlanes = (long long)npairs * L;
+    if ((long long)blockIdx.x * 256 >= nlanes) return;       // (uniform per workgroup: nobody is left behind at the barrier)
+    {
+        const double2 *src = (const double2 *)P.table;
+        const int per_seg = SO3_NCHEB * (NF / 2);
+        for (int e = threadIdx.x; e < P.nseg * per_seg; e += 256) {
+            const int sg = e / per_seg;
+            rtab[sg * SO3_RSEG + (e - sg * per_seg)] = src[e];
+        }
+    }
+    __syncthreads();
     const so3_tab tab = so3_table_layout(NMAX, LMAX, P.nseg, SO3_NCHEB);
     const double seg_scale = (double)P.nseg / P.rcut, inv_rcut = 1.0 / P.rcut;
-    const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
-    const double r2 = vx * vx + vy * vy + vz * vz, w = P.wj[p];
-    int seg = (int)(__builtin_sqrtf((float)r2) * (float)seg_scale);
-    seg = seg < 0 ? 0 : (seg > P.nseg - 1 ? P.nseg - 1 : seg);
-    const double2 *cb = (const double2 *)(P.table + (size_t)seg * SO3_NCHEB * NF) + l;
-    double2 ca[H], cl[H];
-#pragma unroll
-    for (int k = 0; k < H; k++) ca[k] = cb[(H + k) * (NF / 2)];
-#pragma unroll
-    for (int k = 0; k < H; k++) cl[k] = cb[k * (NF / 2)];
-    const double r = sqrt(r2);
-    double sarg, carg;
-    sincospi(r * inv_rcut, &sarg, &carg);
-    const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI * inv_rcut * sarg;
-    const double t = (r * seg_scale - (seg + 0.5)) * 2.0, t2 = 2.0 * t;
-    const double nw = P.table[tab.oNL + l] * w;
-    double *out = ab + (size_t)p * (8 + 2 * NLP) + 8;           // the pair's record head: [ux uy uz 1/r r - - -] | B | A
-    if (l == 0) {
-        const double inv_r = 1.0 / r;
-        out[-8] = vx * inv_r; out[-7] = vy * inv_r; out[-6] = vz * inv_r; out[-5] = inv_r; out[-4] = r;
-    }
-    double T8, T9;
-#pragma unroll
-    for (int n = 0; n < NMAX; n++) {
-        double f0 = 0.0, f1 = 0.0;
-        if (n == 0) {
-            double ta = 1.0, tb = t;
-#pragma unroll
-            for (int k = 2; k <= H + 1; k++) { const double tc = fma(t2, tb, -ta); ta = tb; tb = tc; }
-            T8 = ta; T9 = tb;
+    for (long long t_ = (long long)blockIdx.x * 256 + threadIdx.x; t_ < nlanes; t_ += (long long)gridDim.x * 256) {
+        const int p = (int)(t_ / L), l = (int)(t_ - (long long)p * L);
+        const double vx = P.vec[3 * (size_t)p], vy = P.vec[3 * (size_t)p + 1], vz = P.vec[3 * (size_t)p + 2];
+        const double r2 = vx * vx + vy * vy + vz * vz, w = P.wj[p];
+        int seg = (int)(__builtin_sqrtf((float)r2) * (float)seg_scale);
+        seg = seg < 0 ? 0 : (seg > P.nseg - 1 ? P.nseg - 1 : seg);
+        const double2 *cb = rtab + seg * SO3_RSEG + l;
+        const double r = sqrt(r2);
+        double sarg, carg;
+        sincospi(r * inv_rcut, &sarg, &carg);
+        const double fc = 0.5 * (carg + 1.0), dfc = -0.5 * M_PI * inv_rcut * sarg;
+        const double t = (r * seg_scale - (seg + 0.5)) * 2.0, t2 = 2.0 * t;
+        const double nw = P.table[tab.oNL + l] * w;
+        double *out = ab + (size_t)p * (8 + 2 * NLP) + 8;           // the pair's record head: [ux uy uz 1/r r - - -] | B | A
+        if (l == 0) {
+            const double inv_r = 1.0 / r;
+            out[-8] = vx * inv_r; out[-7] = vy * inv_r; out[-6] = vz * inv_r; out[-5] = inv_r; out[-4] = r;
         }
-        {
-            double ta = T8, tb = T9;
+        // T_k(t) once, k = 0 .. 15 (the same for the three channels of the lane), then three dot products with the coefficients
+        double T[SO3_NCHEB];
+        T[0] = 1.0; T[1] = t;
 #pragma unroll
-            for (int k = 0; k < H; k++) {
-                f0 = fma(ca[k].x, ta, f0); f1 = fma(ca[k].y, ta, f1);
-                const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
+        for (int k = 2; k < SO3_NCHEB; k++) T[k] = fma(t2, T[k - 1], -T[k - 2]);
+#pragma unroll
+        for (int n = 0; n < NMAX; n++) {
+            double f0 = 0.0, f1 = 0.0;
+#pragma unroll
+            for (int k = 0; k < SO3_NCHEB; k++) {
+                const double2 c = cb[n * L + k * (NF / 2)];
+                f0 = fma(c.x, T[k], f0); f1 = fma(c.y, T[k], f1);
             }
+            out[NLP + n * L + l] = nw * (fc * f1 + dfc * f0);
+            out[n * L + l] = nw * fc * f0;
         }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n + 1 < NMAX) {
-#pragma unroll
-            for (int k = 0; k < H; k++) ca[k] = cb[(n + 1) * L + (H + k) * (NF / 2)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        {
-            double ta = 1.0, tb = t;
-#pragma unroll
-            for (int k = 0; k < H; k++) {
-                f0 = fma(cl[k].x, ta, f0); f1 = fma(cl[k].y, ta, f1);
-                const double tc = fma(t2, tb, -ta); ta = tb; tb = tc;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (n + 1 < NMAX) {
-#pragma unroll
-            for (int k = 0; k < H; k++) cl[k] = cb[(n + 1) * L + k * (NF / 2)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        out[NLP + n * L + l] = nw * (fc * f1 + dfc * f0);
-        out[n * L + l] = nw * fc * f0;
     }
 }
 
@@ -1480,7 +1468,10 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         if (ncentres >= g_so3_prepass_min.load() && npairs > 0) {
             if ((rc = gpr_dev_alloc(&ab, (size_t)npairs * (8 + 2 * F::NLP) * sizeof(double), st))) return rc;
             const long long lanes = (long long)npairs * F::L;
-            hipLaunchKernelGGL((so3_radial_pairs_kernel<3, 4>), dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, st, A, ncentres, (double *)ab);
+            // workgroups that stay: each copies the coefficient table into LDS once (four per CU by its 35 KB) and walks its share
+            const long long want = (lanes + 255) / 256, cap = 4LL * gpr_cu_count();
+            const size_t rlds = (size_t)nseg * SO3_RSEG * sizeof(double2);
+            hipLaunchKernelGGL((so3_radial_pairs_kernel<3, 4>), dim3((unsigned)std::min(want, cap)), dim3(256), rlds, st, A, ncentres, (double *)ab);
             A.ab = (const double *)ab;
         }
         if (ab) hipLaunchKernelGGL((so3_fixed_kernel<3, 4, true>), dim3(ncentres), dim3(256), FP::TOTAL * sizeof(double), st, A);
