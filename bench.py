@@ -396,7 +396,8 @@ def main():
                      ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
                       2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N")),
             "gemv": ("gemv_t_partial_kernel: K_trans alpha", 2.0 * m_rows * N, "2 m N"),
-            "so3": ("so3_centre_kernel: SO3 power spectrum and derivatives (FP64 vector; no matrix shape)", n_nbr * 4.0e3,
+            "so3": ("so3_radial_pairs_kernel + so3_fixed_kernel<3, 4, true> (one HIP-event bracket around the two launches; below 512 centres one "
+                    "launch of so3_fixed_kernel<3, 4, false>): SO3 power spectrum and derivatives (FP64 vector; no matrix shape)", n_nbr * 4.0e3,
                     "~4 kflop per neighbour pair (30 Clenshaw sums of 16 terms, Y_lm recurrences, c_tot, R/S "
                     "contraction and 90 outputs per pair); the reference's own formulation (80-node Bessel quadrature "
                     "per pair) would be ~21 kflop"),
