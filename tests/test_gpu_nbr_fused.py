@@ -212,3 +212,26 @@ def _build_any(strucs, capP, capR):
         return _build(strucs, capP, capR, True)
     except AssertionError:
         return _build(strucs, capP, capR, False)
+
+
+def test_first_build_on_streams_that_have_never_seen_one():
+    """The look-back slots of the one-launch build belong to the stream and are cleared when the stream first needs them --
+    ON that stream: cleared on the null stream (which a non-blocking stream does not wait for) the first launch could read
+    them before they were cleared, or lose what it had published.  Thirty fresh non-blocking streams, first build on each
+    with other work keeping the device busy, every table compared with the five-launch build."""
+    import torch
+    from gpr_calculator_amd.synthetic import neb_images
+    strucs = neb_images(48, seed=77)
+    natoms = sum(len(s) for s in strucs)
+    capP, capR = natoms * 140, natoms * 40
+    want = _build(strucs, capP, capR, False)
+    busy = torch.empty((4096, 4096), dtype=torch.float64, device="cuda").normal_()
+    for k in range(30):
+        st = torch.cuda.Stream()
+        busy = busy @ busy * 1e-3                                            # the null stream has work queued: a clear queued there comes late
+        with torch.cuda.stream(st):
+            got = _build(strucs, capP, capR, True)
+        assert got["info"][0] == 0 and got["info"][1] == 0, (k, got["info"])
+        for key in want:
+            assert np.array_equal(got[key], want[key]), (k, key)
+    torch.cuda.synchronize()
