@@ -949,9 +949,11 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         {
             struct lookback { unsigned long long *ag = nullptr; unsigned issued = 0; };     // slots + ticket word, tickets handed out so far
             static std::mutex mu;
-            static std::unordered_map<hipStream_t, lookback> slots;
+            static std::map<std::pair<int, hipStream_t>, lookback> slots;                 // (device, stream): the null stream exists on every device
+            int devid = 0;
+            if (hipGetDevice(&devid) != hipSuccess) { (void)hipGetLastError(); devid = 0; }
             std::lock_guard<std::mutex> lk(mu);
-            lookback &lb = slots[st];
+            lookback &lb = slots[{devid, st}];
             if (!lb.ag) {
                 // zeroed ON THE STREAM that will use them: a plain hipMemset runs on the null stream, which a non-blocking stream
                 // does not wait for -- the first launch could then see the words before they were cleared, or have them cleared

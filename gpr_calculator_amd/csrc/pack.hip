@@ -201,13 +201,19 @@ struct pack_args {
     int plane, kpad;                // doubles per operand plane (64 k-steps), padded descriptor length (4 k-steps)
 };
 
-// one thread per padded row
+// Sixteen lanes per padded row, sixteen rows per block.  (The first form had a thread per row walking its 30 + 90 values one load
+// after the other, every lane of a wavefront in a different cache line: 30-40 us for the 400 rows of one structure's force
+// points.)  The lanes of a row read x and the three derivative columns together into LDS; lane 0 of the row then forms the
+// norm and the three projections in the same order of summation as before (the values are unchanged); all sixteen write the
+// operand planes.
 __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
-    int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= a.rpad) return;
-    const int src = a.src_row[r];
+    extern __shared__ double pk_lds[];                  // [16 rows][4 d]: x[d] | D[d][3]
+    __shared__ double pk_sc[16][6];                     // per row: n, inv, proj[3], live
+    const int lr = threadIdx.x >> 4, g = threadIdx.x & 15;
+    const int r = blockIdx.x * 16 + lr;
+    const bool inr = r < a.rpad;
+    const int src = inr ? a.src_row[r] : -1;
     const int nplanes = (a.role == GPR_ROLE_RESIDENT) ? a.nc : 1;
-    // plane base of this row and its slot inside a plane
     size_t base;
     int slot_row;
     if (a.role == GPR_ROLE_STREAM && a.nc == 4) {
@@ -223,50 +229,63 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(pack_args a) {
             return base + (size_t)s * GPR_WAVE + slot_row + 4 * comp + 16 * kk;
         return base + (size_t)comp * a.plane + (size_t)s * GPR_WAVE + slot_row + 16 * kk;
     };
-
-    double n = 0.0;
     bool live = src >= 0;
-    const double *xr = nullptr;
     int xsrc = src, dsrc = src;
     if (live && a.x_index) xsrc = a.x_index[src];
     if (live && a.d_index) dsrc = a.d_index[src];
     if (xsrc < 0 || dsrc < 0) live = false;
+    double *sx = pk_lds + (size_t)lr * 4 * a.d, *sD = sx + a.d;
     if (live) {
-        xr = a.x + (size_t)xsrc * a.d;
-        double acc = 0.0;
-        for (int k = 0; k < a.d; k++) acc += xr[k] * xr[k];
-        n = sqrt(acc);
-        if (a.numpy_eps) n += 1e-8;                 // base.py:118-119, Dot_mb.py:188-189, :206-211
-        else if (!(n > 1e-8)) live = false;         // rbf_kernel.cpp:26,37 skip
+        const double *xr = a.x + (size_t)xsrc * a.d;
+        for (int k = g; k < a.d; k += 16) sx[k] = xr[k];
+        if (a.nc == 4) {
+            const double *D = a.dxdr + (size_t)dsrc * a.d * a.width + a.col0;
+            for (int e = g; e < 3 * a.d; e += 16) { const int k = e / 3, c = e - 3 * k; sD[e] = D[(size_t)k * a.width + c]; }
+        }
     }
+    __syncthreads();
+    if (g == 0) {
+        double n = 0.0, inv = 0.0, proj[3] = {0.0, 0.0, 0.0};
+        bool lv = live;
+        if (lv) {
+            double acc = 0.0;
+            for (int k = 0; k < a.d; k++) acc += sx[k] * sx[k];
+            n = sqrt(acc);
+            if (a.numpy_eps) n += 1e-8;                 // base.py:118-119, Dot_mb.py:188-189, :206-211
+            else if (!(n > 1e-8)) lv = false;           // rbf_kernel.cpp:26,37 skip
+        }
+        if (lv) {
+            inv = 1.0 / n;
+            if (a.nc == 4)
+                for (int k = 0; k < a.d; k++) {
+                    const double ak = sx[k] * inv;
+                    for (int c = 0; c < 3; c++) proj[c] += ak * (sD[3 * k + c] * inv);
+                }
+        }
+        pk_sc[lr][0] = n; pk_sc[lr][1] = inv; pk_sc[lr][2] = proj[0]; pk_sc[lr][3] = proj[1]; pk_sc[lr][4] = proj[2];
+        pk_sc[lr][5] = lv ? 1.0 : 0.0;
+    }
+    __syncthreads();
+    if (!inr) return;
+    live = pk_sc[lr][5] != 0.0;
     if (!live) {
-        for (int c = 0; c < a.nc; c++)
-            for (int k = 0; k < a.kpad; k++) a.ops[slot(c, k)] = 0.0;
-        a.ele_out[r] = a.pad_code;
-        a.norms[r] = 0.0;
+        for (int e = g; e < a.nc * a.kpad; e += 16) { const int c = e / a.kpad, k = e - c * a.kpad; a.ops[slot(c, k)] = 0.0; }
+        if (g == 0) { a.ele_out[r] = a.pad_code; a.norms[r] = 0.0; }
         return;
     }
-    const double inv = 1.0 / n;
-    const int row_comp = a.nc - 1;                  // plane / comp index of the a~ row
+    const double inv = pk_sc[lr][1];
+    const int row_comp = a.nc - 1;                      // plane / comp index of the a~ row
     if (a.nc == 4) {
-        const double *D = a.dxdr + (size_t)dsrc * a.d * a.width + a.col0;
-        double proj[3] = {0.0, 0.0, 0.0};
-        for (int k = 0; k < a.d; k++) {
-            double ak = xr[k] * inv;
-            for (int c = 0; c < 3; c++) proj[c] += ak * (D[(size_t)k * a.width + c] * inv);
+        const double proj[3] = {pk_sc[lr][2], pk_sc[lr][3], pk_sc[lr][4]};
+        for (int e = g; e < 3 * a.kpad; e += 16) {
+            const int c = e / a.kpad, k = e - c * a.kpad;
+            double v = 0.0;
+            if (k < a.d) { const double ak = sx[k] * inv; v = sD[3 * k + c] * inv - ak * (c == 0 ? proj[0] : (c == 1 ? proj[1] : proj[2])); }
+            a.ops[slot(c, k)] = v;
         }
-        for (int k = 0; k < a.d; k++) {
-            double ak = xr[k] * inv;
-            for (int c = 0; c < 3; c++)
-                a.ops[slot(c, k)] = D[(size_t)k * a.width + c] * inv - ak * proj[c];
-        }
-        for (int c = 0; c < 3; c++)
-            for (int k = a.d; k < a.kpad; k++) a.ops[slot(c, k)] = 0.0;
     }
-    for (int k = 0; k < a.d; k++) a.ops[slot(row_comp, k)] = xr[k] * inv;
-    for (int k = a.d; k < a.kpad; k++) a.ops[slot(row_comp, k)] = 0.0;
-    a.ele_out[r] = a.ele[xsrc];
-    a.norms[r] = n;
+    for (int k = g; k < a.kpad; k += 16) a.ops[slot(row_comp, k)] = k < a.d ? sx[k] * inv : 0.0;
+    if (g == 0) { a.ele_out[r] = a.ele[xsrc]; a.norms[r] = pk_sc[lr][0]; }
 }
 
 // ---------------------------------------------------------------- host side
@@ -470,7 +489,9 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
         a.plane = (int)plane; a.kpad = 4 * s->ks;
         a.pad_code = (role == GPR_ROLE_STREAM) ? GPR_ELE_PAD_STREAM : GPR_ELE_PAD_RESIDENT;
         const int pid = gpr_prof_begin(st, GPR_PROF_PACK);
-        hipLaunchKernelGGL(pack_rows_kernel, dim3((s->rpad + 255) / 256), dim3(256), 0, st, a);
+        const size_t pk_bytes = (size_t)16 * 4 * d * sizeof(double);            // 64 KB at d = 128, next to a few hundred static bytes
+        if (pk_bytes > 60 * 1024 && (rc = gpr_func_lds_once((const void *)pack_rows_kernel, 96 * 1024))) return fail(rc);
+        hipLaunchKernelGGL(pack_rows_kernel, dim3((s->rpad + 15) / 16), dim3(256), pk_bytes, st, a);
         gpr_prof_end(st, pid);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) {
