@@ -417,12 +417,17 @@ extern "C" int gpr_set_create_gather(gpr_set **out, void *stream, int role, int 
     auto fail = [&](int code) { gpr_set_destroy(s, stream); return code; };
     if (role == GPR_ROLE_STREAM) {
         // launch ranges: consecutive packed points, about 128 tiles each (one task = range x resident block; a launch may take
-        // them two at a time, kblock.hip); small sets are cut finer (down to 8 tiles) so that a launch against them still has
+        // them two at a time, kblock.hip); small sets are cut finer (down to 8 tiles, 2 for energy sets) so that a launch against them still has
         // a few dozen ranges to spread over the CUs -- the resident side contributes only npts / (points per wave unit) / NW blocks
         std::vector<int> &irc = s->hk_irc, &irp = s->hk_irp;
         irc.assign(1, 0); irp.assign(1, 0);
         static const int range_cap = getenv("GPR_RANGE_TILES") ? atoi(getenv("GPR_RANGE_TILES")) : 128;    // (A/B: tools/kff_traffic.sh)
-        const int range_tiles = std::max(8, std::min(range_cap, unit / 64));
+        // (energy sets: 16-row tiles and a cheap epilogue -- a few tiles per task keep a small launch from being one long walk
+        //  per block: 80 -> 44 us for the energy-force blocks of one structure against 30 training structures; force sets keep
+        //  eight, where finer tasks only add resident reloads: 269 -> 290 us)
+        static const int floor_env = getenv("GPR_RANGE_FLOOR") ? atoi(getenv("GPR_RANGE_FLOOR")) : 0;            // A/B
+        const int range_floor = floor_env > 0 ? floor_env : (s->nc == 1 && unit <= 64) ? 2 : 8;         // (only the tiny ones: at 128 tiles the finer tasks cost more than they spread)
+        const int range_tiles = std::max(range_floor, std::min(range_cap, unit / 64));
         int tiles = 0;
         for (int p = 0; p < npts; p++) {
             tiles += s->h_pt_tiles[p];
