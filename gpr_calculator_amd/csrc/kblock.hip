@@ -46,6 +46,7 @@ struct kb_args {
     int split;              // small launches: one wave unit per block, its groups dealt to the block's wavefronts (see below)
     int xcd;                // stream ranges dealt to the XCDs (block index -> (jb, ir), see the kernel)
     int merge, npacked;     // packed stream ranges per launch range; packed ranges in all
+    int dparts;             // diagonal launches: blocks per unit
     double zeta, sigma2, inv2l2, inv_l, inv_l3, sigma02, tol;
     double scale, dl_scale;
     double *out; long long s_i, s_j, s_a, s_b;
@@ -129,9 +130,13 @@ kblock_kernel(kb_args P) {                                                      
     if ((jb + ir) % P.shard_mod != P.shard_rem) return;   // multi-GPU: this task belongs to another rank
 
     int c0, c1;
-    if (P.diag_only) {                                 // only the chunks of this block's own points
-        c0 = P.a_pt_chunk0[blk_pt0];
-        c1 = P.a_pt_chunk0[blk_pt1];
+    if (P.diag_only) {                                 // only the chunks of this block's own points -- of its share of them:
+        // `dparts` blocks per unit (blockIdx.y) take consecutive points of the unit each (a point against itself is independent
+        // of the others, and a block's time is the walk over its chunks whichever wavefront owns them)
+        const int npt = blk_pt1 - blk_pt0, part = blockIdx.y;
+        const int lo = blk_pt0 + (int)((long long)npt * part / P.dparts), hi = blk_pt0 + (int)((long long)npt * (part + 1) / P.dparts);
+        c0 = P.a_pt_chunk0[lo];
+        c1 = P.a_pt_chunk0[hi];
     } else {
         if (P.symmetric && P.ir_pt0[ir0] > jlast) return;  // range entirely below the diagonal
         c0 = P.ir_chunk0[ir0];
@@ -424,13 +429,14 @@ kblock_kernel(kb_args P) {                                                      
 
 // ---------------------------------------------------------------- host launcher
 template <int MODE, int KIND, bool Z2, bool GRAD>
-static void launch_nw(hipStream_t st, int nw, int ks, int nblocks, const kb_args &a) {
+static void launch_nw(hipStream_t st, int nw, int ks, int nblocks_, const kb_args &a) {
+    const dim3 nblocks(nblocks_, a.diag_only ? a.dparts : 1);
     if (ks == GPR_KSTEPS_WIDE)      // d <= 128: the resident operands are 256 registers per lane, one wavefront per SIMD
-        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_WIDE>), dim3(nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_WIDE>), nblocks, dim3(256), 0, st, a);
     else if (ks == GPR_KSTEPS_MAX)  // long descriptors: four wavefronts (the resident operands alone are 128 VGPRs per lane)
-        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_MAX>), dim3(nblocks), dim3(256), 0, st, a);
-    else if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8, GPR_KSTEPS>), dim3(nblocks), dim3(512), 0, st, a);
-    else              hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS>), dim3(nblocks), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS_MAX>), nblocks, dim3(256), 0, st, a);
+    else if (nw == 8) hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 8, GPR_KSTEPS>), nblocks, dim3(512), 0, st, a);
+    else              hipLaunchKernelGGL((kblock_kernel<MODE, KIND, Z2, GRAD, 4, GPR_KSTEPS>), nblocks, dim3(256), 0, st, a);
 }
 
 template <int MODE, int KIND>
@@ -518,6 +524,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c) {
     static const int xcd_env = getenv("GPR_KBLOCK_XCD") ? atoi(getenv("GPR_KBLOCK_XCD")) : -1;          // 0 / 1 force it (A/B)
     const bool xcd = !c.diag_only && (xcd_env >= 0 ? xcd_env != 0 : nir >= 16);
     a.xcd = xcd ? 1 : 0; a.merge = merge; a.npacked = nranges;
+    a.dparts = (c.diag_only && s2->max_unit_pts >= 2 && njb < 4 * gpr_cu_count()) ? std::min(4, s2->max_unit_pts) : 1;
     const int nblocks = c.diag_only ? njb : njb * nir;
     const bool grad = c.grad != 0;
     switch (c.mode * 2 + c.kind) {
