@@ -396,11 +396,18 @@ def main():
                      ("gemm128_kernel via gpr_gemm: K_trans^T = sigma^2 Psi_train Psi*^T and K_trans alpha",
                       2.0 * N * m_rows * F + 2.0 * m_rows * N, "2 N m F + 2 m N")),
             "gemv": ("gemv_t_partial_kernel: K_trans alpha", 2.0 * m_rows * N, "2 m N"),
-            "so3": ("so3_radial_pairs_kernel + so3_fixed_kernel<3, 4, true> (one HIP-event bracket around the two launches; below 512 centres one "
-                    "launch of so3_fixed_kernel<3, 4, false>): SO3 power spectrum and derivatives (FP64 vector; no matrix shape)", n_nbr * 4.0e3,
-                    "~4 kflop per neighbour pair (30 Clenshaw sums of 16 terms, Y_lm recurrences, c_tot, R/S "
-                    "contraction and 90 outputs per pair); the reference's own formulation (80-node Bessel quadrature "
-                    "per pair) would be ~21 kflop"),
+            # the descriptor is two launches from 512 centres on: the radial channels of every pair in a streaming
+            # pass, then the centre kernel; each has its own HIP-event bracket.  The ~4 kflop per pair of the whole descriptor
+            # (SURVEY 8d counts it as one unit) split by where they are done: 30 dot products of 16 coefficients with T_k(t),
+            # the cutoff and the root (1.1 kflop) / Y_lm recurrences, c_tot, R / S contraction and 90 outputs per pair (2.9 kflop)
+            "so3": ("so3_fixed_kernel<3, 4, true> (the centre kernel of the descriptor; below 512 centres so3_fixed_kernel<3, 4, false> "
+                    "does the radial part too): SO3 power spectrum and derivatives (FP64 vector; no matrix shape)",
+                    n_nbr * (2.9e3 if ("so3_radial" in per_step) else 4.0e3),
+                    "~2.9 kflop per neighbour pair in the centre kernel (Y_lm recurrences, c_tot, R / S contraction and 90 outputs per "
+                    "pair) + 1.1 in the radial pre-pass = the ~4 kflop of the descriptor; the reference's own formulation (80-node "
+                    "Bessel quadrature per pair) would be ~21 kflop"),
+            "so3_radial": ("so3_radial_pairs_kernel<3, 4>: radial channels A_nl, B_nl of every pair (FP64 vector, table in LDS)", n_nbr * 1.1e3,
+                           "~1.1 kflop per neighbour pair (30 dot products of 16 Chebyshev coefficients with T_k(t), cutoff, root)"),
             "features": ("dot2_force_features_mfma_kernel (+ energy-point kernels): degree-2 feature rows and prior variances",
                          float(len(ele_rows)) * 2 * 3 * 2 * 32 * 32,
                          "two passes (native, numpy-eps) x 3 components x 2 x 32 x 32 flop per descriptor row: the symmetric "
@@ -418,7 +425,7 @@ def main():
             except Exception:
                 traffic = None
         per_sync = {k: (ms / nsync, n / nsync) for k, (ms, n) in prof_sync.items() if n}
-        roofline = {"bound": "fp64-vector" if dom in ("so3", "ee") else "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        roofline = {"bound": "fp64-vector" if dom in ("so3", "so3_radial", "ee") else "mfma", "achieved": achieved, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / FP64_MFMA_PEAK_TFLOPS, "traffic": traffic, "kernel": name,
                     "avg_launch_ms": avg_ms, "launches_per_step": per_step[dom][1], "event_sampling": sample, "flop_per_step": flops,
                     # the timed region keeps `batches_in_flight` device chains running side by side: a launch's duration there

@@ -125,7 +125,7 @@ int gpr_launch_block(hipStream_t st, const gpr_block_call &c);
 // profiling kinds of gpr_profile_fetch (kernel-only HIP-event timing, see include/gpr_hip.h)
 enum gpr_prof_kind { GPR_PROF_FF = 0, GPR_PROF_EF = 1, GPR_PROF_EE = 2, GPR_PROF_DIAG = 3, GPR_PROF_TRMM = 4,
                      GPR_PROF_GEMM = 5, GPR_PROF_SO3 = 6, GPR_PROF_FEATURES = 7, GPR_PROF_PACK = 8, GPR_PROF_GEMV = 9,
-                     GPR_PROF_NKINDS = 10 };
+                     GPR_PROF_SO3_RADIAL = 10, GPR_PROF_NKINDS = 11 };
 int gpr_prof_begin(hipStream_t st, int kind);
 void gpr_prof_end(hipStream_t st, int id);
 

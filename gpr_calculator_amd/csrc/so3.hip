@@ -1454,7 +1454,7 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
         if (!rc_) rc_ = gpr_func_lds_once((const void *)so3_centre_kernel<5, 5, false>, 96 * 1024);
         if (rc_) return rc_;
     }
-    const int pid = gpr_prof_begin(st, GPR_PROF_SO3);
+    int pid = -1;                                            // the profiler's bracket around the centre kernel (one bracket, one kernel)
     const bool small_l = lmax + 1 <= 5 && nmax <= 3;
     if (!rdxdr && nmax == 3 && lmax == 4 && g_so3_variant.load() == 0) {
         // the configuration of the reference's defaults: every size a compile-time constant (so3_fixed_kernel)
@@ -1471,16 +1471,21 @@ extern "C" int gpr_so3_power_spectrum_stress(void *stream, int nmax, int lmax, d
             // workgroups that stay: each copies the coefficient table into LDS once (four per CU by its 35 KB) and walks its share
             const long long want = (lanes + 255) / 256, cap = 4LL * gpr_cu_count();
             const size_t rlds = (size_t)nseg * SO3_RSEG * sizeof(double2);
+            const int rpid = gpr_prof_begin(st, GPR_PROF_SO3_RADIAL);       // a kind of its own: one bracket, one kernel
             hipLaunchKernelGGL((so3_radial_pairs_kernel<3, 4>), dim3((unsigned)std::min(want, cap)), dim3(256), rlds, st, A, ncentres, (double *)ab);
+            gpr_prof_end(st, rpid);
             A.ab = (const double *)ab;
         }
+        pid = gpr_prof_begin(st, GPR_PROF_SO3);
         if (ab) hipLaunchKernelGGL((so3_fixed_kernel<3, 4, true>), dim3(ncentres), dim3(256), FP::TOTAL * sizeof(double), st, A);
         else hipLaunchKernelGGL((so3_fixed_kernel<3, 4, false>), dim3(ncentres), dim3(256), F::TOTAL * sizeof(double), st, A);
         if (ab) gpr_dev_free(ab, st);
     } else if (rdxdr) {
+        pid = gpr_prof_begin(st, GPR_PROF_SO3);
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, true>), dim3(ncentres), dim3(256), lds_bytes, st, A);
     } else {
+        pid = gpr_prof_begin(st, GPR_PROF_SO3);
         if (small_l) hipLaunchKernelGGL((so3_centre_kernel<5, 3, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else if (nmax <= 4) hipLaunchKernelGGL((so3_centre_kernel<SO3_LCAP, 4, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);
         else if (lmax <= 3) hipLaunchKernelGGL((so3_centre_kernel<4, SO3_NCAP, false>), dim3(ncentres), dim3(256), lds_bytes, st, A);   // nmax 5, 6: lmax <= 3

@@ -429,7 +429,7 @@ def profile_fetch(scaled=True):
     """{'ff': (ms, launches), 'ef': ..., 'ee': ..., 'diag': ...} kernel-only times since profile_enable().  With a
     sampling period (profile_enable(n), n > 1) only every n-th launch of a kind carries events; scaled=True returns
     the recorded time scaled to all launches seen (mean recorded launch x launches seen) and the launches seen."""
-    names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack", "gemv")
+    names = ("ff", "ef", "ee", "diag", "trmm", "gemm", "so3", "features", "pack", "gemv", "so3_radial")
     seen = (C.c_int * len(names))()
     check(_lib.lib().gpr_profile_counts(seen), "gpr_profile_counts")
     ms = (C.c_double * len(names))()

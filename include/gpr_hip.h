@@ -223,9 +223,9 @@ int gpr_dev_cache_count(void *stream, int any);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
  * bench.py's roofline leg).  gpr_profile_enable(1) starts recording for this host thread;
- * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 10 entries
+ * gpr_profile_fetch sums the durations (ms) and launch counts per kernel kind into arrays of 11 entries
  * (0 force-force block, 1 energy-force, 2 energy-energy, 3 diagonal-only block launches, 4 triangular product
- * gpr_trmm_lower, 5 gpr_gemm, 6 SO3 descriptor, 7 Dot feature map, 8 row packing, 9 gpr_gemv_t) and clears the
+ * gpr_trmm_lower, 5 gpr_gemm, 6 SO3 descriptor (the centre kernel), 7 Dot feature map, 8 row packing, 9 gpr_gemv_t, 10 the descriptor's radial pre-pass) and clears the
  * records. */
 int gpr_profile_enable(int on);
 int gpr_profile_fetch(double *ms_by_kind, int *launches_by_kind);
