@@ -460,20 +460,21 @@ trmm_sumsq_few_kernel(int n, const double *__restrict__ T, long long ldt, const 
 #pragma unroll
         for (int u = 0; u < DA; u++) load_a(min(wave + u * NWV, last), aq[u]);
         load_b(min(wave, last), bq[0]);
-        for (int run = wave;;) {                                          // (exits by goto: see ws_tail_rows_kernel)
+        // (groups of DA runs with no exit inside a group -- an exit is a place below which the compiler sinks the refills, see
+        //  ws_tail_rows_kernel --: a run beyond the last full one multiplies by a zero A operand)
+        for (int run = wave; run < nfull; run += DA * NWV) {
 #pragma unroll
             for (int u = 0; u < DA; u++) {
-                if (run >= nfull) goto runs_done;
-                load_b(min(run + NWV, last), bq[(u + 1) & 1]);
+                const int r_ = run + u * NWV;
+                const bool live = r_ < nfull;
+                load_b(min(r_ + NWV, last), bq[(u + 1) & 1]);
                 double a[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) a[e] = aq[u][e];
-                load_a(min(run + DA * NWV, last), aq[u]);
+                for (int e = 0; e < 4; e++) a[e] = live ? aq[u][e] : 0.0;
+                load_a(min(r_ + DA * NWV, last), aq[u]);
                 mma(a, bq[u & 1]);
-                run += NWV;
             }
         }
-    runs_done:
         if (wave == (b & (NWV - 1))) {                                  // the diagonal run: k <= i only, and k < n
             double a[4], bb[4][CT];
             const int k = b * RUN + 4 * lq;
