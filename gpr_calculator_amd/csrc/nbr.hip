@@ -946,14 +946,16 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         // but earlier calls' tags: memory of their own, one small array per stream (launches of a stream are ordered),
         // zeroed once.  (They used to sit in the call's recycled temporaries, where an old row count in the upper half of
         // a word could equal a small epoch: a stale total was then taken for a published one.)
+        // (the host's count of tickets handed out and the launch that consumes them go together: two host threads building on
+        //  the same stream must not both start from the same count -- the lock is held until the launch is queued)
+        struct lookback { unsigned long long *ag = nullptr; unsigned issued = 0; };     // slots + ticket word, tickets handed out so far
+        static std::mutex lb_mu;
+        static std::map<std::pair<int, hipStream_t>, lookback> lb_slots;                 // (device, stream): the null stream exists on every device
+        int lb_dev = 0;
+        if (hipGetDevice(&lb_dev) != hipSuccess) { (void)hipGetLastError(); lb_dev = 0; }
+        std::unique_lock<std::mutex> lb_lock(lb_mu);
         {
-            struct lookback { unsigned long long *ag = nullptr; unsigned issued = 0; };     // slots + ticket word, tickets handed out so far
-            static std::mutex mu;
-            static std::map<std::pair<int, hipStream_t>, lookback> slots;                 // (device, stream): the null stream exists on every device
-            int devid = 0;
-            if (hipGetDevice(&devid) != hipSuccess) { (void)hipGetLastError(); devid = 0; }
-            std::lock_guard<std::mutex> lk(mu);
-            lookback &lb = slots[{devid, st}];
+            lookback &lb = lb_slots[{lb_dev, st}];
             if (!lb.ag) {
                 // zeroed ON THE STREAM that will use them: a plain hipMemset runs on the null stream, which a non-blocking stream
                 // does not wait for -- the first launch could then see the words before they were cleared, or have them cleared
@@ -978,7 +980,8 @@ static int nbr_build_device_impl(gpr_nbr **out, void *stream, int nstruct, const
         fa.mask_off = mask_off;
         hipLaunchKernelGGL(nbr_fused_kernel, dim3(nstruct), dim3(64 * NBRF_WAVES), lds, st, fa);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) *ticket_count += (unsigned)nstruct;        // (single host thread per stream: the map entry outlives the call)
+        if (e == hipSuccess) *ticket_count += (unsigned)nstruct;
+        lb_lock.unlock();
         if (e == hipSuccess) { e = hipEventRecord(sb.ev, st); sb.pending = e == hipSuccess; }
         if (e == hipSuccess) fused_arm(flight_slot, nstruct, sb.ev);
         if (e != hipSuccess) { gpr_set_error("gpr_nbr_build_device: fused launch failed: %s", hipGetErrorString(e)); return fail(GPR_ERR_HIP); }
