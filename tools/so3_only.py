@@ -15,9 +15,12 @@ for variant in (0, 2, 1):                           # 0: compile-time instance (
     dev.profile_enable(True)
     for _ in range(20): des.calculate_batch_dev(batch)
     torch.cuda.synchronize()
-    ms, n = dev.profile_fetch()["so3"]
+    prof = dev.profile_fetch()
+    ms, n = prof["so3"]                                 # the centre kernel; the radial pre-pass (variant 0) has a bracket of its own
+    msr, nr = prof.get("so3_radial", (0.0, 0))
     dev.profile_enable(False)
-    print(f"so3 variant {variant} (phase {os.environ.get('GPR_SO3_DBG','0')}): {ms/n:.4f} ms per launch over {n} launches, "
+    parts = f" = radial pre-pass {msr/nr:.4f} + centre kernel {ms/n:.4f}" if nr else ""
+    print(f"so3 variant {variant} (phase {os.environ.get('GPR_SO3_DBG','0')}): {(ms + msr)/n:.4f} ms per call{parts} over {n} calls, "
           f"{out['x'].shape[0]} centres, {out['dxdr'].shape[0]} seq rows")
     if variant == 0: ref = out
     else:

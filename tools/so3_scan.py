@@ -13,6 +13,8 @@ for nb in (4, 8, 12, 16, 24, 32, 40, 48, 56, 64, 72, 96, 128):
     dev.profile_enable(True)
     for _ in range(20): des.calculate_batch_dev(batch)
     torch.cuda.synchronize()
-    ms, n = dev.profile_fetch()["so3"]
+    prof = dev.profile_fetch()
+    ms, n = prof["so3"]
+    msr, nr = prof.get("so3_radial", (0.0, 0))          # from 512 centres on: radial pre-pass + centre kernel (five workgroups per CU)
     dev.profile_enable(False)
-    print(f"{nb:4d} structures = {32 * nb:5d} centres = {32 * nb / 768:5.2f} x 768 resident workgroups: {ms / n * 1e3:7.1f} us")
+    print(f"{nb:4d} structures = {32 * nb:5d} centres: {(ms + msr) / n * 1e3:7.1f} us" + (f"  = radial {msr / nr * 1e3:5.1f} + centre {ms / n * 1e3:5.1f}" if nr else "  (one launch)"))
