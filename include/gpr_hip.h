@@ -289,8 +289,10 @@ int gpr_nbr_check(const gpr_nbr *nb, int *nmissing);
 int gpr_nbr_status_to(const gpr_nbr *nb, double *dst_dev);
 /* gpr_nbr_build_device with caller-guessed capacities for the pair and seq-row arrays: the count pass is not waited
  * for, gpr_nbr_sizes returns the capacities and gpr_nbr_export is refused.  If the true sizes exceed the guess the
- * handle describes an EMPTY table (every centre: zero pairs, zero rows), so whatever was queued behind it runs over
- * empty ranges; gpr_nbr_info_to reports it. */
+ * handle describes a table that stays inside the capacities -- the structures that fitted (a prefix of the batch; none
+ * of them with the five-launch builder) and empty ranges for every centre behind them -- so whatever was queued behind
+ * it touches nothing out of bounds; gpr_nbr_info_to reports the overflow and the true sizes, and the caller discards
+ * the results and repeats the build with exact sizes. */
 int gpr_nbr_build_device_capped(gpr_nbr **out, void *stream, int nstruct, const int *atom0, const double *positions,
                                 const double *cells, const int *pbc, const int *numbers, double rcut, int weight_on,
                                 int cap_pairs, int cap_rows);
