@@ -5,7 +5,7 @@ import torch
 from gpr_calculator_amd import device as dev
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 5807
 d = dev.device()
-for k in (64, 128, 256, 512, 1024, 4096):
+for k in [int(x) for x in os.environ.get("GEMM_KS", "64,128,256,512,1024,4096").split(",")]:
     A = torch.randn(m, k, dtype=torch.float64, device=d)
     C = torch.zeros(m, m, dtype=torch.float64, device=d)
     for beta in (0.0, 1.0):
@@ -16,6 +16,7 @@ for k in (64, 128, 256, 512, 1024, 4096):
             ts.append(time.perf_counter() - t0)
         t = min(ts)
         print(f"m=n={m} k={k:5d} beta={beta}: {t * 1e3:8.3f} ms  {2.0 * m * m * k / t / 1e12:6.2f} TF", flush=True)
+    if os.environ.get("GEMM_NO_VENDOR"): continue
     t0 = time.perf_counter(); R = A @ A.T; torch.cuda.synchronize()
     ts = []
     for _ in range(3):
