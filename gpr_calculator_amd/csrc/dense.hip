@@ -111,12 +111,13 @@ constexpr int GM = 128, GN = 128, GK = 16, GLDK = GM + 16, GLDR = GK + 1;
 struct cyc_rule { int nb, nranks, rank, lb0, col0; };
 constexpr int GBUF = (GK * GLDK > GM * GLDR) ? GK * GLDK : GM * GLDR;
 
-// FAST (only with A not transposed, B transposed -- both operands k-contiguous, the form of every trailing update of the
-// factorisation; leading dimensions below 2^21): the tile loads carry no predicate.  Rows beyond the matrix are clamped to its last
-// row (their products are never stored), the uniform part of the address (tile origin + k0) sits in scalar registers and each lane
-// keeps sixteen 32-bit offsets, and a k range that is not a multiple of 16 ends in one tile whose loads are clamped into the row and
-// whose A values beyond the end become zeros.  The generic form spends ~150 instructions per k tile on predicates and 64-bit
-// pointers, under lane-dependent branches; with the loads removed altogether the kernel ran at 63 TF instead of 55 (k = 4096).
+// FAST (leading dimensions below 2^21): the tile loads carry no predicate.  Rows or columns beyond the matrix are clamped to its
+// last one (their products are never stored), the uniform part of the address (tile origin + k0) sits in scalar registers -- buffer
+// loads: descriptor + 32-bit lane offset + scalar offset -- and each lane keeps sixteen 32-bit offsets; a k range that is not a
+// multiple of 16 ends in one tile whose loads are clamped into the range and whose A values beyond the end become zeros.  The generic
+// form spends ~150 instructions per k tile on predicates and 64-bit pointers, under lane-dependent branches; with the loads removed
+// altogether the kernel ran at 63 TF instead of 55 (k = 4096).  NT at m = n = 5807: k = 256, beta = 1 0.499 -> 0.413 ms;
+// k = 4096 55 -> 60 TF.
 template <bool TA, bool TB, bool FAST = false>
 __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, double alpha,
                                                        const double *__restrict__ A, long long lda,
@@ -214,40 +215,52 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
         }
     };
     const int nkt = (k + GK - 1) / GK;
-    // FAST: offsets of this lane's sixteen elements from the tile origins, in bytes
+    // FAST: byte offsets of this lane's sixteen elements from the tile origins (k = 0).  An operand stored [row][k] (A not
+    // transposed, B transposed) advances along k by a scalar offset; one stored [k][row] by whole rows of the array, more than 32
+    // bits can hold, so its descriptor is rebuilt per k tile (scalar arithmetic)
     unsigned oa[8], ob[8];
     const char *Ab = nullptr, *Bb = nullptr;
     if constexpr (FAST) {
-        static_assert(!FAST || (!TA && TB), "FAST is the NT form");
-        Ab = (const char *)(A + (long long)bm0 * lda);
-        Bb = (const char *)(B + (long long)bn0 * ldb);
-        const int kk = tid & 15, r0 = tid >> 4;
+        Ab = (const char *)(TA ? A + bm0 : A + (long long)bm0 * lda);
+        Bb = (const char *)(TB ? B + (long long)bn0 * ldb : B + bn0);
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            oa[i] = (unsigned)(min(r0 + 16 * i, m - 1 - bm0) * (int)lda + kk) * 8u;
-            ob[i] = (unsigned)(min(r0 + 16 * i, n - 1 - bn0) * (int)ldb + kk) * 8u;
+            oa[i] = TA ? (unsigned)(((tid >> 7) + 2 * i) * (int)lda + min(tid & 127, m - 1 - bm0)) * 8u
+                       : (unsigned)(min((tid >> 4) + 16 * i, m - 1 - bm0) * (int)lda + (tid & 15)) * 8u;
+            ob[i] = TB ? (unsigned)(min((tid >> 4) + 16 * i, n - 1 - bn0) * (int)ldb + (tid & 15)) * 8u
+                       : (unsigned)(((tid >> 7) + 2 * i) * (int)ldb + min(tid & 127, n - 1 - bn0)) * 8u;
         }
     }
     // buffer loads: descriptor (scalar) + 32-bit lane offset + scalar k offset -- no vector arithmetic per load
-    auto panel = [&](const char *base, int rows, long long ld) {
-        const unsigned long long bytes = ((unsigned long long)(rows - 1) * (unsigned long long)ld + (unsigned long long)k) * 8ull;
+    auto rsrc = [&](const char *base, unsigned long long bytes) {
         return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)(unsigned)(bytes > 0xFFFFFFFFull ? 0xFFFFFFFFull : bytes), 0x00020000);
     };
-    const __amdgpu_buffer_rsrc_t ra_src = panel(Ab, min(GM, m - bm0), lda), rb_src = panel(Bb, min(GN, n - bn0), ldb);   // FAST only
     auto ld8 = [&](__amdgpu_buffer_rsrc_t r, unsigned off, int soff) {
         return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, off, soff, 0));
     };
-    auto load_full = [&](int k0) {                       // every k of the tile inside the range
-#pragma unroll
-        for (int i = 0; i < 8; i++) { ra[i] = ld8(ra_src, oa[i], k0 * 8); rb[i] = ld8(rb_src, ob[i], k0 * 8); }
+    const int rows_a = min(GM, m - bm0), rows_b = min(GN, n - bn0);
+    // [row][k] operands: one descriptor for the whole panel
+    const __amdgpu_buffer_rsrc_t pa_src = rsrc(Ab, ((unsigned long long)(rows_a - 1) * (unsigned long long)lda + (unsigned long long)k) * 8ull);
+    const __amdgpu_buffer_rsrc_t pb_src = rsrc(Bb, ((unsigned long long)(rows_b - 1) * (unsigned long long)ldb + (unsigned long long)k) * 8ull);
+    auto tile_src = [&](const char *base, long long ld, int rows, int k0) {          // [k][row] operands: the k tile at k0
+        return rsrc(base + (long long)k0 * ld * 8, ((unsigned long long)(min(GK, k - k0) - 1) * (unsigned long long)ld + (unsigned long long)rows) * 8ull);
     };
-    auto load_last = [&](int k0) {                       // the tile the range ends in
-        const int kk = tid & 15, over = max(k0 + kk - (k - 1), 0);
+    auto load_full = [&](int k0) {                       // every k of the tile inside the range
+        const __amdgpu_buffer_rsrc_t sa = TA ? tile_src(Ab, lda, rows_a, k0) : pa_src, sb = TB ? pb_src : tile_src(Bb, ldb, rows_b, k0);
+        const int ka = TA ? 0 : k0 * 8, kb = TB ? k0 * 8 : 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { ra[i] = ld8(sa, oa[i], ka); rb[i] = ld8(sb, ob[i], kb); }
+    };
+    auto load_last = [&](int k0) {                       // the tile the range ends in: k clamped into it, A's surplus zeroed
+        const __amdgpu_buffer_rsrc_t sa = TA ? tile_src(Ab, lda, rows_a, k0) : pa_src, sb = TB ? pb_src : tile_src(Bb, ldb, rows_b, k0);
+        const int ka = TA ? 0 : k0 * 8, kb = TB ? k0 * 8 : 0, klast = k - 1 - k0;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const double va = ld8(ra_src, oa[i] - 8u * over, k0 * 8);
-            ra[i] = over ? 0.0 : va;
-            rb[i] = ld8(rb_src, ob[i] - 8u * over, k0 * 8);
+            const int over_a = max((TA ? (tid >> 7) + 2 * i : (tid & 15)) - klast, 0);
+            const int over_b = max((TB ? (tid & 15) : (tid >> 7) + 2 * i) - klast, 0);
+            const double va = ld8(sa, oa[i] - 8u * (unsigned)over_a * (TA ? (unsigned)lda : 1u), ka);
+            ra[i] = over_a ? 0.0 : va;
+            rb[i] = ld8(sb, ob[i] - 8u * (unsigned)over_b * (TB ? 1u : (unsigned)ldb), kb);
         }
     };
     if constexpr (FAST) {
@@ -287,8 +300,20 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
         if (kt + 1 < nkt) store_tile(buf ^ 1);
         __syncthreads();
     }
+    const bool rmw = !(beta == 0.0 || init_c);       // general alpha with beta != 0: C is read here, a row of tiles at a time,
+#pragma unroll                                       // every load issued (addresses clamped into the matrix) before the first use
+    for (int i = 0; i < 4; i++) {
+        double cold[4][4];
+        if (rmw) {
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gm = min(bm0 + wm + i * 16 + (lane >> 4) + 4 * r, m - 1);
+                    const int gn = min(bn0 + wn + j * 16 + (lane & 15), n - 1);
+                    cold[j][r] = C[(long long)gm * ldc + gn];
+                }
+        }
 #pragma unroll
         for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -296,11 +321,11 @@ __global__ void __launch_bounds__(256) gemm128_kernel(int m, int n, int k, doubl
                 const int gm = bm0 + wm + i * 16 + (lane >> 4) + 4 * r;
                 const int gn = bn0 + wn + j * 16 + (lane & 15);
                 if (gm < m && gn < n) {
-                    double *c = C + (long long)gm * ldc + gn;
                     const double v = alpha * acc[i][j][r];
-                    *c = (beta == 0.0 || init_c) ? v : v + beta * *c;
+                    C[(long long)gm * ldc + gn] = rmw ? v + beta * cold[j][r] : v;
                 }
             }
+    }
 }
 
 // diagonal-block solve of the blocked TRSM: one thread per right-hand-side column
@@ -1401,6 +1426,7 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
         // tall-skinny A^T B (the F x F Gram matrices of the weight-space fit: a handful of tiles, k in the thousands):
         // slices of k on blockIdx.z, partial tiles to a workspace, summed in slice order
         const int tiles = (int)(g2.x * g2.y);
+        const bool fast = lda < (1 << 21) && ldb < (1 << 21) && !getenv("GPR_GEMM_GENERIC");
         if (ta && !tb && !lower_only && tiles <= 64 && k >= 2048) {
             int nz = std::min(256 / tiles, k / 512);
             const int ksplit = ((k + nz - 1) / nz + GK - 1) / GK * GK;
@@ -1409,7 +1435,8 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
             int rc = gpr_dev_alloc(&wsp, (size_t)nz * m * n * sizeof(double), st);
             if (rc) return rc;
             g2.z = nz;
-            hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp, cyc_rule{0, 0, 0, 0, 0});
+            if (fast) hipLaunchKernelGGL((gemm128_kernel<true, false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp, cyc_rule{0, 0, 0, 0, 0});
+            else hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, 0, ksplit, (double *)wsp, cyc_rule{0, 0, 0, 0, 0});
             hipLaunchKernelGGL(gemm_splitk_reduce_kernel, dim3((unsigned)(((long long)m * n + 255) / 256)), dim3(256), 0, st, m, n, nz,
                                (const double *)wsp, alpha, beta, c, ldc);
             const hipError_t e3 = hipGetLastError();
@@ -1417,12 +1444,12 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
             if (e3 != hipSuccess) { gpr_set_error("split-K gemm launch failed: %s", hipGetErrorString(e3)); return GPR_ERR_HIP; }
             return GPR_OK;
         }
-        if (!ta && !tb) hipLaunchKernelGGL((gemm128_kernel<false, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
-        else if (!ta && tb && lda < (1 << 21) && ldb < (1 << 21))
-            hipLaunchKernelGGL((gemm128_kernel<false, true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
-        else if (!ta && tb) hipLaunchKernelGGL((gemm128_kernel<false, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
-        else if (ta && !tb) hipLaunchKernelGGL((gemm128_kernel<true, false>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
-        else hipLaunchKernelGGL((gemm128_kernel<true, true>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0});
+#define GPR_GEMM128(TA_, TB_, FAST_) hipLaunchKernelGGL((gemm128_kernel<TA_, TB_, FAST_>), g2, b2, 0, st, m, n, k, alpha, a, lda, b, ldb, beta, c, ldc, lower_only, 0, (double *)nullptr, cyc_rule{0, 0, 0, 0, 0})
+        if (!ta && !tb) { if (fast) GPR_GEMM128(false, false, true); else GPR_GEMM128(false, false, false); }
+        else if (!ta && tb) { if (fast) GPR_GEMM128(false, true, true); else GPR_GEMM128(false, true, false); }
+        else if (ta && !tb) { if (fast) GPR_GEMM128(true, false, true); else GPR_GEMM128(true, false, false); }
+        else { if (fast) GPR_GEMM128(true, true, true); else GPR_GEMM128(true, true, false); }
+#undef GPR_GEMM128
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { gpr_set_error("gemm128 launch failed: %s", hipGetErrorString(e2)); return GPR_ERR_HIP; }
         return GPR_OK;

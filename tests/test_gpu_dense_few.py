@@ -56,24 +56,31 @@ def test_column_reductions_few_and_wide(n, cols):
     assert torch.equal(dev.gemv_t(A, x), gv) and torch.equal(dev.colsumsq(A), cs)
 
 
+@pytest.mark.parametrize("ta,tb", [(False, True), (False, False), (True, False), (True, True)])
 @pytest.mark.parametrize("m,n,k", [(300, 333, 16), (300, 333, 250), (257, 256, 257), (1000, 640, 1024), (129, 511, 40)])
-def test_tiled_product_of_two_k_contiguous_operands_reads_nothing_outside_them(m, n, k):
-    """C <- beta C + alpha A B^T through the 128 x 128-tile kernel in its predicate-free form (gemm128_kernel<false, true, true>:
-    the trailing update of gaussianprocess.py:175's Cholesky, scipy there): operands are views into NaN-filled arrays, so a
-    read beyond a row's k range, or below the last row, that reached an accumulator would show; alpha = -1, beta = 1 starts
-    the accumulators from C (the other combination goes through the read-modify-write epilogue); 1e-13 relative to torch"""
+def test_tiled_product_reads_nothing_outside_its_operands(m, n, k, ta, tb):
+    """C <- beta C + alpha op(A) op(B) through the 128 x 128-tile kernel in its predicate-free form (gemm128_kernel<.., .., true>;
+    the NT form is the trailing update of gaussianprocess.py:175's Cholesky, scipy there, the others carry the triangular inverse
+    and the Gram products of the fit): operands are views into NaN-filled arrays, so a read beyond the k range, or beyond the
+    last row or column, that reached an accumulator would show; alpha = -1, beta = 1 starts the accumulators from C, the other
+    combinations go through the plain and the read-modify-write epilogue; 1e-13 relative to torch"""
     from gpr_calculator_amd import device as dev
     torch.manual_seed(m + n + k)
     d = dev.device()
     nan = float("nan")
-    Abig = torch.full((m + 3, k + 5), nan, dtype=torch.float64, device=d)
-    Bbig = torch.full((n + 2, k + 9), nan, dtype=torch.float64, device=d)
-    Abig[:m, :k] = torch.randn(m, k, dtype=torch.float64, device=d)
-    Bbig[:n, :k] = torch.randn(n, k, dtype=torch.float64, device=d)
-    A, B = Abig[:m, :k], Bbig[:n, :k]
+
+    def operand(rows, cols):
+        big = torch.full((rows + 3, cols + 5), nan, dtype=torch.float64, device=d)
+        big[:rows, :cols] = torch.randn(rows, cols, dtype=torch.float64, device=d)
+        return big[:rows, :cols]
+
+    A = operand(k, m) if ta else operand(m, k)
+    B = operand(n, k) if tb else operand(k, n)
+    opA = A.contiguous().T if ta else A.contiguous()
+    opB = B.contiguous().T if tb else B.contiguous()
     C0 = torch.randn(m, n, dtype=torch.float64, device=d)
     for alpha, beta in ((-1.0, 1.0), (1.0, 0.0), (0.5, -2.0), (1.0, 0.25)):
-        ref = alpha * (A.contiguous() @ B.contiguous().T) + beta * C0
-        out = dev.gemm(A, B, transb=True, alpha=alpha, beta=beta, out=C0.clone())
+        ref = alpha * (opA @ opB) + beta * C0
+        out = dev.gemm(A, B, transa=ta, transb=tb, alpha=alpha, beta=beta, out=C0.clone())
         assert torch.isfinite(out).all()
         assert float((out - ref).abs().max() / ref.abs().max()) < 1e-13
