@@ -30,11 +30,15 @@ constexpr int TILE_DOUBLES = 256;      // one tile in operand order [s = 0..3][l
 __host__ __device__ constexpr int tile_base(int j) { return (15 - j) * (16 - j) / 2; }
 __host__ __device__ constexpr int tile_index(int i, int j) { return tile_base(j) + (i - j); }
 
-struct tile_map { unsigned char i[NTILE], j[NTILE]; };
+// ij[t] = i | j << 8: whole words, so that a wave-uniform t is a scalar load (there is no scalar byte load on this chip, and a
+// vector load of the table sat in front of the block's own loads, one round trip per tile)
+struct tile_map { unsigned char i[NTILE], j[NTILE]; int ij[NTILE]; };
 constexpr tile_map make_tile_map() {
     tile_map m{};
     for (int j = 0; j < 16; j++)
-        for (int i = j; i < 16; i++) { m.i[tile_index(i, j)] = (unsigned char)i; m.j[tile_index(i, j)] = (unsigned char)j; }
+        for (int i = j; i < 16; i++) {
+            m.i[tile_index(i, j)] = (unsigned char)i; m.j[tile_index(i, j)] = (unsigned char)j; m.ij[tile_index(i, j)] = i | (j << 8);
+        }
     return m;
 }
 __constant__ tile_map c_tiles = make_tile_map();
@@ -186,23 +190,36 @@ __global__ void __launch_bounds__(64 * DWAVES) potrf_diag256_kernel(double *__re
 #pragma unroll
     for (int s = 0; s < TSLOTS; s++) {
         const int t = s * TWAVES + tw;
-        tij[s] = -1;
-        acc[s] = d4{0.0, 0.0, 0.0, 0.0};
-        if (t < NTILE && c_tiles.i[t] < nt) {
-            const int ti = c_tiles.i[t], tj = c_tiles.j[t];
-            tij[s] = ti | (tj << 8);
-            const int row = ti * DT + lr;
+        int v = -1;
+        if (t < NTILE) { v = c_tiles.ij[t]; if ((v & 255) >= nt) v = -1; }
+        tij[s] = v;
+    }
+    // the block's 64 loads per lane carry no predicate (a load under a lane-dependent branch is waited for at the join: 64 round
+    // trips one after the other, a quarter of this kernel's time): addresses are clamped into the block, padding selected afterwards
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int col = tj * DT + lq + 4 * r;
-                acc[s][r] = (row < kb && col < kb) ? (PUB ? coherent_load(&a[(long long)row * lda + col]) : a[(long long)row * lda + col])
-                                                   : ((row == col) ? 1.0 : 0.0);
-            }
+    for (int s = 0; s < TSLOTS; s++) {
+        const int v = max(tij[s], 0), row = min((v & 255) * DT + lr, kb - 1);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = min((v >> 8) * DT + lq + 4 * r, kb - 1);
+            const double *src = (const double *)((const char *)a + (size_t)((unsigned)(row * (int)lda + col) * 8u));   // 32-bit lane offset
+            acc[s][r] = PUB ? coherent_load(src) : *src;
         }
+        if (s == TSLOTS / 2 - 1) __builtin_amdgcn_sched_barrier(0);      // two batches of 32: the addresses of 64 do not fit the registers
     }
     // tij[s] is read through an opaque move inside the stage loop: otherwise every address derived from it (LDS tile
     // bases, global rows, operand-order slots; 16 slots of each) is hoisted out of the loop and spilled to scratch
     auto slot = [&](int s) { int v = __builtin_amdgcn_readfirstlane(tij[s]); asm volatile("" : "+s"(v)); return v; };
+#pragma unroll
+    for (int s = 0; s < TSLOTS; s++) {
+        const int v0 = slot(s), v = max(v0, 0), row = (v & 255) * DT + lr;       // (opaque: recomputed, not kept across the loads)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int col = (v >> 8) * DT + lq + 4 * r;
+            if (v0 < 0) acc[s][r] = 0.0;
+            else if (!(row < kb && col < kb)) acc[s][r] = (row == col) ? 1.0 : 0.0;
+        }
+    }
     auto hand_over_diag = [&](int k) {                       // the owner of tile (k, k) puts it into S.dg
 #pragma unroll
         for (int s = 0; s < TSLOTS; s++)
@@ -299,8 +316,9 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
     for (int c = 0; c < 4; c++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const int col = (wave + 4 * c) * DT + lq + 4 * r;
-            t[c][r] = (rok && col < kb) ? p[(long long)(r0 + lr) * lda + col] : 0.0;
+            const int col = (wave + 4 * c) * DT + lq + 4 * r;             // no predicate on the load (see the diagonal kernel)
+            const double v = p[(long long)min(r0 + lr, rows - 1) * lda + min(col, kb - 1)];
+            t[c][r] = (rok && col < kb) ? v : 0.0;
         }
     }
     // tile u of stage k: u = 0 -> W_k, u >= 1 -> L_{k+u, k}
@@ -326,8 +344,8 @@ __global__ void __launch_bounds__(256) potrf_panel256_kernel(double *__restrict_
             const double *cur = ops[k & 1];
             double pf[15];
 #pragma unroll
-            for (int u = 0; u < 15 - k; u++)                 // stage k + 1 has nt - k - 1 tiles
-                if (k + 1 + u < nt) pf[u] = tile_elem(k + 1, u);
+            for (int u = 0; u < 15 - k; u++)                 // stage k + 1 has nt - k - 1 tiles (a tile beyond them: its W again)
+                if (FULL || k + 1 < nt) pf[u] = tile_elem(k + 1, (FULL || k + 1 + u < nt) ? u : 0);
             if (wave == (k & 3)) {                           // X_k^T = W_k P_k^T
                 d4 d = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
