@@ -45,25 +45,32 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
         for (int j = 0; j < 2; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
 
     for (int k0 = 0; k0 < k; k0 += BK) {
+        // the eight loads of a k tile carry no predicate (under a lane-dependent branch each is waited for at the join: eight round
+        // trips per tile): addresses clamped into the operand, what lies outside it becomes zero when it is stored to LDS
+        double va[4], vb[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             int mm, kk;
             if (!TA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
             else     { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
-            const int gm = bm0 + mm, gk = k0 + kk;
-            double v = 0.0;
-            if (gm < m && gk < k) v = TA ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk];
-            As[kk][mm] = v;
+            const int gm = min(bm0 + mm, m - 1), gk = min(k0 + kk, k - 1);
+            va[i] = TA ? A[(long long)gk * lda + gm] : A[(long long)gm * lda + gk];
+            int nn, kb;
+            if (!TB) { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
+            else     { kb = tid & 15; nn = (tid >> 4) + 16 * i; }
+            const int gn = min(bn0 + nn, n - 1), gk2 = min(k0 + kb, k - 1);
+            vb[i] = TB ? B[(long long)gn * ldb + gk2] : B[(long long)gk2 * ldb + gn];
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            int nn, kk;
-            if (!TB) { nn = tid & 63; kk = (tid >> 6) + 4 * i; }
-            else     { kk = tid & 15; nn = (tid >> 4) + 16 * i; }
-            const int gn = bn0 + nn, gk = k0 + kk;
-            double v = 0.0;
-            if (gn < n && gk < k) v = TB ? B[(long long)gn * ldb + gk] : B[(long long)gk * ldb + gn];
-            Bs[kk][nn] = v;
+            int mm, kk;
+            if (!TA) { kk = tid & 15; mm = (tid >> 4) + 16 * i; }
+            else     { mm = tid & 63; kk = (tid >> 6) + 4 * i; }
+            As[kk][mm] = (bm0 + mm < m && k0 + kk < k) ? va[i] : 0.0;
+            int nn, kb;
+            if (!TB) { nn = tid & 63; kb = (tid >> 6) + 4 * i; }
+            else     { kb = tid & 15; nn = (tid >> 4) + 16 * i; }
+            Bs[kb][nn] = (bn0 + nn < n && k0 + kb < k) ? vb[i] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -83,6 +90,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
         __syncthreads();
     }
     // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+    double cold[2][2][4];
+    if (beta != 0.0) {                               // the reads of C issued together (see the k loop)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    cold[i][j][r] = C[(long long)min(bm0 + wm + i * 16 + (lane >> 4) + 4 * r, m - 1) * ldc + min(bn0 + wn + j * 16 + (lane & 15), n - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -92,9 +109,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(int m, int n, int k, double a
                 const int gm = bm0 + wm + i * 16 + (lane >> 4) + 4 * r;
                 const int gn = bn0 + wn + j * 16 + (lane & 15);
                 if (gm < m && gn < n) {
-                    double *c = C + (long long)gm * ldc + gn;
                     const double v = alpha * acc[i][j][r];
-                    *c = (beta == 0.0) ? v : v + beta * *c;
+                    C[(long long)gm * ldc + gn] = (beta == 0.0) ? v : v + beta * cold[i][j][r];
                 }
             }
 }
@@ -1581,12 +1597,14 @@ __global__ void __launch_bounds__(512) syrk_bulk_kernel(int m, int k, const doub
 #pragma unroll
             for (int j = 0; j < 4; j++) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
         double ra[4], rb[4];
+        // no predicate on any load of this kernel (a load under a lane-dependent branch is waited for at the join, one round trip
+        // after the other): rows beyond the panel are clamped to its last row -- their products are never stored
         auto load_tile = [&](int k0) {
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const int gm = bm0 + lr + 32 * i, gn = bn0 + lr + 32 * i;
-                ra[i] = gm < m ? P[(long long)gm * ldp + k0 + lk] : 0.0;
-                rb[i] = gn < m ? P[(long long)gn * ldp + k0 + lk] : 0.0;
+                const int gm = min(bm0 + lr + 32 * i, m - 1), gn = min(bn0 + lr + 32 * i, m - 1);
+                ra[i] = P[(long long)gm * ldp + k0 + lk];
+                rb[i] = P[(long long)gn * ldp + k0 + lk];
             }
         };
         auto store_tile = [&](int buf) {
@@ -1615,6 +1633,18 @@ __global__ void __launch_bounds__(512) syrk_bulk_kernel(int m, int k, const doub
             if (kt + 1 < nkt) store_tile(buf ^ 1);
             __syncthreads();
         }
+        // C -= acc: the 32 reads of C issued together, then the stores (one by one under the predicate they were 32 round trips,
+        // longer than the k = 256 product of the tile)
+        double cold[2][4][4];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int gm = min(bm0 + wm + 16 * i + (lane >> 4) + 4 * r, m - 1), gn = min(bn0 + wn + 16 * j + (lane & 15), m - 1);
+                    cold[i][j][r] = C[(long long)gm * ldc + gn];
+                }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -1622,7 +1652,7 @@ __global__ void __launch_bounds__(512) syrk_bulk_kernel(int m, int k, const doub
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int gm = bm0 + wm + 16 * i + (lane >> 4) + 4 * r, gn = bn0 + wn + 16 * j + (lane & 15);
-                    if (gm < m && gn < m) C[(long long)gm * ldc + gn] -= acc[i][j][r];
+                    if (gm < m && gn < m) C[(long long)gm * ldc + gn] = cold[i][j][r] - acc[i][j][r];
                 }
     }
 }

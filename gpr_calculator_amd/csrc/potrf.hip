@@ -446,6 +446,12 @@ __global__ void __launch_bounds__(256) syrk_narrow_kernel(int m, int n, const do
         xa[c][0] = *(const d4u *)(a0 + 16 * c); xa[c][1] = *(const d4u *)(a1 + 16 * c);
         xb[c][0] = *(const d4u *)(b0 + 16 * c); xb[c][1] = *(const d4u *)(b1 + 16 * c);
     }
+    // the four entries of C this lane will update, requested with the operands (under the predicate of the epilogue they were
+    // four round trips one after the other at the end of a link of the chain); nothing else writes them while this kernel runs
+    double cold[4];
+#pragma unroll
+    for (int e = 0; e < 4; e++)
+        cold[e] = C[(long long)min(row0 + 16 * (wave >> 1) + q + 4 * e, m - 1) * ldc + min(col0 + 16 * (wave & 1) + r, n - 1)];
     d4 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; i++)
@@ -474,8 +480,8 @@ __global__ void __launch_bounds__(256) syrk_narrow_kernel(int m, int n, const do
         const double v = (part[0][wave][e * 64 + lane] + part[1][wave][e * 64 + lane]) + (part[2][wave][e * 64 + lane] + part[3][wave][e * 64 + lane]);
         if (gm < m && gn < n) {
             double *c = C + (long long)gm * ldc + gn;
-            if (done) coherent_store(c, *c - v);
-            else *c -= v;
+            if (done) coherent_store(c, cold[e] - v);
+            else *c = cold[e] - v;
         }
     }
     if (done) {
