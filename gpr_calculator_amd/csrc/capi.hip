@@ -6,8 +6,7 @@ static int zero_block(hipStream_t st, double *p, long long ld, long long rows, l
     if (rows <= 0 || cols <= 0) return GPR_OK;
     GPR_REQUIRE(p != nullptr, "block: null output pointer");
     GPR_REQUIRE(ld >= cols, "block: leading dimension %lld < %lld columns", ld, cols);
-    GPR_HIP_TRY(hipMemset2DAsync(p, (size_t)ld * 8, 0, (size_t)cols * 8, (size_t)rows, st));
-    return GPR_OK;
+    return gpr_zero_2d(st, p, ld, rows, cols);
 }
 
 static void fill_kernel(gpr_block_call &c, const gpr_kernel_params *kp) {

@@ -1498,6 +1498,21 @@ __global__ void mirror_lower_kernel(int n, double *a, long long lda) {       // 
 
 // upper triangle <- transpose of the lower one, in place (a covariance matrix assembled as row slabs that hold the
 // lower trapezoid only)
+__global__ void __launch_bounds__(256) zero2d_kernel(double *p, long long ld, long long cols) {
+    double *row = p + (long long)blockIdx.y * ld;
+    for (long long c = (long long)blockIdx.x * 1024 + threadIdx.x; c < min(cols, ((long long)blockIdx.x + 1) * 1024); c += 256) row[c] = 0.0;
+}
+
+int gpr_zero_2d(hipStream_t st, double *p, long long ld, long long rows, long long cols) {
+    if (rows <= 0 || cols <= 0) return GPR_OK;
+    if (ld == cols || rows == 1) { GPR_HIP_TRY(hipMemsetAsync(p, 0, (size_t)(rows == 1 ? cols : rows * cols) * 8, st)); return GPR_OK; }
+    if (rows > 65535) { GPR_HIP_TRY(hipMemset2DAsync(p, (size_t)ld * 8, 0, (size_t)cols * 8, (size_t)rows, st)); return GPR_OK; }
+    hipLaunchKernelGGL(zero2d_kernel, dim3((unsigned)((cols + 1023) / 1024), (unsigned)rows), dim3(256), 0, st, p, ld, cols);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { gpr_set_error("zero2d launch failed: %s", hipGetErrorString(e)); return GPR_ERR_HIP; }
+    return GPR_OK;
+}
+
 extern "C" int gpr_mirror_lower(void *stream, int n, double *a, long long lda) {
     GPR_REQUIRE(n >= 0 && (n == 0 || a) && lda >= n, "gpr_mirror_lower: bad arguments");
     if (n < 2) return GPR_OK;

@@ -612,7 +612,7 @@ extern "C" int gpr_dot2_features(void *stream, const gpr_set *set, int ns, const
     GPR_REQUIRE(out && ld >= F, "gpr_dot2_features: output leading dimension %lld < %d", ld, F);
     if (set->npts == 0) return GPR_OK;
     const long long rows = (long long)set->npts * (set->nc == 4 ? 3 : 1);
-    GPR_HIP_TRY(hipMemset2DAsync(out, (size_t)ld * 8, 0, (size_t)F * 8, (size_t)rows, st));   // points without rows
+    { const int zrc_ = gpr_zero_2d(st, out, ld, rows, F); if (zrc_) return zrc_; }   // points without rows
     feat_args A;
     A.ops = set->ops; A.ele = set->ele; A.chunks = set->chunks; A.pt_chunk0 = set->pt_chunk0; A.perm = set->perm;
     A.inv_cnt = set->inv_cnt; A.npts = set->npts; A.nc = set->nc; A.d = set->d; A.npair = npair; A.ns = ns;

@@ -146,6 +146,9 @@ int gpr_ws_tail_internal(void *stream, int m, int n, const double *P, long long 
 int gpr_func_lds_once(const void *fn, int bytes);
 int gpr_cu_count();                                 // compute units of the current device (cached per device)
 int gpr_dev_alloc(void **p, size_t bytes, hipStream_t st);
+// zeros a [rows x cols] block of doubles with leading dimension ld (one memset when it is contiguous, a coalesced fill kernel otherwise:
+// the runtime's 2-D fill does 0.8 TB/s on a 6063 x 6063 block)
+int gpr_zero_2d(hipStream_t st, double *p, long long ld, long long rows, long long cols);
 int gpr_dev_free(void *p, hipStream_t st);
 int gpr_dev_cache_drop_stream(hipStream_t st);      // before hipStreamDestroy: cached temporaries of that stream go back to the driver
 void gpr_reap_sets();   // frees the host side of destroyed sets whose stream work has completed
