@@ -84,3 +84,27 @@ def test_tiled_product_reads_nothing_outside_its_operands(m, n, k, ta, tb):
         out = dev.gemm(A, B, transa=ta, transb=tb, alpha=alpha, beta=beta, out=C0.clone())
         assert torch.isfinite(out).all()
         assert float((out - ref).abs().max() / ref.abs().max()) < 1e-13
+
+
+@pytest.mark.parametrize("m,k", [(1, 64), (5, 100), (97, 466), (1000, 63), (6063, 2500)])
+def test_product_with_one_right_hand_side(m, k):
+    """gpr_gemm with n = 1 and A not transposed takes the row-per-wavefront matrix-vector kernel (k >= 64; below that the tiled
+    one): against torch, 1e-13 relative to |A| |x|; strided A and x (a column of a wider matrix), beta != 0, and the [1, k] row
+    form of x"""
+    from gpr_calculator_amd import device as dev
+    torch.manual_seed(m + k)
+    d = dev.device()
+    big = torch.randn(m, k + 3, dtype=torch.float64, device=d)
+    A = big[:, :k]
+    xs = torch.randn(k, 4, dtype=torch.float64, device=d)
+    x = xs[:, 2:3]
+    scale = float((A.abs() @ x.abs()).max())
+    ref = A @ x
+    out = dev.gemm(A, x)
+    assert float((out - ref).abs().max()) < 1e-13 * scale
+    c0 = torch.randn(m, 1, dtype=torch.float64, device=d)
+    out2 = dev.gemm(A, x, alpha=-0.5, beta=2.0, out=c0.clone())
+    assert float((out2 - (-0.5 * ref + 2.0 * c0)).abs().max()) < 1e-13 * (scale + float(c0.abs().max()))
+    xr = x.reshape(1, k).contiguous()
+    out3 = dev.gemm(A, xr, transb=True)
+    assert float((out3 - ref).abs().max()) < 1e-13 * scale
