@@ -1472,7 +1472,8 @@ int launch_gemm(hipStream_t st, int ta, int tb, int m, int n, int k, double alph
         // tall-skinny A^T B (the F x F Gram matrices of the weight-space fit: a handful of tiles, k in the thousands):
         // slices of k on blockIdx.z, partial tiles to a workspace, summed in slice order
         const int tiles = (int)(g2.x * g2.y);
-        const bool fast = lda < (1 << 21) && ldb < (1 << 21) && !getenv("GPR_GEMM_GENERIC");
+        static const bool generic_env = getenv("GPR_GEMM_GENERIC") != nullptr;
+        const bool fast = lda < (1 << 21) && ldb < (1 << 21) && !generic_env;
         if (ta && !tb && !lower_only && tiles <= 64 && k >= 2048) {
             int nz = std::min(256 / tiles, k / 512);
             const int ksplit = ((k + nz - 1) / nz + GK - 1) / GK * GK;
