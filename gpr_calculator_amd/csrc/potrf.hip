@@ -399,10 +399,12 @@ __global__ void __launch_bounds__(64) tri_inv64_kernel(const double *__restrict_
                                                         double *__restrict__ dinv) {
     __shared__ double T[64][65];
     const int b = blockIdx.x, k0 = b * 64, kb = min(64, n - k0), c = threadIdx.x;
-    for (int i = 0; i < 64; i++) {
-        double v = (i == c) ? 1.0 : 0.0;
-        if (i < kb && c < kb) v = (c <= i) ? a[(long long)(k0 + i) * lda + k0 + c] : 0.0;
-        T[i][c] = v;
+    {   // the block's 64 loads per lane without predicates (one by one under a branch: 64 round trips, most of this kernel's 35 us)
+        double t[64];
+#pragma unroll
+        for (int i = 0; i < 64; i++) t[i] = a[(long long)(k0 + min(i, kb - 1)) * lda + k0 + min(c, kb - 1)];
+#pragma unroll
+        for (int i = 0; i < 64; i++) T[i][c] = (i < kb && c < kb) ? ((c <= i) ? t[i] : 0.0) : ((i == c) ? 1.0 : 0.0);
     }
     __syncthreads();
     double acc[64];
