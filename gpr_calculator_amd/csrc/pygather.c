@@ -113,8 +113,12 @@ static PyObject *gather(PyObject *self, PyObject *arg) {
             else PyErr_Clear();
         }
     }
-    if (plain) result = Py_BuildValue("(OOOOOOO)", b_atom0, b_num, b_pos, b_cells, b_pbc, any_fixed ? Py_True : Py_False,
-                                      (b_mask && !unresolved) ? b_mask : Py_None);
+    /* element 7: (addresses of atom0, numbers, positions, cells, pbc, number of atoms) -- the caller hands them to the C-ABI as they
+       are (an array view and its .ctypes.data per buffer cost more host time than this whole pass) */
+    if (plain) result = Py_BuildValue("(OOOOOOO(nnnnnn))", b_atom0, b_num, b_pos, b_cells, b_pbc, any_fixed ? Py_True : Py_False,
+                                      (b_mask && !unresolved) ? b_mask : Py_None,
+                                      (Py_ssize_t)(size_t)atom0, (Py_ssize_t)(size_t)numbers, (Py_ssize_t)(size_t)pos, (Py_ssize_t)(size_t)cells,
+                                      (Py_ssize_t)(size_t)pbc, (Py_ssize_t)N);
 done:
     Py_XDECREF(b_atom0); Py_XDECREF(b_cells); Py_XDECREF(b_pbc); Py_XDECREF(b_num); Py_XDECREF(b_pos); Py_XDECREF(b_mask);
     Py_DECREF(seq);

@@ -1201,8 +1201,11 @@ class GP():
         if self._session_depth_set != int(self.session_depth):           # follows the attribute, also on a live session
             dev.check(_lib.lib().gpr_dot2_session_set_depth(ses[1], int(self.session_depth)), "gpr_dot2_session_set_depth")
             self._session_depth_set = int(self.session_depth)
+        # the gathered buffers go to the C-ABI by the addresses the gathering pass returns with them (five array views and their
+        # .ctypes.data were a third of the host time before the call); `got` keeps them alive
+        p_a0, p_num, p_pos, p_cells, p_pbc, natoms = got[7]
         a0 = np.frombuffer(got[0], dtype=np.int32)
-        nS, natoms = len(strucs), int(a0[-1])
+        nS = len(strucs)
         fixed = None
         if got[5]:                                                       # some structure carries fixed atoms
             free = np.frombuffer(got[6], dtype=np.uint8)
@@ -1210,24 +1213,22 @@ class GP():
                 fixed = np.ascontiguousarray(free == 0).view(np.uint8)
         E, F = np.empty(nS), np.empty((natoms, 3))
         Es, Fs = (np.empty(nS), np.empty((natoms, 3))) if return_std else (None, None)
-        vp = lambda a: None if a is None else a.ctypes.data
-        ins = (a0, np.frombuffer(got[2], dtype=np.float64), np.frombuffer(got[3], dtype=np.float64),
-               np.frombuffer(got[4], dtype=np.int32), np.frombuffer(got[1], dtype=np.int32), fixed)
+        vp = lambda a: None if a is None else a.__array_interface__["data"][0]
         if tr is not None:
             tr.append(("native call", time.perf_counter_ns()))
         if sync:
             dev.check(_lib.lib().gpr_dot2_session_predict(
-                ses[1], nS, ins[0].ctypes.data, ins[1].ctypes.data, ins[2].ctypes.data, ins[3].ctypes.data, ins[4].ctypes.data,
-                vp(fixed), E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None), "gpr_dot2_session_predict")
+                ses[1], nS, p_a0, p_pos, p_cells, p_pbc, p_num,
+                vp(fixed), vp(E), vp(F), vp(Es), vp(Fs), None), "gpr_dot2_session_predict")
             if tr is not None:
                 tr.append(("native done", time.perf_counter_ns()))
             return self._session_shape(a0, nS, natoms, return_std, E, F, Es, Fs)
         ticket = C.c_int(-1)
         dev.check(_lib.lib().gpr_dot2_session_submit(
-            ses[1], nS, ins[0].ctypes.data, ins[1].ctypes.data, ins[2].ctypes.data, ins[3].ctypes.data, ins[4].ctypes.data,
+            ses[1], nS, p_a0, p_pos, p_cells, p_pbc, p_num,
             vp(fixed), C.byref(ticket)), "gpr_dot2_session_submit")
         # the ticket keeps the gathered input buffers alive until the results are collected
-        return _SessionTicket(ses, int(ticket.value), (got, ins), (a0, nS, natoms, return_std, E, F, Es, Fs))
+        return _SessionTicket(ses, int(ticket.value), (got, fixed), (a0, nS, natoms, return_std, E, F, Es, Fs))
 
     @staticmethod
     def _session_shape(a0, nS, natoms, return_std, E, F, Es, Fs):
@@ -1269,8 +1270,8 @@ class GP():
             raise RuntimeError("the model was refitted while this batch was in flight; its session is gone")
         from . import _lib
         a0, nS, natoms, return_std, E, F, Es, Fs = out
-        vp = lambda a: None if a is None else a.ctypes.data
-        dev.check(_lib.lib().gpr_dot2_session_wait(ses[1], k, E.ctypes.data, F.ctypes.data, vp(Es), vp(Fs), None), "gpr_dot2_session_wait")
+        vp = lambda a: None if a is None else a.__array_interface__["data"][0]
+        dev.check(_lib.lib().gpr_dot2_session_wait(ses[1], k, vp(E), vp(F), vp(Es), vp(Fs), None), "gpr_dot2_session_wait")
         ticket.ses = ticket.keep = None
         return self._session_shape(a0, nS, natoms, return_std, E, F, Es, Fs)
 

@@ -131,8 +131,11 @@ def test_c_gather_matches_numpy_batch_arrays():
         n = 3 + 2 * k
         strucs.append(SimpleAtoms(numbers=rng.choice([8, 46, 78], n), positions=rng.normal(size=(n, 3)),
                                   cell=rng.normal(size=(3, 3)) + 5 * np.eye(3), pbc=[True, k % 2 == 0, False]))
-    a0, num, pos, cel, pbc, fixed, cmask = _pygather.gather(strucs)
+    a0, num, pos, cel, pbc, fixed, cmask, addr = _pygather.gather(strucs)
     ref = batch_arrays(strucs)
+    # element 7: the buffers' addresses (atom0, numbers, positions, cells, pbc) and the number of atoms, as the C-ABI takes them
+    assert addr[5] == int(ref[0][-1])
+    assert [np.frombuffer(b, np.uint8).ctypes.data for b in (a0, num, pos, cel, pbc)] == list(addr[:5])
     assert np.array_equal(np.frombuffer(a0, np.int32), ref[0]) and np.array_equal(np.frombuffer(num, np.int32), ref[1])
     assert np.array_equal(np.frombuffer(pos, np.float64).reshape(-1, 3), ref[2])
     assert np.array_equal(np.frombuffer(cel, np.float64).reshape(-1, 9), ref[3])
