@@ -39,7 +39,7 @@ try:                                     # host-side marshalling helper (CPython
     from . import _pygather
 except ImportError:
     _pygather = None
-from .parallel import Comm
+from .parallel import Comm, multi
 from .utilities import (convert_train_data, list_to_tuple, metric_values, new_pt, species_numbers,
                         tuple_to_list)
 
@@ -417,7 +417,7 @@ class GP():
             assert K.shape[0] == len(y_train), (K.shape, len(y_train))
             dev.add_diag_(K, NE, self.noise_e ** 2, self.noise_f ** 2)
             return K
-        if not lazy and self.comm.size > 1 and len(y_train) >= self.dist_chol_min_n:
+        if not lazy and multi(self.comm) and len(y_train) >= self.dist_chol_min_n:
             # rows of K block-cyclic over the ranks, panels exchanged over RCCL (distributed.py); L comes back replicated
             from .distributed import DeviceOps, potrf_distributed
             K, dinv, info = potrf_distributed(build(), self.comm, DeviceOps())
@@ -448,7 +448,7 @@ class GP():
     def _try_append_dense(self):
         d = self._dense
         if (not self.incremental_fit or not self._fitted or self._dense_pending or d["L"] is None or self.N_queue <= 0
-                or self.comm.size > 1 or getattr(self, "_fit_train_x", None) is None):
+                or multi(self.comm) or getattr(self, "_fit_train_x", None) is None):
             return False
         if hasattr(self.kernel, "_feature_path") and self.kernel._feature_path(self.train_x, None, self.kernel.zeta) is not None:
             return False            # explicit feature map (Dot, zeta = 2): the F x F weight-space system is refitted anyway
@@ -535,7 +535,7 @@ class GP():
         kernel = self.kernel
         NE_all = self._n_energy_points(train_x)
         y_all = np.asarray(self.y_train).reshape(-1)
-        if self.comm.size > 1:
+        if multi(self.comm):
             from .distributed import shard_points, slice_energy, slice_force
             E, Fc = train_x["energy"], train_x["force"]
             key = (id(E[0]), id(Fc[0]), self.comm.rank, self.comm.size)
@@ -964,7 +964,7 @@ class GP():
         device-resident route as predict_structures -- neighbour search, descriptor, regrouping and prediction
         without a host copy of x / dxdr; `device_single = False` selects the tuple route below, which is also the
         one for stress, for several ranks and for foreign descriptors."""
-        if (not stress and self.device_single and self.comm.size == 1
+        if (not stress and self.device_single and not multi(self.comm)
                 and hasattr(self.descriptor, "calculate_batch_dev")):
             Es, Fs, Es_std, Fs_std = self.predict_structures([struc], return_std=return_std, f_tol=f_tol)
             if return_std:
@@ -1253,7 +1253,7 @@ class GP():
         batch while the device works on the others -- the throughput form of the call (an image band evaluated batch
         after batch); same numbers as predict_structures, bit for bit.  Models or batches the session route does not take
         (other kernels, several ranks, a base potential) are evaluated on the spot and the ticket only carries the result."""
-        if self.comm.size == 1 and len(strucs) and self.session_batch:
+        if not multi(self.comm) and len(strucs) and self.session_batch:
             t = self._session_submit(strucs, return_std, sync=False)
             if t is not None:
                 return t
@@ -1305,7 +1305,8 @@ class GP():
         equally sized structures on one rank -- arrays whose first axis is the structure."""
         nb = len(strucs)
         size, rank = self.comm.size, self.comm.rank
-        if size == 1 and nb and self.session_batch:
+        many = multi(self.comm)          # several ranks (or the one-rank rehearsal of their code path: parallel.multi)
+        if not many and nb and self.session_batch:
             fast = self._predict_batch_session(strucs, return_std)
             if fast is not None:
                 return fast
@@ -1332,7 +1333,7 @@ class GP():
                 n = ns_atoms[0]
                 Eb = mean[:nS] * n
                 Fb = mean[nS:].reshape(nS, n, 3)
-                if size == 1:                    # one rank owns the whole batch: the slices are the answer
+                if not many:                     # one rank owns the whole batch: the slices are the answer
                     if return_std:
                         return list(Eb), list(Fb), list(std[:nS]), list(std[nS:].reshape(nS, n, 3))
                     return list(Eb), list(Fb), [None] * nS, [None] * nS
@@ -1389,7 +1390,7 @@ class GP():
                 else:
                     results[k] = (E, F, None, None)
                 off += nf
-        if size > 1:
+        if many:
             # every rank knows the whole batch, hence where each structure's numbers go in one flat vector
             # [E, E_std, F (3n), F_std (3n)]: the ranks fill their own structures and ONE tensor all-reduce (zeros
             # elsewhere, so the sum is exact) leaves the complete vector everywhere -- nothing is pickled

@@ -9,6 +9,7 @@ import torch
 
 from .. import _lib
 from .. import device as dev
+from ..parallel import multi
 from ..utilities import list_to_tuple
 
 
@@ -106,7 +107,7 @@ class DeviceKernel:
         are cut into contiguous shards, every rank computes the lower-trapezoid row slab of its shard and the slabs are
         all-gathered (distributed.assemble_sharded).  Two different sets: the point-pair tasks of every block are dealt
         round-robin to the ranks and the partial matrices summed with one all-reduce (each element has one owner)."""
-        if comm is not None and comm.size > 1 and data2 is None and not transpose:
+        if multi(comm) and data2 is None and not transpose:
             from ..distributed import DeviceOps, assemble_sharded
 
             def block_fn(d1, d2):
@@ -115,7 +116,7 @@ class DeviceKernel:
             mats = assemble_sharded(data1, comm, block_fn, DeviceOps(), nmat=2 if grad else 1)
             nE = n_points(data1["energy"]) if "energy" in data1 and len(data1["energy"]) > 0 else 0
             return (mats[0], mats[1], nE) if grad else mats[0]
-        if comm is not None and comm.size > 1:
+        if multi(comm):
             dev.set_shard(comm.size, comm.rank)
             try:
                 out = self._assemble(data1, data2, kp_ee, kp_ef, kp_ff, grad=grad, transpose=transpose)

@@ -8,11 +8,28 @@ import torch
 import torch.distributed as dist
 
 
+# GPR_DIST_FORCE=1: a world of ONE still goes through the backend (process group initialised, no single-rank short cuts in the
+# tensor collectives) -- the rehearsal of the RCCL code paths a one-GPU box allows (tools/rccl_one_rank.py, tests/test_gpu_ranks.py)
+_FORCE = os.environ.get("GPR_DIST_FORCE") == "1"
+
+
+def multi(comm):
+    """True when the multi-rank code paths are to run on `comm`: several ranks -- or the rehearsal switch with an initialised
+    backend and one rank (the sharded assembly, the block-cyclic factorisation, the weight-space all-reduce and the strong-scaled
+    prediction then run with a world of one, every exchange a call into the backend)"""
+    return comm is not None and (comm.size > 1 or (_FORCE and bool(getattr(comm, "active", False))))
+
+
 class Comm:
     """World communicator; degrades to a serial no-op when torch.distributed is not initialised."""
 
     def __init__(self, group=None):
         self.group = group
+
+    @property
+    def _solo(self):
+        """nothing to exchange: not initialised, or one rank (unless the rehearsal switch sends that through the backend too)"""
+        return not self.active or (self.size == 1 and not _FORCE)
 
     @property
     def active(self):
@@ -39,7 +56,7 @@ class Comm:
     Barrier = barrier
 
     def bcast(self, obj, root=0):
-        if not self.active or self.size == 1:
+        if self._solo:
             return obj
         box = [obj]
         dist.broadcast_object_list(box, src=root, group=self.group)
@@ -48,7 +65,7 @@ class Comm:
     def allreduce(self, value, op=None):
         """sum of a python float / numpy array over ranks (gaussianprocess.py:246-247): one tensor all-reduce, nothing
         pickled"""
-        if not self.active or self.size == 1:
+        if self._solo:
             return value
         import numpy as np
         arr = np.asarray(value, dtype=np.float64)
@@ -75,7 +92,7 @@ class Comm:
         (allocated here when None).  Equal slabs: one all_gather_into_tensor.  Ragged slabs: rank r's slab is broadcast
         into its rows of `out` -- every element crosses a link once and lands where it stays; there is no padded
         staging copy and no concatenation (a 24 250^2 matrix is 4.7 GB: each avoided copy is one of those)."""
-        if not self.active or self.size == 1:
+        if self._solo:
             if out is None:
                 return local
             out[:local.shape[0]].copy_(local)
@@ -112,7 +129,7 @@ class Comm:
           * unequal slabs on RCCL: all_gather with a list of views -- torch issues the G broadcasts of such a call as one
             grouped launch (ncclGroupStart / End), every broadcast writing its rows of `full` directly;
           * otherwise (gloo wants equal sizes; empty slabs): one asynchronous broadcast per slab, waited for together."""
-        if not self.active or self.size == 1:
+        if self._solo:
             return full
         G = self.size
         slabs = [(int(o), int(c), int(r)) for o, c, r in zip(row0, counts, owners)]
@@ -145,17 +162,17 @@ class Comm:
         return r if self.group is None else dist.get_global_rank(self.group, r)
 
     def all_reduce_sum_(self, t):
-        if self.active and self.size > 1:
+        if not self._solo:
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def all_reduce_max_(self, t):
-        if self.active and self.size > 1:
+        if not self._solo:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return t
 
     def broadcast_(self, t, root=0):
-        if self.active and self.size > 1:
+        if not self._solo:
             dist.broadcast(t, src=self._global_rank(root), group=self.group)
         return t
 
@@ -163,7 +180,7 @@ class Comm:
 def init_from_env(backend=None):
     """torchrun-style initialisation (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*); returns Comm"""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _FORCE) and not dist.is_initialized():
         if backend is None:
             # GPR_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal of the N > 1 path on a
             # one-GPU box: RCCL refuses two ranks on the same device)

@@ -71,12 +71,12 @@ class _Serial:
 def main():
     from gpr_calculator_amd import _lib, device as dev
     from gpr_calculator_amd.distributed import DeviceOps, potrf_distributed
-    from gpr_calculator_amd.parallel import init_from_env
+    from gpr_calculator_amd.parallel import init_from_env, multi
     from gpr_calculator_amd.synthetic import fcc_cell, neb_images
     comm = init_from_env()
     _lib.require_gpu()
     rank, size = comm.rank, comm.size
-    backend = dist.get_backend() if size > 1 else None
+    backend = dist.get_backend() if dist.is_initialized() else None
     d = dev.device()
     report = {"ranks": size, "backend": backend, "devices": torch.cuda.device_count()}
     t_all = time.perf_counter()
@@ -116,7 +116,8 @@ def main():
     Kg1 = gp1.kernel.k_total_with_grad_dev(gp1.train_x)
     K = gp1.kernel.k_total_dev(gp1.train_x, comm=comm)
     Kg = gp1.kernel.k_total_with_grad_dev(gp1.train_x, comm=comm)
-    assert rel(K, K1) < 1e-13 and bool(torch.equal(K, K.T)) and rel(Kg[0], Kg1[0]) < 1e-13 and rel(Kg[1], Kg1[1]) < 1e-13
+    # (exact symmetry is what the mirrored slabs of the sharded assembly give; an unforced world of one takes the single-rank launch)
+    assert rel(K, K1) < 1e-13 and (not multi(comm) or bool(torch.equal(K, K.T))) and rel(Kg[0], Kg1[0]) < 1e-13 and rel(Kg[1], Kg1[1]) < 1e-13
     report["assembly_rel"] = rel(K, K1)
 
     # ---- 3. block-cyclic Cholesky with look-ahead
