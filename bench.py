@@ -114,6 +114,8 @@ def fit_mode(args, comm, gp, dev):
     from GP.dist_chol_min_n rows on) + alpha on the dense route; per-rank feature rows + all-reduce of the F x F system
     on the weight-space route of the Dot kernel at zeta = 2."""
     rank, world = comm.rank, comm.size
+    from gpr_calculator_amd.parallel import multi
+    many = multi(comm)          # several ranks -- or their code path rehearsed with one (GPR_DIST_FORCE=1, tools/rccl_one_rank.py)
     results = {}
     for route, ws in (("dense", False), ("weight_space", True)):
         if ws and args.kernel != "Dot":
@@ -127,7 +129,7 @@ def fit_mode(args, comm, gp, dev):
             gp.fit(show=False, opt=False)
         torch.cuda.synchronize(); comm.barrier()
         el = time.perf_counter() - t0
-        if world > 1:
+        if many:
             t = torch.tensor([el], dtype=torch.float64, device="cuda")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
             el = float(t.item())
@@ -248,16 +250,18 @@ def main():
     from gpr_calculator_amd.synthetic import neb_images
     comm = init_from_env()
     rank, world = comm.rank, comm.size
+    from gpr_calculator_amd.parallel import multi
+    many = multi(comm)          # several ranks -- or their code path rehearsed with one (GPR_DIST_FORCE=1)
     if world == 1:
         torch.cuda.set_device(0)
     _lib.require_gpu()
 
     gp = build_model(args.kernel, args.n_train, comm)
-    if world > 1:
+    if many:
         assert gp.comm.size == world, (gp.comm.size, world)
     if args.mode == "fit":
         fit_mode(args, comm, gp, dev)
-        if world > 1:
+        if many:
             torch.distributed.destroy_process_group()
         return
     # fit(opt=False): with the Dot kernel at zeta = 2 the model is fitted in weight space (F x F system); the dense
@@ -305,7 +309,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = dev.profile_fetch()
     dev.profile_enable(False)
-    if world > 1:
+    if many:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -340,7 +344,7 @@ def main():
     # --- outside the metric, N > 1: the SAME 64-structure batch dealt over the ranks by structure (strong scaling of one
     # prediction; results come back through one tensor all-reduce), next to the weak-scaled headline
     strong = None
-    if world > 1:
+    if many:
         gp.comm = real_comm
         shared = neb_images(args.batch, seed=100)
         for _ in range(5):
@@ -503,11 +507,11 @@ def main():
                            "batches_in_flight": depth if pipelined else 1,
                            "sync_ms_per_step": sync_ms, "sync_structures_per_s": args.batch / (sync_ms * 1e-3),
                            "sustained": sustained, "strong_predict": strong,
-                           "ranks": world, "backend": (torch.distributed.get_backend() if world > 1 else None),
+                           "ranks": world, "backend": (torch.distributed.get_backend() if many else None),
                            "parallelism": f"replicated model, structure-parallel predict x{world}; fit K sharded x{world}"},
                 "roofline": roofline, "cpu_baseline": cpu}
         print(json.dumps(line))
-    if world > 1:
+    if many:
         torch.distributed.destroy_process_group()
 
 

@@ -57,6 +57,7 @@ _L1_SIGNATURES = {
     "gpr_dot2_session_set_depth": ([_vp, _i], _i),
     "gpr_dot2_session_destroy": ([_vp], _i),
     "gpr_dot2_session_slot_stream": ([_vp, _i], _vp),
+    "gpr_dot2_session_reserve_streams": ([], _i),
     "gpr_dev_cache_count": ([_vp, _i], _i),
     "gpr_trsv_chain_fallbacks": ([], _i),
     "gpr_trsv_debug_max_polls": ([_i], _i),

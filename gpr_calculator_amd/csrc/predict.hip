@@ -6,6 +6,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
 #include "gpr_internal.h"
 
 // set by the session call around gpr_predict_dot2_batch: the tail kernel then writes standard deviations (the session
@@ -152,7 +155,7 @@ extern "C" int gpr_predict_dot2_batch(void *stream, int nmax, int lmax, double r
 constexpr int SESSION_SLOTS = 8;
 struct session_slot {
     hipStream_t st = nullptr;       // slot 0: the caller's stream (which may be the null stream)
-    bool has_stream = false, own_stream = false;
+    bool has_stream = false, own_stream = false, pooled = false;      // pooled: a stream of the device's slot pool (never destroyed)
     double *pin = nullptr;          // page-locked [2 m + 4]
     double *pin_dev = nullptr;      // its device address
     long long pin_cap = 0;
@@ -214,6 +217,7 @@ extern "C" int gpr_dot2_session_destroy(gpr_dot2_session *s) {
         if (sl.busy && sl.has_stream) (void)hipStreamSynchronize(sl.st);      // the device still writes into sl.pin
         if (sl.pin) (void)hipHostFree(sl.pin);
         if (sl.own_stream && sl.st) { (void)gpr_dev_cache_drop_stream(sl.st); (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); }
+        else if (sl.pooled && sl.st) { (void)hipStreamSynchronize(sl.st); (void)gpr_dev_cache_drop_stream(sl.st); }
     }
     if (s->model_ready) (void)hipEventDestroy(s->model_ready);
     (void)hipGetLastError();
@@ -227,12 +231,69 @@ extern "C" void *gpr_dot2_session_slot_stream(gpr_dot2_session *s, int k) {
     return (void *)s->slot[k].st;
 }
 
+// ---- the slots' streams come from a pool per device that is reserved EARLY (gpr_dot2_session_reserve_streams: the Python layer
+// calls it at its first use of a device, before anything else of this library or of RCCL has created a stream).  HIP serves a
+// process's streams from four hardware queues and deals them out by creation order, and how well the four chains of a depth-4
+// session overlap turned out to depend on WHERE in that order the slots' streams were created, with period four: as the first three
+// streams of the process (or behind four unused ones) 0.114 ms per step of the headline run whatever else the process does later
+// -- a dense fit with its eight streams, an RCCL communicator --, behind one or three other streams 0.137-0.145, behind two 0.16;
+// created lazily, as before, wherever the process happened to be: 0.115-0.126 alone, 0.120-0.126 after a dense fit, 0.137-0.145
+// after a dense fit beside an RCCL communicator (tools/rccl_presence.py; GPR_SESSION_POOL_LEAD = unused streams created ahead of the
+// pool, for that experiment; the synchronous step does not care).  Reserved first, the order no longer depends on what the process
+// did before its first prediction.  Pool streams live as long as the process (a
+// session hands back its cached temporaries when it ends, not the stream).  GPR_SESSION_POOL=0: a new stream per slot, as before.
+namespace {
+struct slot_pool { std::vector<hipStream_t> lead, slots; };
+std::mutex g_pool_mu;
+std::map<int, slot_pool> g_pools;
+
+int pool_reserve_locked(slot_pool &pl, int want) {
+    static const int lead_env = getenv("GPR_SESSION_POOL_LEAD") ? atoi(getenv("GPR_SESSION_POOL_LEAD")) : 0;
+    while (pl.slots.empty() && (int)pl.lead.size() < lead_env) {          // (streams nobody uses: they only take the first places)
+        hipStream_t c = nullptr;
+        GPR_HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        pl.lead.push_back(c);
+    }
+    while ((int)pl.slots.size() < want) {
+        hipStream_t c = nullptr;
+        GPR_HIP_TRY(hipStreamCreateWithFlags(&c, hipStreamNonBlocking));
+        pl.slots.push_back(c);
+    }
+    return GPR_OK;
+}
+bool pool_enabled() {
+    static const bool on = !(getenv("GPR_SESSION_POOL") && atoi(getenv("GPR_SESSION_POOL")) == 0);
+    return on;
+}
+}  // namespace
+
+// reserve the slot streams of the current device now (idempotent; the streams of slots 1 .. 3, what the default depths use)
+extern "C" int gpr_dot2_session_reserve_streams(void) {
+    if (!pool_enabled()) return GPR_OK;
+    int devid = 0;
+    GPR_HIP_TRY(hipGetDevice(&devid));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    return pool_reserve_locked(g_pools[devid], 3);
+}
+
 // a private stream for slot k >= 1: behind everything queued on the session's stream so far (the model arrays)
 static int session_slot_stream(gpr_dot2_session *s, session_slot &sl) {
     if (sl.has_stream) return GPR_OK;
     if (!s->model_ready) GPR_HIP_TRY(hipEventCreateWithFlags(&s->model_ready, hipEventDisableTiming));
-    GPR_HIP_TRY(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
-    sl.own_stream = sl.has_stream = true;
+    if (pool_enabled()) {
+        int devid = 0;
+        GPR_HIP_TRY(hipGetDevice(&devid));
+        const int k = (int)(&sl - s->slot);
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        slot_pool &pl = g_pools[devid];
+        const int rc = pool_reserve_locked(pl, k);
+        if (rc) return rc;
+        sl.st = pl.slots[(size_t)k - 1];
+        sl.own_stream = false; sl.pooled = true; sl.has_stream = true;
+    } else {
+        GPR_HIP_TRY(hipStreamCreateWithFlags(&sl.st, hipStreamNonBlocking));
+        sl.own_stream = sl.has_stream = true;
+    }
     GPR_HIP_TRY(hipEventRecord(s->model_ready, s->st));
     GPR_HIP_TRY(hipStreamWaitEvent(sl.st, s->model_ready, 0));
     return GPR_OK;

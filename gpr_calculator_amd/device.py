@@ -22,6 +22,9 @@ def device():
     d = _DEVICES.get(idx)
     if d is None:
         d = _DEVICES[idx] = torch.device("cuda", idx)
+        # first use of this device: the prediction session's slot streams take their place in the process's stream order now,
+        # before the factorisation's look-ahead context, RCCL or anything else creates streams (csrc/predict.hip: the pool)
+        _lib.lib().gpr_dot2_session_reserve_streams()
     return d
 
 

@@ -219,6 +219,12 @@ int gpr_dot2_session_set_depth(gpr_dot2_session *s, int depth);
  * stream-ordered temporaries that still remember `stream` (any != 0: all streams) -- zero for every slot stream once
  * gpr_dot2_session_destroy has returned. */
 void *gpr_dot2_session_slot_stream(gpr_dot2_session *s, int k);
+/* Slots 1.. take their streams from a pool per device.  HIP deals a process's streams to four hardware queues by creation order, and
+ * how well the chains of a depth-4 session overlap depends on where in that order the slots' streams were created (0.115 - 0.145 ms per
+ * step of the headline run): call this at the first use of a device, before anything else creates streams, and the place is fixed.
+ * Idempotent.  GPR_SESSION_POOL=0: a new stream per slot at its first use instead; GPR_SESSION_POOL_LEAD: unused streams created
+ * ahead of the pool (default 0; 1 - 3 are measurably worse, 4 is 0 again). */
+int gpr_dot2_session_reserve_streams(void);
 int gpr_dev_cache_count(void *stream, int any);
 
 /* Kernel-only timing of the block launches with HIP events recorded on the launch stream (used by
