@@ -1,6 +1,10 @@
 """What an initialised RCCL communicator costs the pipelined prediction of the SAME process (one rank; no collective inside the
 timed loop): host time of a submission, of a collection, and the step, with and without the process group.
-usage (under torch.distributed.run --nproc-per-node 1): GPR_DIST_FORCE=1 python tools/rccl_presence.py [nccl|gloo|none]"""
+usage (nccl / gloo: under torch.distributed.run --nproc-per-node 1): python tools/rccl_presence.py [nccl|gloo|none]
+  PRESENCE_DENSE_FIT=1        a dense fit first (its look-ahead context creates eight streams before the first prediction)
+  PRESENCE_EXTRA_STREAMS=n    n unrelated torch streams created before the first prediction
+  GPR_SESSION_POOL_LEAD=n     n unused streams ahead of the session's slot-stream pool; GPR_SESSION_POOL=0: streams per slot, lazily
+what came out of it: profiles/r04_stream_order.log, DESIGN section 7 "Round 4, last"."""
 import os, sys, time
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np, torch
